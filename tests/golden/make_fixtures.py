@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container, where the reference checkout is mounted read-only at
+/root/reference; nothing on the GPU box or in the product path reads it.  The reference
+is imported unchanged.  Four modules it imports at package level but never uses on the
+model/audio path are absent from this image (yt_dlp, inflect, wandb, g2p_en) and are
+registered as empty stand-ins before the import.
+
+What is written (inputs + expected outputs only, no reference code):
+  tf_*.npz     teacher-forced Tacotron2.forward: batch, bit-packed Prenet keep masks,
+               the four outputs and intermediate taps
+  ar_*.npz     autoregressive Tacotron2.inference (batch 1): tokens, per-step masks, outputs
+  audio.npz    mel basis / pseudo-inverse, STFT / iSTFT, Griffin-Lim phases, convert_mel2wav
+
+Weights are NOT stored: they are regenerated from genvox_amd.weights (seed, dims) and
+loaded INTO the reference with load_state_dict.
+
+Usage:  python tests/golden/make_fixtures.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+
+for _name in ("yt_dlp", "inflect", "wandb", "g2p_en"):
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+sys.modules["inflect"].engine = lambda *a, **k: None
+sys.modules["g2p_en"].G2p = lambda *a, **k: None
+sys.path.insert(0, REFERENCE)
+sys.path.insert(1, REPO)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import configs as ref_configs  # noqa: E402  (reference)
+from configs.models import Tacotron2Config as RefTacotron2Config  # noqa: E402  (reference)
+from models.tts.tacotron2 import Tacotron2 as RefTacotron2  # noqa: E402  (reference)
+from core.processors import AudioProcessor as RefAudioProcessor  # noqa: E402  (reference)
+from utils.audio import base as ref_audio  # noqa: E402  (reference)
+
+from genvox_amd import weights as gw  # noqa: E402
+from tests.golden.cases import AR_CASES, AUDIO_CASE, TF_CASES, case_configs  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def build_reference_model(case):
+    mc, ac, tc = case_configs(case)
+    ref_tc = ref_configs.TextConfig()
+    ref_tc.n_tokens = tc.n_tokens
+    ref_ac = ref_configs.AudioConfig(**{k: v for k, v in ac.to_dict().items()})
+    ref_mc = RefTacotron2Config(**{k: v for k, v in mc.to_dict().items()})
+    model = RefTacotron2(ref_mc, ref_ac, ref_tc).eval()
+    sd = gw.generate_state_dict(mc, ac, tc, seed=case["weight_seed"], peaky_attention=case.get("peaky", False))
+    model.load_state_dict(sd, strict=True)
+    return model, (mc, ac, tc)
+
+
+def draw_keep_masks(seed, shape, n_pairs=1):
+    """The reference consumes torch's CPU RNG only in the two Prenet dropouts (eval mode),
+    so after manual_seed(s) its masks equal these draws, in this order."""
+    torch.manual_seed(seed)
+    out = []
+    for _ in range(n_pairs):
+        pair = [(F.dropout(torch.ones(*shape), 0.5, True) > 0).to(torch.uint8) for _ in range(2)]
+        out.append(torch.stack(pair))
+    return out
+
+
+def make_tf_case(name, case):
+    model, (mc, ac, tc) = build_reference_model(case)
+    B, L, T = case["B"], case["L"], case["T"]
+    inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=case["input_seed"],
+                              token_lengths=case["token_lengths"], mel_lengths=case["mel_lengths"])
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    masks = draw_keep_masks(case["mask_seed"], (T + 1, B, mc.prenet_dim))[0]  # [2, T+1, B, P]
+
+    taps = {"ctx": []}
+    hooks = [
+        model.encoder.register_forward_hook(lambda m, i, o: taps.__setitem__("encoder_outputs", o.detach().clone())),
+        model.decoder.prenet.register_forward_hook(lambda m, i, o: taps.__setitem__("prenet_outputs", o.detach().clone())),
+        model.decoder.attention_layer.memory_layer.register_forward_hook(
+            lambda m, i, o: taps.__setitem__("processed_memory", o.detach().clone())),
+        model.decoder.attention_layer.register_forward_hook(lambda m, i, o: taps["ctx"].append(o[0].detach().clone())),
+    ]
+    torch.manual_seed(case["mask_seed"])
+    with torch.no_grad():
+        out = model.forward({k: v.clone() for k, v in batch.items()})
+    for h in hooks:
+        h.remove()
+    # the masks above really are what the reference drew: its prenet output must be reproduced exactly
+    x = torch.cat((torch.zeros(1, B, ac.n_mels), batch["mel_padded"].permute(2, 0, 1)), 0)
+    w0 = model.decoder.prenet.layers[0].linear_layer.weight
+    w1 = model.decoder.prenet.layers[1].linear_layer.weight
+    chk = torch.relu(torch.relu(x @ w0.t()) * masks[0] * 2 @ w1.t()) * masks[1] * 2
+    assert torch.equal(chk, taps["prenet_outputs"]), "mask extraction does not reproduce the reference's Prenet"
+
+    np.savez_compressed(
+        os.path.join(HERE, f"{name}.npz"),
+        **{k: v for k, v in inp.items()},
+        keep_masks_packed=np.packbits(masks.numpy().reshape(2, -1), axis=1),
+        mel_outputs=out["mel_outputs"].numpy(), mel_outputs_postnet=out["mel_outputs_postnet"].numpy(),
+        gate_outputs=out["gate_outputs"].numpy(), alignments=out["alignments"].numpy(),
+        encoder_outputs=taps["encoder_outputs"].numpy(), processed_memory=taps["processed_memory"].numpy(),
+        prenet_outputs=taps["prenet_outputs"].numpy(), attention_contexts=torch.stack(taps["ctx"], 1).numpy(),
+    )
+    a = out["alignments"]
+    print(f"{name}: mel_post |max| {out['mel_outputs_postnet'].abs().max():.3f}  max alignment {a.max():.3f}")
+
+
+def make_ar_case(name, case):
+    model, (mc, ac, tc) = build_reference_model(case)
+    L, steps = case["L"], case["max_decoder_steps"]
+    tokens = (gw.hashed_uniform(case["input_seed"], "ar_tokens", L) * tc.n_tokens).astype(np.int64)[None, :]
+    pairs = draw_keep_masks(case["mask_seed"], (1, mc.prenet_dim), n_pairs=steps)
+    masks = torch.stack(pairs, dim=1).squeeze(2)  # [2, steps, P]
+
+    def run(threshold):
+        model.decoder.gate_threshold = threshold
+        model.decoder.max_decoder_steps = steps
+        torch.manual_seed(case["mask_seed"])
+        return model.inference({"tokens": torch.from_numpy(tokens).int()})
+
+    out = run(1.0)  # never fires: exactly `steps` frames
+    assert out["mel_outputs"].shape[2] == steps
+    threshold = 1.0
+    if case["gate_fires"]:
+        # choose a threshold the sigmoid(gate) track first crosses at a step well inside the run
+        sig = torch.sigmoid(out["gate_outputs"][0]).numpy()
+        lo, hi = steps // 4, (3 * steps) // 4
+        k = lo + int(np.argmax(sig[lo:hi]))
+        prior = float(sig[:k].max())
+        if sig[k] > prior:
+            threshold = float((prior + sig[k]) / 2)
+        else:  # pick the last record-setting step instead
+            rec = [i for i in range(1, steps) if sig[i] > sig[:i].max()]
+            k = rec[-1]
+            threshold = float((sig[:k].max() + sig[k]) / 2)
+        out = run(threshold)
+        assert out["mel_outputs"].shape[2] == k + 1, (out["mel_outputs"].shape, k)
+    np.savez_compressed(
+        os.path.join(HERE, f"{name}.npz"),
+        tokens=tokens, keep_masks_packed=np.packbits(masks.numpy().reshape(2, -1), axis=1),
+        gate_threshold=np.float64(threshold), max_decoder_steps=np.int64(steps),
+        mel_outputs=out["mel_outputs"].numpy(), mel_outputs_postnet=out["mel_outputs_postnet"].numpy(),
+        gate_outputs=out["gate_outputs"].numpy(), alignments=out["alignments"].numpy(),
+    )
+    print(f"{name}: frames {out['mel_outputs'].shape[2]} threshold {threshold:.6f}")
+
+
+def make_audio_case():
+    c = AUDIO_CASE
+    ref_ac = ref_configs.AudioConfig(sampling_rate=c["fs"], filter_length=c["n_fft"], hop_length=c["hop"],
+                                     n_mels=c["n_mels"], mel_fmin=c["fmin"], mel_fmax=c["fmax"],
+                                     log_func=c["log_func"], ref_level_db=c["ref"])
+    ap = RefAudioProcessor(ref_ac)
+    n_fft, hop, T = c["n_fft"], c["hop"], c["frames"]
+    n = n_fft + (T - 1) * hop
+    t = np.arange(n) / c["fs"]
+    u = gw.hashed_uniform(c["seed"], "audio_noise", n)
+    sig = (0.45 * np.sin(2 * np.pi * (220 + 900 * t) * t) + 0.25 * np.sin(2 * np.pi * 1330 * t)
+           + 0.05 * (2 * u - 1)).astype(np.float32)
+    spec = ref_audio.stft(sig, n_fft, hop)
+    back = ref_audio.istft(spec, n_fft, hop)
+    mel_amp = ref_audio.fft2mel(np.abs(spec), ap.mel_basis)
+    mel_db = ref_audio.amplitude_to_db(mel_amp, log_func=c["log_func"], ref=c["ref"], power=False, scale=1)
+    mag = ref_audio.mel2fft(ref_audio.db_to_amplitude(mel_db.copy(), log_func=c["log_func"], ref=c["ref"],
+                                                      power=False, scale=1), ap.inverse_mel_basis)
+    gl = {f"gl_phase_{k}": ref_audio.griffin_lim(mag, n_fft, hop, n_iter=k) for k in (1, 2, 32)}
+    fs, wav = ap.convert_mel2wav(mel_db.copy())
+    np.savez_compressed(
+        os.path.join(HERE, "audio.npz"), signal=sig, stft_real=spec.real, stft_imag=spec.imag, istft=back,
+        mel_basis=ap.mel_basis, inverse_mel_basis=ap.inverse_mel_basis, mel_db=mel_db.astype(np.float32),
+        mag=mag.astype(np.float32), wav=wav, fs=np.int64(fs), **gl)
+    print(f"audio: frames {T} wav {wav.shape} {wav.dtype} neg-mag-frac {(mag < 0).mean():.4f}")
+
+
+if __name__ == "__main__":
+    for name, case in TF_CASES.items():
+        make_tf_case(name, case)
+    for name, case in AR_CASES.items():
+        make_ar_case(name, case)
+    make_audio_case()

@@ -1,0 +1,73 @@
+"""CPU: the oracle (oracle/) against the golden fixtures produced by the reference itself.
+This is what pins the oracle; the GPU parity tests then compare the HIP path with both."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio_ref, tacotron2_ref
+from tests.golden.cases import AR_CASES, AUDIO_CASE, TF_CASES, case_configs
+from tests.helpers import case_state_dict, load_fixture, max_abs_diff, tf_batch, unpack_masks
+
+ORACLE_TOL = 2e-5  # the reference's own fp32-vs-fp64 drift is ~2e-6
+
+
+@pytest.mark.parametrize("name", list(TF_CASES))
+def test_teacher_forced_oracle_matches_reference(name):
+    case, fx = TF_CASES[name], load_fixture(name)
+    mc, ac, tc = case_configs(case)
+    sd = case_state_dict(name)
+    B, T = case["B"], case["T"]
+    masks = unpack_masks(fx["keep_masks_packed"], (2, (T + 1) * B, mc.prenet_dim))
+    out = tacotron2_ref.tacotron2_forward(sd, tf_batch(fx), masks, mask_padding=mc.mask_padding, taps=True)
+    for key in ("encoder_outputs", "processed_memory", "prenet_outputs", "attention_contexts",
+                "alignments", "gate_outputs", "mel_outputs", "mel_outputs_postnet"):
+        d = max_abs_diff(out[key], fx[key])
+        assert d <= ORACLE_TOL, f"{name}/{key}: {d}"
+    # padding semantics: zero mels, gate 1e3, zero encoder rows past each length
+    for b in range(B):
+        ml, tl = int(fx["mel_lengths"][b]), int(fx["token_lengths"][b])
+        assert torch.all(out["mel_outputs_postnet"][b, :, ml:] == 0)
+        assert torch.all(out["gate_outputs"][b, ml:] == 1e3)
+        assert torch.all(out["encoder_outputs"][b, tl:] == 0)
+        assert torch.all(out["alignments"][b, :, tl:] == 0)
+
+
+@pytest.mark.parametrize("name", list(AR_CASES))
+def test_autoregressive_oracle_matches_reference(name):
+    case, fx = AR_CASES[name], load_fixture(name)
+    mc, ac, tc = case_configs(case)
+    sd = case_state_dict(name)
+    steps = int(fx["max_decoder_steps"])
+    masks = unpack_masks(fx["keep_masks_packed"], (2, steps, mc.prenet_dim))
+    out = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(fx["tokens"]), masks,
+                                            float(fx["gate_threshold"]), steps)
+    assert out["mel_outputs"].shape == fx["mel_outputs"].shape
+    if case["gate_fires"]:
+        assert out["mel_outputs"].shape[2] < steps
+    for key in ("alignments", "gate_outputs", "mel_outputs", "mel_outputs_postnet"):
+        d = max_abs_diff(out[key], fx[key])
+        assert d <= ORACLE_TOL, f"{name}/{key}: {d}"
+
+
+def test_audio_oracle_matches_reference():
+    c, fx = AUDIO_CASE, load_fixture("audio")
+    n_fft, hop = c["n_fft"], c["hop"]
+    basis = audio_ref.mel_filter(c["fs"], n_fft, c["n_mels"], c["fmin"], c["fmax"])
+    assert basis.dtype == np.float32 and np.array_equal(basis, fx["mel_basis"])
+    inv = audio_ref.inverse_mel_filter(basis)
+    assert max_abs_diff(inv, fx["inverse_mel_basis"]) <= 1e-6
+    spec = audio_ref.stft(fx["signal"], n_fft, hop)
+    assert spec.dtype == np.complex64
+    assert np.array_equal(spec.real, fx["stft_real"]) and np.array_equal(spec.imag, fx["stft_imag"])
+    assert np.array_equal(audio_ref.istft(spec, n_fft, hop), fx["istft"])
+    mag = np.matmul(fx["inverse_mel_basis"], audio_ref.db_to_amplitude(fx["mel_db"], c["log_func"], c["ref"]))
+    assert max_abs_diff(mag, fx["mag"]) <= 1e-6
+    for k in (1, 2, 32):
+        ph = audio_ref.griffin_lim(fx["mag"], n_fft, hop, n_iter=k)
+        # phases are compared on the unit circle (wrap-around safe)
+        d = np.abs(np.exp(1j * ph) - np.exp(1j * fx[f"gl_phase_{k}"])).max()
+        assert d <= 1e-4, (k, d)
+    fs, wav = audio_ref.convert_mel2wav(fx["mel_db"].copy(), fx["inverse_mel_basis"], c["fs"], n_fft, hop,
+                                        c["log_func"], c["ref"])
+    assert fs == int(fx["fs"]) and wav.shape == fx["wav"].shape and wav.dtype == np.float64
+    assert max_abs_diff(wav, fx["wav"]) <= 1e-4

@@ -1,0 +1,75 @@
+"""ctypes binding of libgenvox_amd.so (C ABI declared in include/genvox_amd.h).
+
+There is no fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgenvox_amd.so")
+
+
+class GvxError(RuntimeError):
+    pass
+
+
+class gvx_dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_tokens", "embed_dim", "enc_kernel", "enc_n_conv", "prenet_dim", "att_rnn_dim", "dec_rnn_dim", "att_dim",
+        "att_loc_filters", "att_loc_kernel", "postnet_dim", "postnet_kernel", "postnet_n_conv", "n_mels")]
+
+
+class gvx_weight_desc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+_vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); every symbol include/genvox_amd.h declares
+SIGNATURES = {
+    "gvx_last_error": (C.c_char_p, []),
+    "gvx_version": (_i, []),
+    "gvx_model_create": (_i, [C.POINTER(gvx_dims), C.POINTER(_vp)]),
+    "gvx_model_destroy": (None, [_vp]),
+    "gvx_model_blob_bytes": (_sz, [_vp]),
+    "gvx_model_pack_weights": (_i, [_vp, C.POINTER(gvx_weight_desc), _i, _vp]),
+    "gvx_model_bind_blob": (_i, [_vp, _vp]),
+    "gvx_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "gvx_encoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "gvx_decoder_teacher_forced": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_decoder_autoregressive": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp, _sz, _vp]),
+    "gvx_postnet_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "gvx_mask_padding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "gvx_tacotron2_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_prenet_masks_generate": (_i, [_vp, _sz, C.c_uint64, _vp]),
+    "gvx_stage_timing_enable": (_i, [_vp, _i]),
+    "gvx_stage_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library once; raise ImportError with the build recipe if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the gfx950 library first (python -m genvox_amd.build, or "
+            f"__graft_entry__.build()). genvox_amd has no CPU or eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().gvx_last_error()
+        raise GvxError(f"genvox_amd error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,54 @@
+"""Build recipe for the gfx950 shared library (hipcc, in-tree, no JIT cache).
+
+    python -m genvox_amd.build          # or __graft_entry__.build()
+
+Produces genvox_amd/libgenvox_amd.so next to this file; the .so is git-ignored but travels
+with the tree to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgenvox_amd.so")
+SOURCES = ["gemm_f32.hip", "skinny.hip", "attention.hip", "misc.hip", "gvx_api.hip"]
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+            "-ffp-contract=off"]  # keep a*b+c as written: fused/unfused choices are explicit (fmaf) in the kernels
+
+
+def _newer(a: str, b: str) -> bool:
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    objs, jobs = [], []
+    headers = [os.path.join(CSRC, "gvx_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "genvox_amd.h")]
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(s, o) or any(_newer(h, o) for h in headers):
+            jobs.append([HIPCC, *CXXFLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

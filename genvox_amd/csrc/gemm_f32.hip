@@ -1,0 +1,185 @@
+// Dense fp32 GEMM on the gfx950 f32 matrix instruction (v_mfma_f32_32x32x2_f32): exact fp32,
+// bit-for-bit a k-ordered fmaf chain per output, which is what the 1e-3 parity budget needs
+// (bf16/f16 MFMA inputs would not fit it; there is no xf32 on gfx950).
+//
+// Used for every "dense over all positions" contraction on the path:
+//   encoder convs, encoder LSTM input projection, memory projection, Prenet, mel/gate projection
+//   (teacher-forced: hoisted out of the step loop), Postnet convs.
+// conv1d(k, pad (k-1)/2) is an implicit GEMM: activations are kept channels-last with a zero halo,
+// [B][T+2p][C], so the im2col row of (b,t) is simply the 5*C contiguous floats starting at row t
+// of the padded buffer - no gather, no materialised im2col.  The conv weight is repacked at load
+// time to [Cout][k][Cin] with eval-mode BatchNorm folded in.
+//
+// Tile: 256 threads = 4 waves, BK = 32, LDS double buffered through registers.
+//   <2,2,2,2>: 128x128 tile, each wave 64x64 (2x2 MFMA tiles)       - general case
+//   <4,1,1,3>: 128x96 tile, each wave 32x96 (1x3 MFMA tiles)        - N <= 96 (the last Postnet conv, N = 80)
+//   <4,1,1,1>: 128x32                                              - N <= 32
+// LDS rows are 36 floats (144 B): with that stride the ds_read_b128 fragment reads of the
+// sixteen-lane groups fall on distinct 16-byte bank slots (conflict free).
+// MFMA operand trick: one float4 per lane feeds four k-steps (k = 8*kg + 4*(lane>>5) + s), so both
+// operands are read as 16-byte vectors from K-contiguous rows; the k order inside a group of 8 is
+// permuted, which only reorders the fp32 summation.
+#include "gvx_kernels.h"
+
+namespace gvx {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;
+
+__device__ __forceinline__ long row_off(const RowMap& m, int row) {
+    return (long)(row / m.R) * m.s1 + (long)(row % m.R) * m.s0;
+}
+
+template <int WR, int WC, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
+    constexpr int BM = WR * TM * 32;
+    constexpr int BN = WC * TN * 32;
+    constexpr int A_V4 = BM / 32;  // float4 loads per thread for the A tile
+    constexpr int B_V4 = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                         // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int r = lane & 31, h = lane >> 5;
+    // consecutive blocks share the W panel (same n-tile) -> neighbouring M tiles stay in one L2
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x % n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // global -> register staging assignments
+    const int ld_row = tid >> 3, ld_c4 = tid & 7;
+    const float* a_ptr[A_V4]; bool a_ok[A_V4];
+    const float* b_ptr[B_V4]; bool b_ok[B_V4];
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) {
+        int m = m0 + ld_row + 32 * i;
+        a_ok[i] = m < p.M;
+        a_ptr[i] = p.A + (a_ok[i] ? row_off(p.amap, m) : 0) + 4 * ld_c4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) {
+        int n = n0 + ld_row + 32 * i;
+        b_ok[i] = n < p.N;
+        b_ptr[i] = p.W + (b_ok[i] ? (long)n * p.ldw : 0) + 4 * ld_c4;
+    }
+    float4 a_reg[A_V4], b_reg[B_V4];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_tile = [&](int k0) {
+        const bool k_ok = (k0 + 4 * ld_c4) < p.K;
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i)
+            a_reg[i] = (a_ok[i] && k_ok) ? *reinterpret_cast<const float4*>(a_ptr[i] + k0) : zero4;
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i)
+            b_reg[i] = (b_ok[i] && k_ok) ? *reinterpret_cast<const float4*>(b_ptr[i] + k0) : zero4;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i)
+            *reinterpret_cast<float4*>(&As[(buf * BM + ld_row + 32 * i) * LDS_LD + 4 * ld_c4]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i)
+            *reinterpret_cast<float4*>(&Bs[(buf * BN + ld_row + 32 * i) * LDS_LD + 4 * ld_c4]) = b_reg[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int nkt = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile((kt + 1) * BK);
+        const float* a_base = &As[(cur * BM + wr * TM * 32 + r) * LDS_LD + 4 * h];
+        const float* b_base = &Bs[(cur * BN + wc * TN * 32 + r) * LDS_LD + 4 * h];
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDS_LD + 8 * kg);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDS_LD + 8 * kg);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[row][col] with col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + (wr * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (m >= p.M) continue;
+            const long c_off = row_off(p.cmap, m);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wc * TN + j) * 32 + r;
+                if (n >= p.N) continue;
+                float v = acc[i][j][q];
+                if (p.bias) v += p.bias[n];
+                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == ACT_TANH) v = tanhf(v);
+                if (p.keep) v = p.keep[(long)m * p.keep_ld + n] ? 2.f * v : 0.f;
+                p.C[c_off + n] = v;
+            }
+        }
+    }
+}
+
+template <int WR, int WC, int TM, int TN>
+static size_t lds_bytes_cfg() { return (size_t)2 * (WR * TM * 32 + WC * TN * 32) * LDS_LD * sizeof(float); }
+
+template <int WR, int WC, int TM, int TN>
+static hipError_t init_cfg() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<WR, WC, TM, TN>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_cfg<WR, WC, TM, TN>());
+}
+
+hipError_t gemm_init() {
+    hipError_t e = init_cfg<2, 2, 2, 2>();
+    if (e != hipSuccess) return e;
+    e = init_cfg<4, 1, 1, 3>();
+    if (e != hipSuccess) return e;
+    return init_cfg<4, 1, 1, 1>();
+}
+
+template <int WR, int WC, int TM, int TN>
+static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    gemm_f32_kernel<WR, WC, TM, TN><<<dim3(grid), dim3(256), lds_bytes_cfg<WR, WC, TM, TN>(), s>>>(p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if (p.K & 3) return hipErrorInvalidValue;
+    if (p.N <= 32) return launch_cfg<4, 1, 1, 1>(p, s);
+    if (p.N <= 96) return launch_cfg<4, 1, 1, 3>(p, s);
+    return launch_cfg<2, 2, 2, 2>(p, s);
+}
+
+}  // namespace gvx

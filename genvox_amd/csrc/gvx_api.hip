@@ -1,0 +1,796 @@
+// C-ABI of the MI355X Tacotron2 forward path (include/genvox_amd.h): model handle, host-side weight
+// packing (BatchNorm folding, LSTM gate-row permutation, MFMA-fragment layout), workspace planning and
+// the launch sequences of the encoder, the teacher-forced / autoregressive decoder and the Postnet.
+//
+// Data layout in HBM (all fp32):
+//   activations are channels-last; conv inputs carry a zero halo of (k-1)/2 rows per sequence
+//       encoder   x[B][L+2p][E]         memory[B][L][E]        pm[B][L][a]        xg[B][L][2*4H]
+//       decoder   frames[(T+1)*B][M]    prenet[(T+1)*B][P]     (time-major: one step's rows are contiguous)
+//                 hc[T+1][B][D+E]       slot s holds [h_d ; ctx] after step s-1 (slot 0 = zeros); it is at
+//                                       once the LSTM input of the next step and the A operand of the hoisted
+//                                       mel/gate projection GEMM over all T*B rows
+//                 h_a[2][B][A] (ping-pong), c_a[B][A], c_d[B][D], w_cum[B][L], q_slab[A/8][B][a]
+//       postnet   y[B][T+2p][C]
+//   weights live in one packed blob (see pack_weights) so that multi-GPU start-up is a single broadcast.
+#include "../../include/genvox_amd.h"
+#include "gvx_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace gvx {
+hipError_t skinny_init();
+hipError_t gemm_init();
+hipError_t attention_init();
+}  // namespace gvx
+
+using namespace gvx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) return fail(GVX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+constexpr int MAX_CONV = 8;
+constexpr double BN_EPS = 1e-5;
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Blob {  // offsets in floats into the packed weight blob
+    size_t emb;
+    size_t enc_w[MAX_CONV], enc_b[MAX_CONV];
+    size_t enc_wih, enc_bih, enc_whh_frag[2];
+    size_t pre_w0, pre_w1, pre_w0_frag, pre_w1_frag;
+    size_t att_frag, att_bias, wq_t, wmem, v, loc_conv, loc_dense;
+    size_t dec_frag, dec_bias;
+    size_t proj_w, proj_b, proj_frag;
+    size_t post_w[MAX_CONV], post_b[MAX_CONV];
+    size_t total;
+};
+
+inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 8) * 64 * 4; }
+
+struct WsPlan {  // byte offsets into the caller's workspace
+    size_t xa, xb, xg, enc_h, enc_c, flags, memory;
+    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj;
+    size_t ya, yb;
+    size_t total;
+};
+
+}  // namespace
+
+struct gvx_model {
+    gvx_dims d;
+    Blob blob;
+    const float* dev_blob = nullptr;
+    bool timing = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    int last_decoder_launches = 0;
+    // derived
+    int H() const { return d.embed_dim / 2; }
+    int PS() const { return (d.n_mels + 1 + 3) & ~3; }  // padded row stride of the mel+gate projection
+};
+
+namespace {
+
+Blob make_blob_layout(const gvx_dims& d) {
+    Blob b{};
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off = align_up(off + n, 64); return o; };
+    const int E = d.embed_dim, H = E / 2, M = d.n_mels, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim;
+    b.emb = take((size_t)d.n_tokens * E);
+    for (int i = 0; i < d.enc_n_conv; ++i) { b.enc_w[i] = take((size_t)E * d.enc_kernel * E); b.enc_b[i] = take(E); }
+    b.enc_wih = take((size_t)8 * H * E);
+    b.enc_bih = take((size_t)8 * H);
+    for (int dir = 0; dir < 2; ++dir) b.enc_whh_frag[dir] = take(frag_floats(4 * H, H));
+    b.pre_w0 = take((size_t)P * M); b.pre_w1 = take((size_t)P * P);
+    b.pre_w0_frag = take(frag_floats(P, M)); b.pre_w1_frag = take(frag_floats(P, P));
+    b.att_frag = take(frag_floats(4 * A, P + E + A)); b.att_bias = take((size_t)4 * A);
+    b.wq_t = take((size_t)A * d.att_dim);
+    b.wmem = take((size_t)d.att_dim * E); b.v = take(d.att_dim);
+    b.loc_conv = take((size_t)d.att_loc_filters * 2 * d.att_loc_kernel);
+    b.loc_dense = take((size_t)d.att_dim * d.att_loc_filters);
+    b.dec_frag = take(frag_floats(4 * D, A + E + D)); b.dec_bias = take((size_t)4 * D);
+    b.proj_w = take((size_t)(M + 1) * (D + E)); b.proj_b = take(M + 1);
+    b.proj_frag = take(frag_floats(M + 1, D + E));
+    for (int i = 0; i < d.postnet_n_conv; ++i) {
+        const int cin = i == 0 ? M : d.postnet_dim, cout = i == d.postnet_n_conv - 1 ? M : d.postnet_dim;
+        b.post_w[i] = take((size_t)cout * d.postnet_kernel * cin);
+        b.post_b[i] = take(cout);
+    }
+    b.total = off;
+    return b;
+}
+
+WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
+    const gvx_dims& d = m->d;
+    const int E = d.embed_dim, H = E / 2, M = d.n_mels, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim;
+    const int pe = (d.enc_kernel - 1) / 2, pp = (d.postnet_kernel - 1) / 2;
+    WsPlan w{};
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
+    w.xa = take((size_t)B * (L + 2 * pe) * E);
+    w.xb = take((size_t)B * (L + 2 * pe) * E);
+    w.xg = take((size_t)B * L * 8 * H);
+    w.enc_h = take((size_t)2 * 2 * B * H);
+    w.enc_c = take((size_t)2 * B * H);
+    w.flags = take(64);  // [0] token error, [1] AR rows done
+    w.memory = take((size_t)B * L * E);  // encoder output of the fused forward
+    w.pm = take((size_t)B * L * d.att_dim);
+    w.frames = take((size_t)(T + 1) * B * M);
+    w.pre1 = take((size_t)(T + 1) * B * P);
+    w.prenet = take((size_t)(T + 1) * B * P);
+    w.h_a = take((size_t)2 * B * A);
+    w.c_a = take((size_t)B * A);
+    w.c_d = take((size_t)B * D);
+    w.hc = take((size_t)(T + 1) * B * (D + E));
+    w.w_cum = take((size_t)B * L);
+    w.q_slab = take((size_t)(A / 8) * B * d.att_dim);
+    w.proj = take((size_t)B * T * m->PS());
+    const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
+    w.ya = take((size_t)B * (T + 2 * pp) * cmax);
+    w.yb = take((size_t)B * (T + 2 * pp) * cmax);
+    w.total = off;
+    return w;
+}
+
+template <typename T>
+T* ws_ptr(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
+
+int check_dims(const gvx_dims& d) {
+    if (d.n_tokens < 1) return fail(GVX_ERR_INVALID_ARG, "n_tokens must be >= 1");
+    const int dims8[] = {d.embed_dim, d.prenet_dim, d.att_rnn_dim, d.dec_rnn_dim, d.att_dim, d.postnet_dim, d.n_mels};
+    const char* names[] = {"embed_dim", "prenet_dim", "att_rnn_dim", "dec_rnn_dim", "att_dim", "postnet_dim", "n_mels"};
+    for (int i = 0; i < 7; ++i)
+        if (dims8[i] < 8 || dims8[i] % 8) return fail(GVX_ERR_UNSUPPORTED, "%s = %d must be a positive multiple of 8", names[i], dims8[i]);
+    if (d.embed_dim % 16) return fail(GVX_ERR_UNSUPPORTED, "embed_dim = %d must be a multiple of 16 (BiLSTM halves are multiples of 8)", d.embed_dim);
+    if (d.att_dim > 256) return fail(GVX_ERR_UNSUPPORTED, "att_dim = %d > 256 is not supported", d.att_dim);
+    if (d.att_loc_filters < 1 || d.att_loc_filters > 32) return fail(GVX_ERR_UNSUPPORTED, "att_loc_filters = %d must be in [1, 32]", d.att_loc_filters);
+    const int ks[] = {d.enc_kernel, d.att_loc_kernel, d.postnet_kernel};
+    for (int k : ks)
+        if (k < 1 || k % 2 == 0) return fail(GVX_ERR_UNSUPPORTED, "kernel size %d must be odd (the reference pads (k-1)/2 on both sides)", k);
+    if (d.enc_n_conv < 1 || d.enc_n_conv > MAX_CONV || d.postnet_n_conv < 1 || d.postnet_n_conv > MAX_CONV)
+        return fail(GVX_ERR_UNSUPPORTED, "number of convolutions must be in [1, %d]", MAX_CONV);
+    return GVX_OK;
+}
+
+// W: N x K row-major -> [tile][k-group][lane][4]; lane (n = lane&31, half = lane>>5) holds k = 8*kg + 4*half + 0..3
+void pack_frag(const std::vector<float>& W, int N, int K, float* out) {
+    const int ntiles = (N + 31) / 32, nkg = K / 8;
+    for (int t = 0; t < ntiles; ++t)
+        for (int kg = 0; kg < nkg; ++kg)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = t * 32 + (lane & 31), k = 8 * kg + 4 * (lane >> 5);
+                float* o = out + (((size_t)t * nkg + kg) * 64 + lane) * 4;
+                for (int s = 0; s < 4; ++s) o[s] = n < N ? W[(size_t)n * K + k + s] : 0.f;
+            }
+}
+
+struct WeightTable {
+    std::unordered_map<std::string, const gvx_weight_desc*> map;
+    const float* get(const std::string& name, int64_t numel, int* rc) const {
+        auto it = map.find(name);
+        if (it == map.end()) { *rc = fail(GVX_ERR_MISSING_WEIGHT, "missing weight '%s'", name.c_str()); return nullptr; }
+        if (it->second->numel != numel) {
+            *rc = fail(GVX_ERR_SHAPE, "weight '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second->numel, (long long)numel);
+            return nullptr;
+        }
+        return it->second->data;
+    }
+};
+
+// conv (+ eval BatchNorm) -> [Cout][k][Cin] with the BN scale folded in, bias' = (b - mean) * scale + beta
+int pack_conv(const WeightTable& wt, const std::string& prefix, int cout, int cin, int k, float* w_out, float* b_out) {
+    int rc = GVX_OK;
+    const float* w = wt.get(prefix + ".0.conv.weight", (int64_t)cout * cin * k, &rc); if (!w) return rc;
+    const float* b = wt.get(prefix + ".0.conv.bias", cout, &rc); if (!b) return rc;
+    const float* g = wt.get(prefix + ".1.weight", cout, &rc); if (!g) return rc;
+    const float* beta = wt.get(prefix + ".1.bias", cout, &rc); if (!beta) return rc;
+    const float* mu = wt.get(prefix + ".1.running_mean", cout, &rc); if (!mu) return rc;
+    const float* var = wt.get(prefix + ".1.running_var", cout, &rc); if (!var) return rc;
+    for (int co = 0; co < cout; ++co) {
+        const double scale = (double)g[co] / std::sqrt((double)var[co] + BN_EPS);
+        for (int kk = 0; kk < k; ++kk)
+            for (int ci = 0; ci < cin; ++ci)
+                w_out[((size_t)co * k + kk) * cin + ci] = (float)((double)w[((size_t)co * cin + ci) * k + kk] * scale);
+        b_out[co] = (float)(((double)b[co] - (double)mu[co]) * scale + (double)beta[co]);
+    }
+    return GVX_OK;
+}
+
+// LSTM: rows permuted to row' = 4*j + gate, columns = [W_ih | W_hh], bias = b_ih + b_hh
+int pack_lstm(const WeightTable& wt, const std::string& wih_name, const std::string& whh_name, const std::string& bih_name,
+              const std::string& bhh_name, int Hd, int Kin, std::vector<float>* wcat, float* bias_out) {
+    int rc = GVX_OK;
+    const float* wih = wt.get(wih_name, (int64_t)4 * Hd * Kin, &rc); if (!wih) return rc;
+    const float* whh = wt.get(whh_name, (int64_t)4 * Hd * Hd, &rc); if (!whh) return rc;
+    const float* bih = wt.get(bih_name, 4 * Hd, &rc); if (!bih) return rc;
+    const float* bhh = wt.get(bhh_name, 4 * Hd, &rc); if (!bhh) return rc;
+    const int K = Kin + Hd;
+    wcat->assign((size_t)4 * Hd * K, 0.f);
+    for (int j = 0; j < Hd; ++j)
+        for (int q = 0; q < 4; ++q) {
+            const int src = q * Hd + j, dst = 4 * j + q;
+            std::memcpy(&(*wcat)[(size_t)dst * K], wih + (size_t)src * Kin, sizeof(float) * Kin);
+            std::memcpy(&(*wcat)[(size_t)dst * K + Kin], whh + (size_t)src * Hd, sizeof(float) * Hd);
+            bias_out[dst] = bih[src] + bhh[src];
+        }
+    return GVX_OK;
+}
+
+hipError_t zero_async(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); }
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* gvx_last_error(void) { return g_err.c_str(); }
+int gvx_version(void) { return 1; }
+
+int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
+    if (!dims || !out) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    int rc = check_dims(*dims);
+    if (rc != GVX_OK) return rc;
+    gvx_model* m = new gvx_model();
+    m->d = *dims;
+    m->blob = make_blob_layout(*dims);
+    *out = m;
+    return GVX_OK;
+}
+
+void gvx_model_destroy(gvx_model* m) {
+    if (!m) return;
+    if (m->ev_valid)
+        for (auto& e : m->ev) (void)hipEventDestroy(e);
+    delete m;
+}
+
+size_t gvx_model_blob_bytes(const gvx_model* m) { return m ? m->blob.total * sizeof(float) : 0; }
+
+int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, void* host_blob) {
+    if (!m || !table || !host_blob) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    WeightTable wt;
+    for (int i = 0; i < n; ++i) wt.map[table[i].name] = &table[i];
+    const gvx_dims& d = m->d;
+    const Blob& bl = m->blob;
+    float* out = reinterpret_cast<float*>(host_blob);
+    std::memset(out, 0, bl.total * sizeof(float));
+    const int E = d.embed_dim, H = E / 2, M = d.n_mels, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim, a = d.att_dim;
+    int rc = GVX_OK;
+    const float* src;
+
+    if (!(src = wt.get("embedding.weight", (int64_t)d.n_tokens * E, &rc))) return rc;
+    std::memcpy(out + bl.emb, src, sizeof(float) * d.n_tokens * E);
+
+    for (int i = 0; i < d.enc_n_conv; ++i) {
+        rc = pack_conv(wt, "encoder.convolutions." + std::to_string(i), E, E, d.enc_kernel, out + bl.enc_w[i], out + bl.enc_b[i]);
+        if (rc != GVX_OK) return rc;
+    }
+    {   // encoder BiLSTM: input projection rows [dir][4*j+gate], recurrent part in fragment order
+        const char* sfx[2] = {"", "_reverse"};
+        for (int dir = 0; dir < 2; ++dir) {
+            std::vector<float> wcat;
+            std::vector<float> bias(4 * H);
+            rc = pack_lstm(wt, std::string("encoder.lstm.weight_ih_l0") + sfx[dir], std::string("encoder.lstm.weight_hh_l0") + sfx[dir],
+                           std::string("encoder.lstm.bias_ih_l0") + sfx[dir], std::string("encoder.lstm.bias_hh_l0") + sfx[dir], H, E, &wcat, bias.data());
+            if (rc != GVX_OK) return rc;
+            std::vector<float> whh((size_t)4 * H * H);
+            for (int r = 0; r < 4 * H; ++r) {
+                std::memcpy(out + bl.enc_wih + ((size_t)dir * 4 * H + r) * E, &wcat[(size_t)r * (E + H)], sizeof(float) * E);
+                std::memcpy(&whh[(size_t)r * H], &wcat[(size_t)r * (E + H) + E], sizeof(float) * H);
+            }
+            std::memcpy(out + bl.enc_bih + (size_t)dir * 4 * H, bias.data(), sizeof(float) * 4 * H);
+            pack_frag(whh, 4 * H, H, out + bl.enc_whh_frag[dir]);
+        }
+    }
+    {   // Prenet (no bias)
+        if (!(src = wt.get("decoder.prenet.layers.0.linear_layer.weight", (int64_t)P * M, &rc))) return rc;
+        std::memcpy(out + bl.pre_w0, src, sizeof(float) * P * M);
+        pack_frag(std::vector<float>(src, src + (size_t)P * M), P, M, out + bl.pre_w0_frag);
+        if (!(src = wt.get("decoder.prenet.layers.1.linear_layer.weight", (int64_t)P * P, &rc))) return rc;
+        std::memcpy(out + bl.pre_w1, src, sizeof(float) * P * P);
+        pack_frag(std::vector<float>(src, src + (size_t)P * P), P, P, out + bl.pre_w1_frag);
+    }
+    {   // attention LSTM: x = [prenet ; context ; h_a]
+        std::vector<float> wcat;
+        rc = pack_lstm(wt, "decoder.attention_rnn.weight_ih", "decoder.attention_rnn.weight_hh", "decoder.attention_rnn.bias_ih",
+                       "decoder.attention_rnn.bias_hh", A, P + E, &wcat, out + bl.att_bias);
+        if (rc != GVX_OK) return rc;
+        pack_frag(wcat, 4 * A, P + E + A, out + bl.att_frag);
+    }
+    {   // attention layer
+        const std::string att = "decoder.attention_layer.";
+        if (!(src = wt.get(att + "query_layer.linear_layer.weight", (int64_t)a * A, &rc))) return rc;
+        for (int t = 0; t < A / 8; ++t)
+            for (int dd = 0; dd < a; ++dd)
+                for (int jj = 0; jj < 8; ++jj) out[bl.wq_t + ((size_t)t * a + dd) * 8 + jj] = src[(size_t)dd * A + t * 8 + jj];
+        if (!(src = wt.get(att + "memory_layer.linear_layer.weight", (int64_t)a * E, &rc))) return rc;
+        std::memcpy(out + bl.wmem, src, sizeof(float) * a * E);
+        if (!(src = wt.get(att + "v.linear_layer.weight", a, &rc))) return rc;
+        std::memcpy(out + bl.v, src, sizeof(float) * a);
+        const int64_t nconv = (int64_t)d.att_loc_filters * 2 * d.att_loc_kernel;
+        if (!(src = wt.get(att + "location_layer.location_conv.conv.weight", nconv, &rc))) return rc;
+        std::memcpy(out + bl.loc_conv, src, sizeof(float) * nconv);
+        if (!(src = wt.get(att + "location_layer.location_dense.linear_layer.weight", (int64_t)a * d.att_loc_filters, &rc))) return rc;
+        std::memcpy(out + bl.loc_dense, src, sizeof(float) * a * d.att_loc_filters);
+    }
+    {   // decoder LSTM: x = [h_a ; context ; h_d]
+        std::vector<float> wcat;
+        rc = pack_lstm(wt, "decoder.decoder_rnn.weight_ih", "decoder.decoder_rnn.weight_hh", "decoder.decoder_rnn.bias_ih",
+                       "decoder.decoder_rnn.bias_hh", D, A + E, &wcat, out + bl.dec_bias);
+        if (rc != GVX_OK) return rc;
+        pack_frag(wcat, 4 * D, A + E + D, out + bl.dec_frag);
+    }
+    {   // mel + gate projection, rows 0..M-1 = linear_projection, row M = gate_layer; x = [h_d ; context]
+        const int K = D + E;
+        std::vector<float> w((size_t)(M + 1) * K);
+        if (!(src = wt.get("decoder.linear_projection.linear_layer.weight", (int64_t)M * K, &rc))) return rc;
+        std::memcpy(w.data(), src, sizeof(float) * M * K);
+        if (!(src = wt.get("decoder.gate_layer.linear_layer.weight", K, &rc))) return rc;
+        std::memcpy(w.data() + (size_t)M * K, src, sizeof(float) * K);
+        std::memcpy(out + bl.proj_w, w.data(), sizeof(float) * w.size());
+        pack_frag(w, M + 1, K, out + bl.proj_frag);
+        if (!(src = wt.get("decoder.linear_projection.linear_layer.bias", M, &rc))) return rc;
+        std::memcpy(out + bl.proj_b, src, sizeof(float) * M);
+        if (!(src = wt.get("decoder.gate_layer.linear_layer.bias", 1, &rc))) return rc;
+        out[bl.proj_b + M] = src[0];
+    }
+    for (int i = 0; i < d.postnet_n_conv; ++i) {
+        const int cin = i == 0 ? M : d.postnet_dim, cout = i == d.postnet_n_conv - 1 ? M : d.postnet_dim;
+        rc = pack_conv(wt, "postnet.convolutions." + std::to_string(i), cout, cin, d.postnet_kernel, out + bl.post_w[i], out + bl.post_b[i]);
+        if (rc != GVX_OK) return rc;
+    }
+    return GVX_OK;
+}
+
+int gvx_model_bind_blob(gvx_model* m, const void* device_blob) {
+    if (!m || !device_blob) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (reinterpret_cast<uintptr_t>(device_blob) & 255) return fail(GVX_ERR_INVALID_ARG, "blob must be 256-byte aligned");
+    m->dev_blob = reinterpret_cast<const float*>(device_blob);
+    HIP_TRY(gemm_init());
+    HIP_TRY(skinny_init());
+    HIP_TRY(attention_init());
+    return GVX_OK;
+}
+
+size_t gvx_workspace_bytes(const gvx_model* m, int B, int L, int T) {
+    if (!m || B < 1 || L < 1 || T < 1) return 0;
+    return make_ws_plan(m, B, L, T).total;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+namespace {
+
+int check_common(const gvx_model* m, int B, int L, int T, void* ws, size_t ws_bytes) {
+    if (!m) return fail(GVX_ERR_INVALID_ARG, "null model");
+    if (!m->dev_blob) return fail(GVX_ERR_STATE, "weights not bound (call gvx_model_bind_blob)");
+    if (B < 1 || B > 64) return fail(GVX_ERR_UNSUPPORTED, "batch %d not in [1, 64] (shard larger batches across calls / GPUs)", B);
+    if (L < 1 || T < 1) return fail(GVX_ERR_INVALID_ARG, "L and T must be >= 1");
+    if (!ws) return fail(GVX_ERR_WORKSPACE, "null workspace");
+    if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(GVX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    const size_t need = make_ws_plan(m, B, L, T).total;
+    if (ws_bytes < need) return fail(GVX_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+    if (attention_lds_bytes(L, m->d.att_dim, m->d.att_loc_filters, m->d.att_loc_kernel) > 160 * 1024)
+        return fail(GVX_ERR_UNSUPPORTED, "L = %d is too long for the attention kernel's LDS budget", L);
+    return GVX_OK;
+}
+
+// conv stack on channels-last halo buffers: in -> (ping/pong) ; returns pointer of the final output buffer
+int conv_layer(const gvx_model* m, const float* in, float* out, int B, int T, int cin, int cout, int k, size_t w_off, size_t b_off,
+               int act, int out_halo, hipStream_t s) {
+    const int p = (k - 1) / 2;
+    GemmParams g{};
+    g.A = in; g.amap = RowMap{T, (long)(T + 2 * p) * cin, (long)cin};
+    g.W = m->dev_blob + w_off; g.ldw = (long)k * cin;
+    g.C = out + (long)out_halo * cout; g.cmap = RowMap{T, (long)(T + 2 * out_halo) * cout, (long)cout};
+    g.bias = m->dev_blob + b_off;
+    g.M = B * T; g.N = cout; g.K = k * cin; g.act = act;
+    HIP_TRY(launch_gemm(g, s));
+    return GVX_OK;
+}
+
+int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, int B, int L, float* memory_out, void* ws,
+                 const WsPlan& wp, hipStream_t s) {
+    const gvx_dims& d = m->d;
+    const int E = d.embed_dim, H = E / 2, pe = (d.enc_kernel - 1) / 2;
+    float* xa = ws_ptr<float>(ws, wp.xa);
+    float* xb = ws_ptr<float>(ws, wp.xb);
+    float* xg = ws_ptr<float>(ws, wp.xg);
+    float* enc_h = ws_ptr<float>(ws, wp.enc_h);
+    float* enc_c = ws_ptr<float>(ws, wp.enc_c);
+    int* flags = ws_ptr<int>(ws, wp.flags);
+    const size_t xbytes = (size_t)B * (L + 2 * pe) * E * sizeof(float);
+    HIP_TRY(zero_async(xa, xbytes, s));
+    HIP_TRY(zero_async(xb, xbytes, s));
+    HIP_TRY(zero_async(flags, sizeof(int), s));
+    HIP_TRY(launch_embed(tokens, m->dev_blob + m->blob.emb, d.n_tokens, xa, B, L, E, pe, flags, s));
+    float* cur = xa;
+    float* nxt = xb;
+    for (int i = 0; i < d.enc_n_conv; ++i) {
+        int rc = conv_layer(m, cur, nxt, B, L, E, E, d.enc_kernel, m->blob.enc_w[i], m->blob.enc_b[i], ACT_RELU, pe, s);
+        if (rc != GVX_OK) return rc;
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    {   // LSTM input projection for both directions: xg[b][l][dir*4H + 4j+gate]
+        GemmParams g{};
+        g.A = cur + (long)pe * E; g.amap = RowMap{L, (long)(L + 2 * pe) * E, (long)E};
+        g.W = m->dev_blob + m->blob.enc_wih; g.ldw = E;
+        g.C = xg; g.cmap = RowMap{B * L, 0, (long)8 * H};
+        g.bias = m->dev_blob + m->blob.enc_bih;
+        g.M = B * L; g.N = 8 * H; g.K = E; g.act = ACT_NONE;
+        HIP_TRY(launch_gemm(g, s));
+    }
+    HIP_TRY(zero_async(enc_h, (size_t)4 * B * H * sizeof(float), s));
+    HIP_TRY(zero_async(enc_c, (size_t)2 * B * H * sizeof(float), s));
+    HIP_TRY(zero_async(memory_out, (size_t)B * L * E * sizeof(float), s));
+    for (int step = 0; step < L; ++step) {
+        SkinnyJob jobs[2];
+        for (int dir = 0; dir < 2; ++dir) {
+            SkinnyJob& J = jobs[dir];
+            std::memset(&J, 0, sizeof J);
+            float* h_cur = enc_h + ((size_t)dir * 2 + (step & 1)) * B * H;
+            float* h_nxt = enc_h + ((size_t)dir * 2 + ((step + 1) & 1)) * B * H;
+            J.Wp = m->dev_blob + m->blob.enc_whh_frag[dir];
+            J.x[0] = XSeg{h_cur, (long)H, H};
+            J.N = 4 * H; J.nkg = H / 8; J.mode = 0; J.B = B;
+            J.c = enc_c + (size_t)dir * B * H;
+            J.h_out = h_nxt; J.h_out_stride = H;
+            J.addend = xg + (size_t)dir * 4 * H; J.add_bs = (long)L * 8 * H; J.add_ts = 8 * H;
+            J.lengths = lengths; J.step = step; J.reverse = dir; J.seq_len = L;
+            J.seq_out = memory_out + (size_t)dir * H; J.seq_bs = (long)L * E; J.seq_ts = E;
+            J.h_prev = h_cur; J.h_prev_stride = H;
+        }
+        HIP_TRY(launch_skinny(jobs, 2, s));
+    }
+    return GVX_OK;
+}
+
+struct DecoderBuffers {
+    float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj;
+};
+
+DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
+    DecoderBuffers b;
+    b.pm = ws_ptr<float>(ws, wp.pm); b.frames = ws_ptr<float>(ws, wp.frames); b.pre1 = ws_ptr<float>(ws, wp.pre1);
+    b.prenet = ws_ptr<float>(ws, wp.prenet); b.h_a = ws_ptr<float>(ws, wp.h_a); b.c_a = ws_ptr<float>(ws, wp.c_a);
+    b.c_d = ws_ptr<float>(ws, wp.c_d); b.hc = ws_ptr<float>(ws, wp.hc); b.w_cum = ws_ptr<float>(ws, wp.w_cum);
+    b.q_slab = ws_ptr<float>(ws, wp.q_slab); b.proj = ws_ptr<float>(ws, wp.proj);
+    return b;
+}
+
+// Decoder.initialize_decoder_states (models/tts/tacotron2.py:303-315): zero states + memory projection
+int decoder_init_states(gvx_model* m, const float* memory, int B, int L, const DecoderBuffers& db, hipStream_t s) {
+    const gvx_dims& d = m->d;
+    const int E = d.embed_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim;
+    HIP_TRY(zero_async(db.h_a, (size_t)2 * B * A * sizeof(float), s));
+    HIP_TRY(zero_async(db.c_a, (size_t)B * A * sizeof(float), s));
+    HIP_TRY(zero_async(db.c_d, (size_t)B * D * sizeof(float), s));
+    HIP_TRY(zero_async(db.hc, (size_t)B * (D + E) * sizeof(float), s));  // slot 0
+    HIP_TRY(zero_async(db.w_cum, (size_t)B * L * sizeof(float), s));
+    GemmParams g{};
+    g.A = memory; g.amap = RowMap{B * L, 0, (long)E};
+    g.W = m->dev_blob + m->blob.wmem; g.ldw = E;
+    g.C = db.pm; g.cmap = RowMap{B * L, 0, (long)d.att_dim};
+    g.M = B * L; g.N = d.att_dim; g.K = E; g.act = ACT_NONE;
+    HIP_TRY(launch_gemm(g, s));
+    return GVX_OK;
+}
+
+void fill_att_job(const gvx_model* m, SkinnyJob& J, const float* prenet_t, long prenet_stride, int t, int B, const DecoderBuffers& db) {
+    const gvx_dims& d = m->d;
+    const int E = d.embed_dim, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim;
+    std::memset(&J, 0, sizeof J);
+    const float* hc_t = db.hc + (size_t)t * B * (D + E);
+    J.Wp = m->dev_blob + m->blob.att_frag; J.bias = m->dev_blob + m->blob.att_bias;
+    J.x[0] = XSeg{prenet_t, prenet_stride, P};
+    J.x[1] = XSeg{hc_t + D, (long)(D + E), E};                       // context of step t-1
+    J.x[2] = XSeg{db.h_a + (size_t)(t & 1) * B * A, (long)A, A};     // h_a of step t-1
+    J.N = 4 * A; J.nkg = (P + E + A) / 8; J.mode = 0; J.B = B;
+    J.c = db.c_a;
+    J.h_out = db.h_a + (size_t)((t + 1) & 1) * B * A; J.h_out_stride = A;
+    J.Wq_t = m->dev_blob + m->blob.wq_t; J.q_slab = db.q_slab; J.att_dim = d.att_dim;
+}
+
+// decoder LSTM of step t: x = [h_a(t) ; ctx(t) ; h_d(t-1)], writes h_d(t) into hc slot t+1
+void fill_dec_job(const gvx_model* m, SkinnyJob& J, int t, int B, const DecoderBuffers& db) {
+    const gvx_dims& d = m->d;
+    const int E = d.embed_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim;
+    std::memset(&J, 0, sizeof J);
+    const float* hc_t = db.hc + (size_t)t * B * (D + E);
+    float* hc_n = db.hc + (size_t)(t + 1) * B * (D + E);
+    J.Wp = m->dev_blob + m->blob.dec_frag; J.bias = m->dev_blob + m->blob.dec_bias;
+    J.x[0] = XSeg{db.h_a + (size_t)((t + 1) & 1) * B * A, (long)A, A};
+    J.x[1] = XSeg{hc_n + D, (long)(D + E), E};
+    J.x[2] = XSeg{hc_t, (long)(D + E), D};
+    J.N = 4 * D; J.nkg = (A + E + D) / 8; J.mode = 0; J.B = B;
+    J.c = db.c_d;
+    J.h_out = hc_n; J.h_out_stride = D + E;
+}
+
+void fill_attn(const gvx_model* m, AttnParams& p, const float* memory, const int32_t* lengths, int t, int B, int L,
+               float* align_out, long align_bs, long align_ts, const DecoderBuffers& db) {
+    const gvx_dims& d = m->d;
+    const int E = d.embed_dim, D = d.dec_rnn_dim;
+    std::memset(&p, 0, sizeof p);
+    p.q_slab = db.q_slab; p.n_slabs = d.att_rnn_dim / 8;
+    p.w_prev = t > 0 ? align_out + (size_t)(t - 1) * align_ts : nullptr; p.w_prev_bs = align_bs;
+    p.w_cum = db.w_cum;
+    p.loc_conv = m->dev_blob + m->blob.loc_conv; p.loc_dense = m->dev_blob + m->blob.loc_dense; p.v = m->dev_blob + m->blob.v;
+    p.pm = db.pm; p.memory = memory; p.lengths = lengths;
+    p.w_out = align_out + (size_t)t * align_ts; p.w_out_bs = align_bs;
+    p.ctx_out = db.hc + (size_t)(t + 1) * B * (D + E) + D; p.ctx_bs = D + E;
+    p.B = B; p.L = L; p.a = d.att_dim; p.F = d.att_loc_filters; p.kl = d.att_loc_kernel; p.E = E;
+}
+
+int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
+                    const uint8_t* keep_masks, float* mel_out, float* gate_out, float* align_out, void* ws, const WsPlan& wp,
+                    hipStream_t s) {
+    const gvx_dims& d = m->d;
+    const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, D = d.dec_rnn_dim;
+    const DecoderBuffers db = decoder_buffers(ws, wp);
+    const bool timed = m->timing && m->ev_valid;
+    // ---- Prenet over all T+1 frames at once (models/tts/tacotron2.py:370-373)
+    HIP_TRY(zero_async(db.frames, (size_t)B * M * sizeof(float), s));  // go-frame
+    HIP_TRY(launch_frames_from_mel(mel_in, db.frames, B, M, T, s));
+    const int rows = (T + 1) * B;
+    {
+        GemmParams g{};
+        g.A = db.frames; g.amap = RowMap{rows, 0, (long)M};
+        g.W = m->dev_blob + m->blob.pre_w0; g.ldw = M;
+        g.C = db.pre1; g.cmap = RowMap{rows, 0, (long)P};
+        g.keep = keep_masks; g.keep_ld = P;
+        g.M = rows; g.N = P; g.K = M; g.act = ACT_RELU;
+        HIP_TRY(launch_gemm(g, s));
+        g.A = db.pre1; g.amap = RowMap{rows, 0, (long)P};
+        g.W = m->dev_blob + m->blob.pre_w1; g.ldw = P;
+        g.C = db.prenet;
+        g.keep = keep_masks + (size_t)rows * P;
+        g.K = P;
+        HIP_TRY(launch_gemm(g, s));
+    }
+    int rc = decoder_init_states(m, memory, B, L, db, s);
+    if (rc != GVX_OK) return rc;
+    if (timed) HIP_TRY(hipEventRecord(m->ev[2], s));
+    // ---- T decoder steps.  Launch 1 of step t: attention-LSTM(t) together with decoder-LSTM(t-1), which is off
+    // the critical chain (only the next step's projection needs it).  Launch 2: attention(t).
+    int launches = 0;
+    for (int t = 0; t < T; ++t) {
+        SkinnyJob jobs[2];
+        fill_att_job(m, jobs[0], db.prenet + (size_t)t * B * P, P, t, B, db);
+        if (t > 0) fill_dec_job(m, jobs[1], t - 1, B, db);
+        HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, s));
+        AttnParams ap;
+        fill_attn(m, ap, memory, lengths, t, B, L, align_out, (long)T * L, L, db);
+        HIP_TRY(launch_attention(ap, s));
+        launches += 2;
+    }
+    {
+        SkinnyJob job;
+        fill_dec_job(m, job, T - 1, B, db);
+        HIP_TRY(launch_skinny(&job, 1, s));
+        ++launches;
+    }
+    m->last_decoder_launches = launches;
+    if (timed) HIP_TRY(hipEventRecord(m->ev[3], s));
+    // ---- mel + gate projection hoisted out of the loop: one GEMM over all T*B rows of hc[1..T]
+    {
+        const int PS = m->PS();
+        GemmParams g{};
+        g.A = db.hc + (size_t)B * (D + E); g.amap = RowMap{T * B, 0, (long)(D + E)};
+        g.W = m->dev_blob + m->blob.proj_w; g.ldw = D + E;
+        g.C = db.proj; g.cmap = RowMap{B, (long)PS, (long)T * PS};  // row (t,b) -> proj[b][t][:]
+        g.bias = m->dev_blob + m->blob.proj_b;
+        g.M = T * B; g.N = M + 1; g.K = D + E; g.act = ACT_NONE;
+        HIP_TRY(launch_gemm(g, s));
+        HIP_TRY(launch_split_projection(db.proj, mel_out, gate_out, B, M, T, s));
+    }
+    return GVX_OK;
+}
+
+int postnet_impl(gvx_model* m, const float* mel_in, int B, int T, float* mel_post_out, void* ws, const WsPlan& wp, hipStream_t s) {
+    const gvx_dims& d = m->d;
+    const int M = d.n_mels, pp = (d.postnet_kernel - 1) / 2, n = d.postnet_n_conv;
+    float* ya = ws_ptr<float>(ws, wp.ya);
+    float* yb = ws_ptr<float>(ws, wp.yb);
+    // every conv input needs zero halo rows in ITS channel layout; the GEMM only writes interior rows
+    HIP_TRY(launch_zero_halo(ya, B, T, pp, M, s));
+    HIP_TRY(launch_to_channels_last(mel_in, ya, B, M, T, pp, s));
+    float* cur = ya;
+    float* nxt = yb;
+    for (int i = 0; i < n; ++i) {
+        const int cin = i == 0 ? M : d.postnet_dim, cout = i == n - 1 ? M : d.postnet_dim;
+        const bool last = i == n - 1;
+        if (!last) HIP_TRY(launch_zero_halo(nxt, B, T, pp, cout, s));
+        int rc = conv_layer(m, cur, nxt, B, T, cin, cout, d.postnet_kernel, m->blob.post_w[i], m->blob.post_b[i],
+                            last ? ACT_NONE : ACT_TANH, last ? 0 : pp, s);
+        if (rc != GVX_OK) return rc;
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    HIP_TRY(launch_residual_to_channels_first(mel_in, cur, mel_post_out, B, M, T, s));
+    return GVX_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int gvx_encoder_forward(gvx_model* m, const int64_t* tokens, const int32_t* lengths, int B, int L, float* memory_out,
+                        void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(m, B, L, 1, ws, ws_bytes);
+    if (rc != GVX_OK) return rc;
+    if (!tokens || !memory_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    return encoder_impl(m, tokens, lengths, B, L, memory_out, ws, make_ws_plan(m, B, L, 1), (hipStream_t)stream);
+}
+
+int gvx_decoder_teacher_forced(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
+                               const uint8_t* keep_masks, float* mel_out, float* gate_out, float* align_out, void* ws,
+                               size_t ws_bytes, void* stream) {
+    int rc = check_common(m, B, L, T, ws, ws_bytes);
+    if (rc != GVX_OK) return rc;
+    if (!memory || !mel_in || !keep_masks || !mel_out || !gate_out || !align_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    return decoder_tf_impl(m, memory, lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws,
+                           make_ws_plan(m, B, L, T), (hipStream_t)stream);
+}
+
+int gvx_postnet_forward(gvx_model* m, const float* mel_in, int B, int T, float* mel_post_out, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(m, B, 1, T, ws, ws_bytes);
+    if (rc != GVX_OK) return rc;
+    if (!mel_in || !mel_post_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    return postnet_impl(m, mel_in, B, T, mel_post_out, ws, make_ws_plan(m, B, 1, T), (hipStream_t)stream);
+}
+
+int gvx_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths, int B, int n_mels, int T, void* stream) {
+    if (!mel_lengths || B < 1 || T < 1 || n_mels < 1) return fail(GVX_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(launch_mask_padding(mel, mel_post, gate, mel_lengths, B, n_mels, T, (hipStream_t)stream));
+    return GVX_OK;
+}
+
+int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* token_lengths, int B, int L, const float* mel_in,
+                          const int32_t* mel_lengths, int T, const uint8_t* keep_masks, float* mel_out, float* mel_post_out,
+                          float* gate_out, float* align_out, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(m, B, L, T, ws, ws_bytes);
+    if (rc != GVX_OK) return rc;
+    if (!tokens || !mel_in || !keep_masks || !mel_out || !mel_post_out || !gate_out || !align_out)
+        return fail(GVX_ERR_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const WsPlan wp = make_ws_plan(m, B, L, T);
+    const bool timed = m->timing && m->ev_valid;
+    float* memory = ws_ptr<float>(ws, wp.memory);
+    if (timed) HIP_TRY(hipEventRecord(m->ev[0], s));
+    rc = encoder_impl(m, tokens, token_lengths, B, L, memory, ws, wp, s);
+    if (rc != GVX_OK) return rc;
+    if (timed) HIP_TRY(hipEventRecord(m->ev[1], s));
+    rc = decoder_tf_impl(m, memory, token_lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws, wp, s);
+    if (rc != GVX_OK) return rc;
+    if (timed) HIP_TRY(hipEventRecord(m->ev[4], s));
+    rc = postnet_impl(m, mel_out, B, T, mel_post_out, ws, wp, s);
+    if (rc != GVX_OK) return rc;
+    if (mel_lengths) HIP_TRY(launch_mask_padding(mel_out, mel_post_out, gate_out, mel_lengths, B, m->d.n_mels, T, s));
+    if (timed) HIP_TRY(hipEventRecord(m->ev[5], s));
+    return GVX_OK;
+}
+
+int gvx_prenet_masks_generate(uint8_t* masks_out, size_t n, uint64_t seed, void* stream) {
+    if (!masks_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(launch_mask_gen(masks_out, n, seed, (hipStream_t)stream));
+    return GVX_OK;
+}
+
+int gvx_stage_timing_enable(gvx_model* m, int enable) {
+    if (!m) return fail(GVX_ERR_INVALID_ARG, "null model");
+    if (enable && !m->ev_valid) {
+        for (auto& e : m->ev) HIP_TRY(hipEventCreate(&e));
+        m->ev_valid = true;
+    }
+    m->timing = enable != 0;
+    return GVX_OK;
+}
+
+int gvx_stage_times_ms(gvx_model* m, float* t5, int* launches) {
+    if (!m || !t5) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (!m->ev_valid) return fail(GVX_ERR_STATE, "stage timing was not enabled");
+    HIP_TRY(hipEventSynchronize(m->ev[5]));
+    // ev: 0 start, 1 encoder done, 2 prenet+init done, 3 decoder loop done, 4 projection done, 5 postnet done
+    for (int i = 0; i < 5; ++i) HIP_TRY(hipEventElapsedTime(&t5[i], m->ev[i], m->ev[i + 1]));
+    if (launches) *launches = m->last_decoder_launches;
+    return GVX_OK;
+}
+
+int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, int max_steps,
+                               float gate_threshold, const uint8_t* keep_masks, float* mel_out, float* gate_out, float* align_out,
+                               int32_t* n_frames_out, int* steps_run_out, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(m, B, L, max_steps, ws, ws_bytes);
+    if (rc != GVX_OK) return rc;
+    if (!memory || !keep_masks || !mel_out || !gate_out || !align_out || !n_frames_out)
+        return fail(GVX_ERR_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const gvx_dims& d = m->d;
+    const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, D = d.dec_rnn_dim, T = max_steps;
+    const WsPlan wp = make_ws_plan(m, B, L, T);
+    const DecoderBuffers db = decoder_buffers(ws, wp);
+    const int PS = m->PS();
+    int32_t* flags = ws_ptr<int32_t>(ws, wp.flags);
+    int32_t* n_done = flags + 1;
+    // db.proj is used time-major here: proj[t][b][PS]; frames: one zero go-frame [B][M]
+    rc = decoder_init_states(m, memory, B, L, db, s);
+    if (rc != GVX_OK) return rc;
+    HIP_TRY(zero_async(db.frames, (size_t)B * M * sizeof(float), s));
+    HIP_TRY(zero_async(n_done, sizeof(int32_t), s));
+    HIP_TRY(zero_async(n_frames_out, (size_t)B * sizeof(int32_t), s));
+    const int CHUNK = 16;  // steps between host checks of the all-rows-finished counter
+    int t = 0;
+    int32_t done_host = 0;
+    while (t < T) {
+        const int t_end = t + CHUNK < T ? t + CHUNK : T;
+        for (; t < t_end; ++t) {
+            // Prenet on the previous mel frame (Decoder.inference, models/tts/tacotron2.py:398)
+            SkinnyJob job;
+            std::memset(&job, 0, sizeof job);
+            job.Wp = m->dev_blob + m->blob.pre_w0_frag;
+            job.x[0] = t == 0 ? XSeg{db.frames, (long)M, M} : XSeg{db.proj + (size_t)(t - 1) * B * PS, (long)PS, M};
+            job.N = P; job.nkg = M / 8; job.mode = 1; job.B = B; job.act = ACT_RELU;
+            job.y = db.pre1; job.y_stride = P;
+            job.keep = keep_masks + (size_t)t * B * P; job.keep_stride = P;
+            HIP_TRY(launch_skinny(&job, 1, s));
+            job.Wp = m->dev_blob + m->blob.pre_w1_frag;
+            job.x[0] = XSeg{db.pre1, (long)P, P};
+            job.nkg = P / 8;
+            job.y = db.prenet;
+            job.keep = keep_masks + ((size_t)T + t) * B * P;
+            HIP_TRY(launch_skinny(&job, 1, s));
+            SkinnyJob lj;
+            fill_att_job(m, lj, db.prenet, P, t, B, db);
+            HIP_TRY(launch_skinny(&lj, 1, s));
+            AttnParams ap;
+            fill_attn(m, ap, memory, lengths, t, B, L, align_out, (long)T * L, L, db);
+            HIP_TRY(launch_attention(ap, s));
+            fill_dec_job(m, lj, t, B, db);
+            HIP_TRY(launch_skinny(&lj, 1, s));
+            // mel + gate projection of this step
+            std::memset(&job, 0, sizeof job);
+            job.Wp = m->dev_blob + m->blob.proj_frag; job.bias = m->dev_blob + m->blob.proj_b;
+            job.x[0] = XSeg{db.hc + (size_t)(t + 1) * B * (D + E), (long)(D + E), D + E};
+            job.N = M + 1; job.nkg = (D + E) / 8; job.mode = 1; job.B = B; job.act = ACT_NONE;
+            job.y = db.proj + (size_t)t * B * PS; job.y_stride = PS;
+            HIP_TRY(launch_skinny(&job, 1, s));
+            HIP_TRY(launch_ar_emit(db.proj + (size_t)t * B * PS, PS, mel_out, gate_out, B, M, T, t, s));
+            HIP_TRY(launch_ar_stop(db.proj + (size_t)t * B * PS, PS, M, gate_threshold, t, B, n_frames_out, n_done, s));
+        }
+        HIP_TRY(hipMemcpyAsync(&done_host, n_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (done_host >= B) break;
+    }
+    // rows that never fired ran into the cap ("Warning! Reached max decoder steps", models/tts/tacotron2.py:407-409)
+    HIP_TRY(launch_ar_stop(db.proj, PS, M, -1.f, t - 1, B, n_frames_out, n_done, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (steps_run_out) *steps_run_out = t;
+    return GVX_OK;
+}
+
+}  // extern "C"

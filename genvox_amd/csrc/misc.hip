@@ -1,0 +1,215 @@
+// Data-movement kernels around the GEMM / recurrent kernels: embedding gather, layout changes between
+// the reference's channels-first API tensors ([B, C, T]) and the channels-last halo-padded layout the
+// implicit-GEMM convolutions use, output padding mask, Prenet keep-mask generator and the
+// autoregressive stop bookkeeping.  All of them are pure HBM-bound byte movers: coalesced 128-byte
+// rows in, LDS tile transpose, coalesced rows out.
+#include "gvx_kernels.h"
+
+namespace gvx {
+
+// ---- embedding gather (reference: nn.Embedding, models/tts/tacotron2.py:459/:486) -------------------
+__global__ void embed_kernel(const int64_t* tokens, const float* emb, int n_tokens, float* x, int L, int E, int halo, int* err_flag) {
+    const int row = blockIdx.x;  // b*L + l
+    const int b = row / L, l = row - b * L;
+    long tok = tokens[row];
+    bool ok = tok >= 0 && tok < n_tokens;
+    if (!ok && threadIdx.x == 0) atomicExch(err_flag, 1);
+    const float4* src = reinterpret_cast<const float4*>(emb + (ok ? tok : 0) * E);
+    float4* dst = reinterpret_cast<float4*>(x + ((long)b * (L + 2 * halo) + halo + l) * E);
+    for (int i = threadIdx.x; i < E / 4; i += blockDim.x) dst[i] = ok ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+hipError_t launch_embed(const int64_t* tokens, const float* emb, int n_tokens, float* x, int B, int L, int E, int halo,
+                        int* err_flag, hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(128), 0, s, tokens, emb, n_tokens, x, L, E, halo, err_flag);
+    return hipGetLastError();
+}
+
+// ---- batched 2-D transpose with strides:  dst[b][j][i] = src[b][i][j] (+ add[b][j][i]) -------------
+// src element (b,i,j) at src + b*sb + i*si + j ; dst element at dst + b*db + j*dj + i.
+// Column j == extra_col (if extra != nullptr) is diverted to extra[b*extra_bs + i] instead.
+struct Tr3 {
+    const float* src; long sb, si; int ni, nj;
+    float* dst; long db, dj;
+    const float* add;
+    float* extra; long extra_bs; int extra_col;
+    int nj_main;  // columns [0, nj_main) go to dst
+};
+
+__global__ void transpose3_kernel(Tr3 p) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + tx;
+        tile[r][tx] = (i < p.ni && j < p.nj) ? p.src[(long)b * p.sb + (long)i * p.si + j] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r, i = i0 + tx;
+        if (i >= p.ni || j >= p.nj) continue;
+        const float v = tile[tx][r];
+        if (j < p.nj_main) {
+            const long o = (long)b * p.db + (long)j * p.dj + i;
+            p.dst[o] = p.add ? v + p.add[o] : v;
+        } else if (p.extra && j == p.extra_col) {
+            p.extra[(long)b * p.extra_bs + i] = v;
+        }
+    }
+}
+
+static hipError_t launch_tr3(const Tr3& p, int B, hipStream_t s) {
+    dim3 grid((p.nj + 31) / 32, (p.ni + 31) / 32, B);
+    hipLaunchKernelGGL(transpose3_kernel, grid, dim3(32, 8), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_frames_from_mel(const float* mel_in, float* frames, int B, int M, int T, hipStream_t s) {
+    // frames[(t+1)*B + b][m] = mel_in[b][m][t]; the go-frame rows (t = 0) are zeroed by the caller
+    Tr3 p{};
+    p.src = mel_in; p.sb = (long)M * T; p.si = T; p.ni = M; p.nj = T;
+    p.dst = frames + (long)B * M; p.db = M; p.dj = (long)B * M;
+    p.nj_main = T;
+    return launch_tr3(p, B, s);
+}
+
+hipError_t launch_split_projection(const float* proj, float* mel_out, float* gate_out, int B, int M, int T, hipStream_t s) {
+    // proj [B][T][PS] (PS = padded M+1) -> mel_out [B][M][T], gate_out [B][T]
+    const int PS = (M + 1 + 3) & ~3;
+    Tr3 p{};
+    p.src = proj; p.sb = (long)T * PS; p.si = PS; p.ni = T; p.nj = M + 1;
+    p.dst = mel_out; p.db = (long)M * T; p.dj = T;
+    p.nj_main = M; p.extra = gate_out; p.extra_bs = T; p.extra_col = M;
+    return launch_tr3(p, B, s);
+}
+
+hipError_t launch_to_channels_last(const float* src, float* dst, int B, int M, int T, int halo, hipStream_t s) {
+    Tr3 p{};
+    p.src = src; p.sb = (long)M * T; p.si = T; p.ni = M; p.nj = T;
+    p.dst = dst + (long)halo * M; p.db = (long)(T + 2 * halo) * M; p.dj = M;
+    p.nj_main = T;
+    return launch_tr3(p, B, s);
+}
+
+hipError_t launch_residual_to_channels_first(const float* mel, const float* y, float* mel_post, int B, int M, int T, hipStream_t s) {
+    Tr3 p{};
+    p.src = y; p.sb = (long)T * M; p.si = M; p.ni = T; p.nj = M;
+    p.dst = mel_post; p.db = (long)M * T; p.dj = T; p.add = mel;
+    p.nj_main = M;
+    return launch_tr3(p, B, s);
+}
+
+// ---- zero halo rows of a channels-last buffer ---------------------------------------------------------
+__global__ void zero_halo_kernel(float* buf, int T, int halo, int C) {
+    const int b = blockIdx.x;
+    float* base = buf + (long)b * (T + 2 * halo) * C;
+    const int n = halo * C;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        base[i] = 0.f;
+        base[(long)(halo + T) * C + i] = 0.f;
+    }
+}
+
+hipError_t launch_zero_halo(float* buf, int B, int T, int halo, int C, hipStream_t s) {
+    if (halo <= 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_halo_kernel, dim3(B), dim3(256), 0, s, buf, T, halo, C);
+    return hipGetLastError();
+}
+
+// ---- output padding mask (models/tts/tacotron2.py:466-473) -----------------------------------------
+__global__ void mask_padding_kernel(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths, int M, int T) {
+    const int b = blockIdx.y;
+    const int len = mel_lengths[b];
+    const long n = (long)M * T;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        if (t >= len) {
+            if (mel) mel[(long)b * n + i] = 0.f;
+            if (mel_post) mel_post[(long)b * n + i] = 0.f;
+            if (gate && i < T) gate[(long)b * T + t] = 1e3f;
+        }
+    }
+}
+
+hipError_t launch_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths, int B, int M, int T,
+                               hipStream_t s) {
+    const long n = (long)M * T;
+    int gx = (int)((n + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(mask_padding_kernel, dim3(gx, B), dim3(256), 0, s, mel, mel_post, gate, mel_lengths, M, T);
+    return hipGetLastError();
+}
+
+// ---- Prenet keep masks: Bernoulli(0.5) bytes from a splitmix64 counter hash --------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void mask_gen_kernel(uint8_t* out, size_t n, uint64_t seed) {
+    // one 64-bit hash gives 64 keep bits -> 64 output bytes (8 per 8-byte store)
+    const size_t words = (n + 7) / 8;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t bits = splitmix64(splitmix64(seed) ^ (w >> 3));
+        const unsigned byte = (unsigned)(bits >> (8 * (w & 7))) & 0xFFu;
+        uint64_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= (uint64_t)((byte >> i) & 1u) << (8 * i);
+        if (8 * w + 8 <= n) {
+            reinterpret_cast<uint64_t*>(out)[w] = v;
+        } else {
+            for (size_t i = 8 * w; i < n; ++i) out[i] = (uint8_t)((v >> (8 * (i - 8 * w))) & 1u);
+        }
+    }
+}
+
+hipError_t launch_mask_gen(uint8_t* out, size_t n, uint64_t seed, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (reinterpret_cast<uintptr_t>(out) & 7) return hipErrorInvalidValue;
+    const size_t words = (n + 7) / 8;
+    int grid = (int)((words + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(mask_gen_kernel, dim3(grid), dim3(256), 0, s, out, n, seed);
+    return hipGetLastError();
+}
+
+// ---- autoregressive bookkeeping (models/tts/tacotron2.py:405-409, per row) ----------------------------
+__global__ void ar_stop_kernel(const float* proj_t, long proj_stride, int gate_col, float threshold, int t, int B,
+                               int32_t* n_frames, int32_t* n_done) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (n_frames[b] != 0) return;  // already finished
+    const float g = proj_t[(long)b * proj_stride + gate_col];
+    const float sg = 1.f / (1.f + expf(-g));
+    if (sg > threshold) {
+        n_frames[b] = t + 1;
+        atomicAdd(n_done, 1);
+    }
+}
+
+hipError_t launch_ar_stop(const float* proj_t, long proj_stride, int gate_col, float threshold, int t, int B,
+                          int32_t* n_frames, int32_t* n_done, hipStream_t s) {
+    hipLaunchKernelGGL(ar_stop_kernel, dim3((B + 63) / 64), dim3(64), 0, s, proj_t, proj_stride, gate_col, threshold, t, B,
+                       n_frames, n_done);
+    return hipGetLastError();
+}
+
+__global__ void ar_emit_kernel(const float* proj_t, long proj_stride, float* mel_out, float* gate_out, int M, int Tmax, int t) {
+    const int b = blockIdx.x;
+    for (int m = threadIdx.x; m <= M; m += blockDim.x) {
+        const float v = proj_t[(long)b * proj_stride + m];
+        if (m < M) mel_out[((long)b * M + m) * Tmax + t] = v;
+        else gate_out[(long)b * Tmax + t] = v;
+    }
+}
+
+hipError_t launch_ar_emit(const float* proj_t, long proj_stride, float* mel_out, float* gate_out, int B, int M, int Tmax, int t,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(ar_emit_kernel, dim3(B), dim3(128), 0, s, proj_t, proj_stride, mel_out, gate_out, M, Tmax, t);
+    return hipGetLastError();
+}
+
+}  // namespace gvx

@@ -1,0 +1,225 @@
+// Skinny recurrent GEMM for the sequential part of the path (batch rows <= 64):
+//   decoder attention-LSTM and decoder-LSTM cells (one launch per decoder step covers both),
+//   encoder BiLSTM recurrence (one launch per time step covers both directions),
+//   the per-step Prenet / projection GEMVs of the autoregressive mode.
+//
+// Roofline: these are weight-streaming kernels. Every step re-reads the full recurrent matrices
+// (72 MB fp32 for the two decoder cells) while each weight is used only B times, so the kernel is
+// bound by HBM/Infinity-Cache bandwidth at B = 32 and is balanced against the fp32 MFMA rate at B = 64.
+//
+// Mapping (one workgroup of 8 waves per 32 output rows, normally one per CU):
+//   * the weight matrix is pre-packed in MFMA-fragment order [tile][k-group][lane][4], so each wave
+//     instruction reads 1 KiB contiguous - perfectly coalesced, streamed exactly once per step;
+//   * K is split over the 8 waves (no barrier in the main loop, each wave streams its own slice straight
+//     to VGPRs - an LDS round trip would be pure overhead for an operand nobody else reuses);
+//   * x (the concatenated [input ; context ; hidden] rows, <= 3 segments) comes from L2;
+//   * v_mfma_f32_32x32x2_f32 with A = W (rows = outputs), B = x^T (cols = batch rows): lane (b, half)
+//     ends up holding the four gate pre-activations i,f,g,o of hidden units 2g+half in accumulator
+//     registers 4g..4g+3, because gate rows are packed as row = 4*j + gate.  The LSTM cell update is
+//     therefore lane-local after the cross-wave K reduction (through LDS, 4 KiB per wave).
+//   * attention-LSTM tiles also emit the partial products of the attention query projection for their 8
+//     hidden units (slab[tile][b][:]), so the attention kernel never has to re-read the 512 KiB query matrix
+//     per batch row.
+#include "gvx_kernels.h"
+
+namespace gvx {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int SK_WAVES = 8;
+constexpr int SK_THREADS = SK_WAVES * 64;
+constexpr int SK_UNROLL = 4;  // k-groups in flight per wave and per batch tile
+
+struct SkinnyJobs {
+    SkinnyJob job[2];
+    int njobs;
+    int tiles0;  // tiles of job 0
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int MT>
+__global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkinnyJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;                                   // [SK_WAVES][MT][16][64]
+    float* hs = smem + SK_WAVES * MT * 16 * 64;          // [MT*32][8] h' of this tile (LSTM + q slabs)
+
+    const int jsel = (jobs.njobs > 1 && (int)blockIdx.x >= jobs.tiles0) ? 1 : 0;
+    const SkinnyJob& J = jobs.job[jsel];
+    const int tile = (int)blockIdx.x - (jsel ? jobs.tiles0 : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bl = lane & 31, h = lane >> 5;
+
+    // ---- main loop: this wave's K slice
+    const int per = (J.nkg + SK_WAVES - 1) / SK_WAVES;
+    const int kg_begin = wave * per;
+    const int kg_end = min(J.nkg, kg_begin + per);
+    const int e0 = J.x[0].len, e1 = e0 + J.x[1].len;
+
+    const float* xb[MT][3];
+    bool row_ok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int b = mt * 32 + bl;
+        row_ok[mt] = b < J.B;
+        const long bb = row_ok[mt] ? b : 0;
+        xb[mt][0] = J.x[0].p ? J.x[0].p + bb * J.x[0].stride + 4 * h : nullptr;
+        xb[mt][1] = J.x[1].p ? J.x[1].p + bb * J.x[1].stride + 4 * h - e0 : nullptr;
+        xb[mt][2] = J.x[2].p ? J.x[2].p + bb * J.x[2].stride + 4 * h - e1 : nullptr;
+    }
+    const float4* wp = reinterpret_cast<const float4*>(J.Wp) + ((long)tile * J.nkg) * 64 + lane;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[mt][q] = 0.f;
+
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kg = kg_begin; kg < kg_end; kg += SK_UNROLL) {
+        float4 wv[SK_UNROLL], xv[MT][SK_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SK_UNROLL; ++u) {
+            const int g = kg + u;
+            const bool ok = g < kg_end;
+            wv[u] = ok ? wp[(long)g * 64] : zero4;
+            const int k = 8 * g;
+            const int sidx = (k < e0) ? 0 : ((k < e1) ? 1 : 2);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float* base = sidx == 0 ? xb[mt][0] : (sidx == 1 ? xb[mt][1] : xb[mt][2]);
+                xv[mt][u] = (ok && row_ok[mt]) ? *reinterpret_cast<const float4*>(base + k) : zero4;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SK_UNROLL; ++u) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u].x, xv[mt][u].x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u].y, xv[mt][u].y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u].z, xv[mt][u].z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u].w, xv[mt][u].w, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- cross-wave K reduction through LDS
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[((wave * MT + mt) * 16 + q) * 64 + lane] = acc[mt][q];
+    __syncthreads();
+
+    // unit u = (mt, g): register group g (4 registers) of batch tile mt; one unit per wave
+    for (int u = wave; u < 4 * MT; u += SK_WAVES) {
+        const int mt = u >> 2, g = u & 3;
+        float s[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; ++w) t += red[((w * MT + mt) * 16 + 4 * g + qq) * 64 + lane];
+            s[qq] = t;
+        }
+        const int b = mt * 32 + bl;
+        const int nloc = 8 * g + 4 * h;          // first of the lane's 4 consecutive packed rows in the tile
+        const int n = tile * 32 + nloc;
+        if (J.mode == 0) {
+            // LSTM cell: rows n..n+3 are gates i,f,g,o of hidden unit j
+            const int jloc = 2 * g + h;
+            const int j = tile * 8 + jloc;
+            const int H = J.N >> 2;
+            float hval = 0.f;
+            if (b < J.B) {
+                bool active = true;
+                int tb = 0;
+                if (J.seq_out) {
+                    const int len = J.lengths ? J.lengths[b] : J.seq_len;
+                    active = J.step < len;
+                    tb = J.reverse ? (len - 1 - J.step) : J.step;
+                }
+                if (active) {
+                    float pre[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        float v = s[qq];
+                        if (J.bias) v += J.bias[n + qq];
+                        if (J.addend) v += J.addend[(long)b * J.add_bs + (long)tb * J.add_ts + n + qq];
+                        pre[qq] = v;
+                    }
+                    const float c_old = J.c[(long)b * H + j];
+                    const float c_new = sigmoidf_(pre[1]) * c_old + sigmoidf_(pre[0]) * tanhf(pre[2]);
+                    hval = sigmoidf_(pre[3]) * tanhf(c_new);
+                    J.c[(long)b * H + j] = c_new;
+                    if (J.seq_out) J.seq_out[(long)b * J.seq_bs + (long)tb * J.seq_ts + j] = hval;
+                } else {
+                    hval = J.h_prev[(long)b * J.h_prev_stride + j];
+                }
+                J.h_out[(long)b * J.h_out_stride + j] = hval;
+                if (J.h_out2) J.h_out2[(long)b * J.h_out2_stride + j] = hval;
+            }
+            if (J.q_slab) hs[b * 8 + jloc] = hval;
+        } else {
+            if (b < J.B) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int nn = n + qq;
+                    if (nn < J.N) {
+                        float v = s[qq];
+                        if (J.bias) v += J.bias[nn];
+                        if (J.act == ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (J.act == ACT_TANH) v = tanhf(v);
+                        if (J.keep) v = J.keep[(long)b * J.keep_stride + nn] ? 2.f * v : 0.f;
+                        J.y[(long)b * J.y_stride + nn] = v;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- attention query partial products for this tile's 8 hidden units
+    if (J.mode == 0 && J.q_slab) {
+        __syncthreads();
+        const int a = J.att_dim;
+        const float* wq = J.Wq_t + (long)tile * a * 8;
+        for (int idx = tid; idx < J.B * a; idx += SK_THREADS) {
+            const int b = idx / a, d = idx - b * a;
+            const float4 w0 = *reinterpret_cast<const float4*>(wq + d * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(wq + d * 8 + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(hs + b * 8);
+            const float4 h1 = *reinterpret_cast<const float4*>(hs + b * 8 + 4);
+            float v = w0.x * h0.x;
+            v = fmaf(w0.y, h0.y, v); v = fmaf(w0.z, h0.z, v); v = fmaf(w0.w, h0.w, v);
+            v = fmaf(w1.x, h1.x, v); v = fmaf(w1.y, h1.y, v); v = fmaf(w1.z, h1.z, v); v = fmaf(w1.w, h1.w, v);
+            J.q_slab[((long)tile * J.B + b) * a + d] = v;
+        }
+    }
+}
+
+static size_t skinny_lds(int MT) { return (size_t)(SK_WAVES * MT * 16 * 64 + MT * 32 * 8) * sizeof(float); }
+
+hipError_t skinny_init() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_lds(2));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_lds(1));
+}
+
+hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, hipStream_t s) {
+    if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
+    SkinnyJobs js;
+    js.njobs = njobs;
+    js.job[0] = jobs[0];
+    js.job[1] = jobs[njobs - 1];
+    js.tiles0 = (jobs[0].N + 31) / 32;
+    int tiles = js.tiles0 + (njobs > 1 ? (jobs[1].N + 31) / 32 : 0);
+    int B = jobs[0].B;
+    if (njobs > 1 && jobs[1].B != B) return hipErrorInvalidValue;
+    if (B < 1 || B > 64) return hipErrorInvalidValue;
+    if (B > 32) hipLaunchKernelGGL(skinny_kernel<2>, dim3(tiles), dim3(SK_THREADS), skinny_lds(2), s, js);
+    else hipLaunchKernelGGL(skinny_kernel<1>, dim3(tiles), dim3(SK_THREADS), skinny_lds(1), s, js);
+    return hipGetLastError();
+}
+
+}  // namespace gvx

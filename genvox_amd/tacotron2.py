@@ -1,0 +1,341 @@
+"""Host-side mirror of the reference's ``models.tts.tacotron2.Tacotron2`` for the MI355X forward path.
+
+Same constructor, attributes, ``state_dict`` key names, ``forward(batch)`` / ``inference(inputs)``
+contracts and checkpoint helpers as the reference (models/tts/tacotron2.py:416-596,
+models/tts/__init__.py:64-95), but no torch.nn compute: parameters are plain tensors in a module
+tree, and ``forward`` / ``inference`` hand device pointers to the HIP library through the C ABI
+(include/genvox_amd.h).  PyTorch is used for allocation, streams and the user-visible tensors only.
+
+Differences from the reference, on purpose:
+  * inference only: no autograd through ``forward`` (training is out of scope);
+  * the Prenet's always-on dropout (tacotron2.py:143) takes explicit keep masks when the caller
+    supplies ``batch["prenet_keep_masks"]`` (parity tests); otherwise masks are drawn on the device
+    from a seed taken from torch's RNG, so ``torch.manual_seed`` still makes runs repeatable;
+  * ``inference`` accepts a batch (the reference is batch-1 only, tacotron2.py:405) and then also
+    returns ``mel_lengths``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .configs import AudioConfig, BaseConfig, Tacotron2Config, TextConfig
+from .weights import state_dict_spec
+
+MAX_CALL_BATCH = 64  # rows per C-ABI call; larger batches are split on the host
+
+_GAIN = {"linear": "linear", "sigmoid": "sigmoid", "tanh": "tanh", "relu": "relu"}
+
+
+class _Node(nn.Module):
+    """Parameter container; children are created on demand so dotted names nest like the reference's modules."""
+
+    def child(self, name: str) -> "_Node":
+        if name not in self._modules:
+            self.add_module(name, _Node())
+        return self._modules[name]
+
+
+def dims_from_configs(mc: Tacotron2Config, ac: AudioConfig, tc: TextConfig) -> _lib.gvx_dims:
+    assert tc.n_tokens is not None and tc.n_tokens >= 1, "text_config.n_tokens must be set (size of the token map)"
+    return _lib.gvx_dims(
+        n_tokens=tc.n_tokens, embed_dim=mc.encoder_embedding_dim, enc_kernel=mc.encoder_kernel_size,
+        enc_n_conv=mc.encoder_n_convolutions, prenet_dim=mc.prenet_dim, att_rnn_dim=mc.attention_rnn_dim,
+        dec_rnn_dim=mc.decoder_rnn_dim, att_dim=mc.attention_dim, att_loc_filters=mc.attention_location_n_filters,
+        att_loc_kernel=mc.attention_location_kernel_size, postnet_dim=mc.postnet_embedding_dim,
+        postnet_kernel=mc.postnet_kernel_size, postnet_n_conv=mc.postnet_n_convolutions, n_mels=ac.n_mels)
+
+
+class Tacotron2(nn.Module):
+    def __init__(self, model_config: Tacotron2Config, audio_config: AudioConfig, text_config: TextConfig) -> None:
+        super().__init__()
+        self.model_name = self.__class__.__name__
+        self.model_config = model_config
+        self.audio_config = audio_config
+        self.text_config = text_config
+        self._spec = state_dict_spec(model_config, audio_config, text_config)
+        for key, (shape, kind, arg) in self._spec.items():
+            *path, leaf = key.split(".")
+            node = self
+            for name in path:
+                node = node.child(name)
+            if kind == "count":
+                node.register_buffer(leaf, torch.zeros((), dtype=torch.long))
+            elif kind in ("bn_mean", "bn_var"):
+                node.register_buffer(leaf, torch.ones(shape) if kind == "bn_var" else torch.zeros(shape))
+            else:
+                t = torch.empty(shape)
+                if kind == "xavier":
+                    nn.init.xavier_uniform_(t, gain=nn.init.calculate_gain(_GAIN[arg]))
+                elif kind == "uniform":
+                    t.uniform_(-arg, arg)
+                elif kind == "bn_w":
+                    t.fill_(1.0)
+                elif kind == "bn_b":
+                    t.zero_()
+                node.register_parameter(leaf, nn.Parameter(t, requires_grad=False))
+        self._handle: Optional[int] = None
+        self._blob: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._workspace: Optional[torch.Tensor] = None
+        self._timing = False
+        self.eval()
+
+    # child() for the root, which is not a _Node
+    def child(self, name: str) -> _Node:
+        return _Node.child(self, name)
+
+    # ------------------------------------------------------------------ C-ABI plumbing
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.load().gvx_model_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _device(self) -> torch.device:
+        return self.embedding.weight.device
+
+    def _require_gpu(self) -> torch.device:
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("genvox_amd.Tacotron2 runs on an MI355X only: move the model with .to('cuda:0'). "
+                               "There is no CPU fallback (the reference's CPU path is the oracle under oracle/).")
+        return dev
+
+    def _weights_key(self):
+        sd = self.state_dict()
+        return (str(self._device()),) + tuple((v.data_ptr(), v._version) for v in sd.values())
+
+    def _ensure_packed(self) -> None:
+        """Fold / repack the current state_dict into the device blob the kernels read (once per weight version)."""
+        dev = self._require_gpu()
+        key = self._weights_key()
+        if self._packed_key == key:
+            return
+        lib = _lib.load()
+        if self._handle is None:
+            h = C.c_void_p()
+            dims = dims_from_configs(self.model_config, self.audio_config, self.text_config)
+            _lib.check(lib.gvx_model_create(C.byref(dims), C.byref(h)))
+            self._handle = h.value
+        host = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()
+                if v.is_floating_point()}
+        table = (_lib.gvx_weight_desc * len(host))()
+        for i, (k, v) in enumerate(host.items()):
+            table[i] = _lib.gvx_weight_desc(k.encode(), v.data_ptr(), v.numel())
+        nbytes = lib.gvx_model_blob_bytes(self._handle)
+        blob_host = torch.empty(nbytes // 4, dtype=torch.float32)
+        _lib.check(lib.gvx_model_pack_weights(self._handle, table, len(host), blob_host.data_ptr()))
+        self._blob = blob_host.to(dev)
+        _lib.check(lib.gvx_model_bind_blob(self._handle, self._blob.data_ptr()))
+        if self._timing:
+            _lib.check(lib.gvx_stage_timing_enable(self._handle, 1))
+        self._packed_key = key
+
+    def packed_blob(self) -> torch.Tensor:
+        """The packed device weight blob (what a multi-GPU start-up broadcasts, see genvox_amd.dist)."""
+        self._ensure_packed()
+        return self._blob
+
+    def bind_packed_blob(self, blob: torch.Tensor) -> None:
+        """Adopt a packed blob produced by another rank's ``packed_blob()`` (same configs)."""
+        dev = self._require_gpu()
+        lib = _lib.load()
+        if self._handle is None:
+            h = C.c_void_p()
+            dims = dims_from_configs(self.model_config, self.audio_config, self.text_config)
+            _lib.check(lib.gvx_model_create(C.byref(dims), C.byref(h)))
+            self._handle = h.value
+        assert blob.dtype == torch.float32 and blob.device == dev and blob.is_contiguous()
+        assert blob.numel() * 4 == lib.gvx_model_blob_bytes(self._handle), "blob size does not match this model's dims"
+        self._blob = blob
+        _lib.check(lib.gvx_model_bind_blob(self._handle, blob.data_ptr()))
+        self._packed_key = self._weights_key()
+
+    def _get_workspace(self, B: int, L: int, T: int) -> torch.Tensor:
+        need = _lib.load().gvx_workspace_bytes(self._handle, B, L, T)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != self._device():
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self._device())
+        return self._workspace
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def enable_stage_timing(self, enable: bool = True) -> None:
+        self._timing = enable
+        if self._handle is not None:
+            _lib.check(_lib.load().gvx_stage_timing_enable(self._handle, int(enable)))
+
+    def stage_times_ms(self):
+        t = (C.c_float * 5)()
+        n = C.c_int()
+        _lib.check(_lib.load().gvx_stage_times_ms(self._handle, t, C.byref(n)))
+        names = ("encoder", "prenet", "decoder_loop", "projection", "postnet")
+        return dict(zip(names, list(t))), n.value
+
+    def _keep_masks(self, given: Optional[torch.Tensor], n: int, dev) -> torch.Tensor:
+        if given is not None:
+            m = given.to(device=dev, dtype=torch.uint8).contiguous()
+            assert m.numel() == n, f"prenet_keep_masks has {m.numel()} elements, expected {n}"
+            return m
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: torch.manual_seed makes this repeatable
+        m = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.load().gvx_prenet_masks_generate(m.data_ptr(), n, seed, self._stream()))
+        return m
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Teacher-forced text->mel (reference: models/tts/tacotron2.py:450-481). Inference only."""
+        dev = self._require_gpu()
+        self._ensure_packed()
+        tokens = batch["token_padded"].to(device=dev, dtype=torch.int64).contiguous()
+        tok_len = batch["token_lengths"].to(device=dev, dtype=torch.int32).contiguous()
+        mel_in = batch["mel_padded"].to(device=dev, dtype=torch.float32).contiguous()
+        mel_len = batch["mel_lengths"].to(device=dev, dtype=torch.int32).contiguous()
+        B, L = tokens.shape
+        _, M, T = mel_in.shape
+        assert M == self.audio_config.n_mels
+        P = self.model_config.prenet_dim
+        if B > MAX_CALL_BATCH:
+            return self._forward_split(batch)
+        masks = self._keep_masks(batch.get("prenet_keep_masks"), 2 * (T + 1) * B * P, dev)
+        mel_out = torch.empty(B, M, T, device=dev)
+        mel_post = torch.empty(B, M, T, device=dev)
+        gate_out = torch.empty(B, T, device=dev)
+        align = torch.empty(B, T, L, device=dev)
+        ws = self._get_workspace(B, L, T)
+        lib = _lib.load()
+        _lib.check(lib.gvx_tacotron2_forward(
+            self._handle, tokens.data_ptr(), tok_len.data_ptr(), B, L, mel_in.data_ptr(),
+            mel_len.data_ptr() if self.model_config.mask_padding else None, T, masks.data_ptr(),
+            mel_out.data_ptr(), mel_post.data_ptr(), gate_out.data_ptr(), align.data_ptr(),
+            ws.data_ptr(), ws.numel(), self._stream()))
+        return {"mel_outputs": mel_out, "mel_outputs_postnet": mel_post, "gate_outputs": gate_out, "alignments": align}
+
+    def _forward_split(self, batch):
+        B = batch["token_padded"].shape[0]
+        P = self.model_config.prenet_dim
+        T = batch["mel_padded"].shape[2]
+        outs = []
+        for lo in range(0, B, MAX_CALL_BATCH):
+            hi = min(B, lo + MAX_CALL_BATCH)
+            sub = {k: v[lo:hi] for k, v in batch.items() if k != "prenet_keep_masks"}
+            if "prenet_keep_masks" in batch:
+                km = batch["prenet_keep_masks"].reshape(2, T + 1, B, P)
+                sub["prenet_keep_masks"] = km[:, :, lo:hi].contiguous()
+            outs.append(self.forward(sub))
+        return {k: torch.cat([o[k] for o in outs], dim=0) for k in outs[0]}
+
+    def inference(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Autoregressive text->mel (reference: models/tts/tacotron2.py:483-499; Decoder.inference :390-414).
+
+        inputs: ``tokens`` [B, L] (the reference: B = 1); optional ``token_lengths`` [B] for padded batches and
+        ``prenet_keep_masks`` uint8 [2, max_decoder_steps, B, prenet_dim].  Outputs are trimmed to the longest row."""
+        dev = self._require_gpu()
+        self._ensure_packed()
+        tokens = inputs["tokens"].to(device=dev, dtype=torch.int64).contiguous()
+        B, L = tokens.shape
+        assert B <= MAX_CALL_BATCH, f"inference batch {B} > {MAX_CALL_BATCH}: shard across calls or GPUs"
+        lens = inputs.get("token_lengths")
+        lens_t = lens.to(device=dev, dtype=torch.int32).contiguous() if lens is not None else None
+        mc = self.model_config
+        M, E, P, S = self.audio_config.n_mels, mc.encoder_embedding_dim, mc.prenet_dim, mc.max_decoder_steps
+        masks = self._keep_masks(inputs.get("prenet_keep_masks"), 2 * S * B * P, dev)
+        lib = _lib.load()
+        ws = self._get_workspace(B, L, S)
+        memory = torch.empty(B, L, E, device=dev)
+        mel_out = torch.zeros(B, M, S, device=dev)
+        gate_out = torch.zeros(B, S, device=dev)
+        align = torch.zeros(B, S, L, device=dev)
+        n_frames = torch.zeros(B, dtype=torch.int32, device=dev)
+        steps = C.c_int(0)
+        s = self._stream()
+        _lib.check(lib.gvx_encoder_forward(self._handle, tokens.data_ptr(), lens_t.data_ptr() if lens_t is not None else None,
+                                           B, L, memory.data_ptr(), ws.data_ptr(), ws.numel(), s))
+        _lib.check(lib.gvx_decoder_autoregressive(
+            self._handle, memory.data_ptr(), lens_t.data_ptr() if lens_t is not None else None, B, L, S,
+            float(mc.gate_threshold), masks.data_ptr(), mel_out.data_ptr(), gate_out.data_ptr(), align.data_ptr(),
+            n_frames.data_ptr(), C.byref(steps), ws.data_ptr(), ws.numel(), s))
+        n_host = n_frames.cpu()
+        Tn = int(n_host.max())
+        if int((n_host >= S).sum()) > 0 and Tn >= S:
+            print("Warning! Reached max decoder steps")
+        mel_out = mel_out[:, :, :Tn].contiguous()
+        mel_post = torch.empty_like(mel_out)
+        _lib.check(lib.gvx_postnet_forward(self._handle, mel_out.data_ptr(), B, Tn, mel_post.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), s))
+        out = {"mel_outputs": mel_out, "mel_outputs_postnet": mel_post,
+               "gate_outputs": gate_out[:, :Tn].contiguous(), "alignments": align[:, :Tn].contiguous()}
+        if B > 1:
+            out["mel_lengths"] = n_frames
+        return out
+
+    # ---- stage-level entry points (used by the parity tests to localise failures)
+    def encode(self, tokens: torch.Tensor, token_lengths: Optional[torch.Tensor]) -> torch.Tensor:
+        dev = self._require_gpu()
+        self._ensure_packed()
+        tokens = tokens.to(device=dev, dtype=torch.int64).contiguous()
+        B, L = tokens.shape
+        lens = token_lengths.to(device=dev, dtype=torch.int32).contiguous() if token_lengths is not None else None
+        ws = self._get_workspace(B, L, 1)
+        memory = torch.empty(B, L, self.model_config.encoder_embedding_dim, device=dev)
+        _lib.check(_lib.load().gvx_encoder_forward(self._handle, tokens.data_ptr(), lens.data_ptr() if lens is not None else None,
+                                                   B, L, memory.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        return memory
+
+    def postnet_residual(self, mel: torch.Tensor) -> torch.Tensor:
+        dev = self._require_gpu()
+        self._ensure_packed()
+        mel = mel.to(device=dev, dtype=torch.float32).contiguous()
+        B, M, T = mel.shape
+        ws = self._get_workspace(B, 1, T)
+        out = torch.empty_like(mel)
+        _lib.check(_lib.load().gvx_postnet_forward(self._handle, mel.data_ptr(), B, T, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   self._stream()))
+        return out
+
+    # ---- reference contract: batches, checkpoints, configs (models/tts/__init__.py:91-95, tacotron2.py:574-596)
+    def prepare_batch(self, batch: Dict[str, torch.Tensor], device: str) -> Dict[str, torch.Tensor]:
+        for key, val in batch.items():
+            batch[key] = val.to(device=device)
+        return batch
+
+    def get_checkpoint_statedicts(self, optimizer: Optional[Dict] = None) -> Dict:
+        statedicts = {"model_statedict": self.state_dict()}
+        if optimizer is not None:
+            statedicts["optim_statedict"] = optimizer["optimizer"].state_dict()
+        return statedicts
+
+    def load_checkpoint_statedicts(self, statedicts: Dict, save_optimizer_dict: bool = False, optimizer: Optional[Dict] = None) -> None:
+        self.load_state_dict(statedicts["model_statedict"])
+        if save_optimizer_dict:
+            optimizer["optimizer"].load_state_dict(statedicts["optim_statedict"])
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self._packed_key = None
+        return out
+
+    @staticmethod
+    def load_from_config(config_path: str) -> "Tacotron2":
+        configs = BaseConfig.load_configs_from_file(
+            path=config_path,
+            config_map={"text_config": TextConfig, "audio_config": AudioConfig, "model_config": Tacotron2Config})
+        return Tacotron2(**configs)
+
+    def train_step(self, *args, **kwargs):
+        raise NotImplementedError("genvox_amd.Tacotron2 is an inference-only forward path (no backward kernels); "
+                                  "train with the reference and load the checkpoint here.")
+
+    def eval_step(self, batch: Dict, criterion: Optional[Dict] = None, eval_outdir: Optional[str] = None) -> Dict[str, torch.Tensor]:
+        """Forward under no_grad (reference: tacotron2.py:524-528); plotting/loss logging is out of scope."""
+        with torch.no_grad():
+            return self.forward(batch)

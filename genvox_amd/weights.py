@@ -174,7 +174,7 @@ def generate_state_dict(model_config, audio_config, text_config, seed: int = 0, 
     import torch
 
     sd = generate_state_dict_numpy(model_config, audio_config, text_config, seed, peaky_attention)
-    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd.items())
+    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)).reshape(v.shape)) for k, v in sd.items())
 
 
 def synthetic_inputs(B: int, L: int, T: int, n_tokens: int, n_mels: int, seed: int = 3,

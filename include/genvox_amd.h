@@ -1,0 +1,151 @@
+/*
+ * genvox_amd.h — C ABI of the MI355X (gfx950) Tacotron2 text->mel forward path and the
+ * batched Griffin-Lim vocoder.
+ *
+ * The reference (saiakarsh193/GenVox) has no FFI/operator layer: its boundary for this
+ * path is the Python class surface.  This header is the boundary a
+ * native replacement exposes underneath that surface; every entry point names the
+ * reference function it replaces (paths relative to the reference root).  The Python
+ * mirror in genvox_amd/ binds these with ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.
+ *  - Unless a parameter says "host", every pointer is a DEVICE pointer (e.g. tensor.data_ptr()
+ *    of a PyTorch-ROCm tensor).  Outputs and workspaces are caller-allocated; nothing is
+ *    retained after a call returns except the blob pointer given to gvx_model_bind_blob.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *    Calls enqueue work and return; they do not synchronise unless stated.
+ *  - Every int-returning call returns GVX_OK (0) or a negative gvx_status;
+ *    gvx_last_error() gives the message for the calling thread.
+ *  - A gvx_model handle is not thread-safe; distinct handles may be used concurrently.
+ *  - All floating point data is fp32 (the reference's dtype).  Channel dims must be
+ *    multiples of 8 (GVX_ERR_UNSUPPORTED otherwise).
+ */
+#ifndef GENVOX_AMD_H
+#define GENVOX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gvx_status {
+    GVX_OK = 0,
+    GVX_ERR_INVALID_ARG = -1,
+    GVX_ERR_UNSUPPORTED = -2,
+    GVX_ERR_MISSING_WEIGHT = -3,
+    GVX_ERR_SHAPE = -4,
+    GVX_ERR_WORKSPACE = -5,
+    GVX_ERR_HIP = -6,
+    GVX_ERR_STATE = -7
+} gvx_status;
+
+/* Hyper-parameters that fix tensor shapes.  Mirrors configs/models.py:10-26 (Tacotron2Config),
+ * configs/__init__.py:136 (AudioConfig.n_mels) and TextConfig.n_tokens (configs/__init__.py:81). */
+typedef struct gvx_dims {
+    int32_t n_tokens;          /* embedding rows                                   */
+    int32_t embed_dim;         /* symbols_embedding_dim == encoder_embedding_dim   */
+    int32_t enc_kernel;        /* encoder_kernel_size (odd)                        */
+    int32_t enc_n_conv;        /* encoder_n_convolutions                           */
+    int32_t prenet_dim;
+    int32_t att_rnn_dim;
+    int32_t dec_rnn_dim;
+    int32_t att_dim;
+    int32_t att_loc_filters;   /* attention_location_n_filters                     */
+    int32_t att_loc_kernel;    /* attention_location_kernel_size (odd)             */
+    int32_t postnet_dim;       /* postnet_embedding_dim                            */
+    int32_t postnet_kernel;    /* postnet_kernel_size (odd)                        */
+    int32_t postnet_n_conv;
+    int32_t n_mels;
+} gvx_dims;
+
+/* One named fp32 tensor of the reference's state_dict (models/tts/tacotron2.py:574-584). */
+typedef struct gvx_weight_desc {
+    const char* name;      /* e.g. "decoder.attention_rnn.weight_ih"                      */
+    const float* data;     /* HOST pointer, contiguous row-major                          */
+    int64_t numel;
+} gvx_weight_desc;
+
+typedef struct gvx_model gvx_model;
+
+const char* gvx_last_error(void);
+int gvx_version(void);
+
+/* ---- model handle + weights: replaces Tacotron2.__init__ / load_state_dict
+ *      (models/tts/tacotron2.py:417-448, :581-584).
+ * gvx_model_pack_weights folds eval-mode BatchNorm into the conv weights, reorders LSTM gate
+ * rows and lays the recurrent matrices out in MFMA-fragment order, writing one contiguous
+ * blob of gvx_model_blob_bytes() bytes to HOST memory.  The caller copies the blob to the
+ * device (or receives it over RCCL, see gvx_model_blob_bytes) and binds it. */
+int gvx_model_create(const gvx_dims* dims, gvx_model** out);
+void gvx_model_destroy(gvx_model* model);
+size_t gvx_model_blob_bytes(const gvx_model* model);
+int gvx_model_pack_weights(gvx_model* model, const gvx_weight_desc* table, int n, void* host_blob);
+int gvx_model_bind_blob(gvx_model* model, const void* device_blob);
+
+/* Bytes of scratch the calls below need for batch B, L tokens and up to T frames. */
+size_t gvx_workspace_bytes(const gvx_model* model, int B, int L, int T);
+
+/* ---- Encoder: embedding + conv/BN/relu stack + BiLSTM with packed-sequence semantics.
+ * Replaces nn.Embedding + Encoder.forward / Encoder.inference (models/tts/tacotron2.py:459,
+ * :231-246, :248-256).  tokens: int64 [B, L]; lengths: int32 [B] or NULL (= all L);
+ * memory_out: [B, L, embed_dim], zero past each row's length. */
+int gvx_encoder_forward(gvx_model* model, const int64_t* tokens, const int32_t* lengths, int B, int L,
+                        float* memory_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Teacher-forced decoder: Prenet over all frames, T x (attention LSTM, location-sensitive
+ * attention, decoder LSTM), mel/gate projection.  Replaces Decoder.forward
+ * (models/tts/tacotron2.py:365-388; decode :333-363; Attention :89-129; Prenet :140-144).
+ * memory: [B, L, embed_dim]; lengths: int32 [B] or NULL; mel_in: [B, n_mels, T];
+ * keep_masks: uint8 {0,1} [2, (T+1)*B, prenet_dim], row = t*B + b (the two Prenet dropout keep masks);
+ * mel_out: [B, n_mels, T]; gate_out: [B, T] (logits); align_out: [B, T, L]. */
+int gvx_decoder_teacher_forced(gvx_model* model, const float* memory, const int32_t* lengths, int B, int L,
+                               const float* mel_in, int T, const uint8_t* keep_masks,
+                               float* mel_out, float* gate_out, float* align_out,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Autoregressive decoder, batched.  Replaces Decoder.inference (models/tts/tacotron2.py:390-414),
+ * which is batch-1 only; here every row stops on its own: n_frames_out[b] = index of the first step
+ * whose sigmoid(gate) > gate_threshold, plus one (or max_steps).  Frames past n_frames_out[b] are
+ * unspecified.  keep_masks: uint8 [2, max_steps, B, prenet_dim].  Outputs are sized for max_steps:
+ * mel_out [B, n_mels, max_steps], gate_out [B, max_steps], align_out [B, max_steps, L].
+ * This call synchronises the stream (it polls the all-rows-finished flag between step chunks).
+ * steps_run_out (HOST int) receives the number of steps actually executed. */
+int gvx_decoder_autoregressive(gvx_model* model, const float* memory, const int32_t* lengths, int B, int L,
+                               int max_steps, float gate_threshold, const uint8_t* keep_masks,
+                               float* mel_out, float* gate_out, float* align_out, int32_t* n_frames_out,
+                               int* steps_run_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Postnet + residual: mel_post_out = mel_in + Postnet(mel_in).  Replaces Postnet.forward and the
+ * residual add (models/tts/tacotron2.py:194-200, :464/:491).  Tensors are [B, n_mels, T]. */
+int gvx_postnet_forward(gvx_model* model, const float* mel_in, int B, int T, float* mel_post_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Output padding mask (models/tts/tacotron2.py:466-473): frames >= mel_lengths[b] get
+ * mel = 0, mel_post = 0, gate = 1e3.  mel_lengths: int32 [B]. In place. */
+int gvx_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths,
+                     int B, int n_mels, int T, void* stream);
+
+/* ---- Whole teacher-forced forward in one call (what Tacotron2.forward does, models/tts/tacotron2.py:450-481).
+ * mel_lengths may be NULL (no padding mask). */
+int gvx_tacotron2_forward(gvx_model* model, const int64_t* tokens, const int32_t* token_lengths, int B, int L,
+                          const float* mel_in, const int32_t* mel_lengths, int T, const uint8_t* keep_masks,
+                          float* mel_out, float* mel_post_out, float* gate_out, float* align_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Prenet keep-mask generator for callers that do not supply masks (the reference draws them from
+ * torch's RNG inside F.dropout, models/tts/tacotron2.py:143).  Writes n bytes of Bernoulli(0.5) {0,1}. */
+int gvx_prenet_masks_generate(uint8_t* masks_out, size_t n, uint64_t seed, void* stream);
+
+/* ---- Stage timing (measurement only): when enabled, the whole-forward call records HIP events around
+ * each stage on `stream`; gvx_stage_times_ms synchronises and returns encoder, prenet, decoder loop,
+ * projection, postnet milliseconds of the last call and the number of decoder-step kernel launches. */
+int gvx_stage_timing_enable(gvx_model* model, int enable);
+int gvx_stage_times_ms(gvx_model* model, float* times5_out, int* decoder_launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENVOX_AMD_H */

@@ -9,7 +9,7 @@ SMALL = dict(
                decoder_rnn_dim=64, attention_rnn_dim=48, prenet_dim=24, attention_dim=16,
                attention_location_n_filters=8, attention_location_kernel_size=7,
                postnet_embedding_dim=40, postnet_kernel_size=5, postnet_n_convolutions=3),
-    n_mels=20, n_tokens=17)
+    n_mels=24, n_tokens=17)
 
 TF_CASES = {
     "tf_full": dict(dims=FULL, weight_seed=0, input_seed=3, mask_seed=11, B=3, L=24, T=40,

@@ -46,6 +46,8 @@ SIGNATURES = {
     "gvx_prenet_masks_generate": (_i, [_vp, _sz, C.c_uint64, _vp]),
     "gvx_stage_timing_enable": (_i, [_vp, _i]),
     "gvx_stage_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
+    "gvx_kernel_timing_enable": (_i, [_vp, _i]),
+    "gvx_kernel_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i)]),
 }
 
 _lib = None

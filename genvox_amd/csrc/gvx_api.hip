@@ -88,6 +88,18 @@ struct gvx_model {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     int last_decoder_launches = 0;
+    // per-launch timing of the decoder step kernels (measurement only)
+    bool ktiming = false;
+    std::vector<hipEvent_t> kev;
+    int n_lstm_ev = 0, n_attn_ev = 0;
+    int reserve_events(size_t n) {
+        while (kev.size() < n) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return GVX_ERR_HIP;
+            kev.push_back(e);
+        }
+        return GVX_OK;
+    }
     // derived
     int H() const { return d.embed_dim / 2; }
     int PS() const { return (d.n_mels + 1 + 3) & ~3; }  // padded row stride of the mel+gate projection
@@ -265,6 +277,7 @@ void gvx_model_destroy(gvx_model* m) {
     if (!m) return;
     if (m->ev_valid)
         for (auto& e : m->ev) (void)hipEventDestroy(e);
+    for (auto& e : m->kev) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -465,7 +478,7 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
             J.seq_out = memory_out + (size_t)dir * H; J.seq_bs = (long)L * E; J.seq_ts = E;
             J.h_prev = h_cur; J.h_prev_stride = H;
         }
-        HIP_TRY(launch_skinny(jobs, 2, s));
+        HIP_TRY(launch_skinny(jobs, 2, SK_ENCODER, s));
     }
     return GVX_OK;
 }
@@ -579,20 +592,32 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     // ---- T decoder steps.  Launch 1 of step t: attention-LSTM(t) together with decoder-LSTM(t-1), which is off
     // the critical chain (only the next step's projection needs it).  Launch 2: attention(t).
     int launches = 0;
+    const bool kt = m->ktiming;
+    if (kt) {
+        rc = m->reserve_events(4 * (size_t)T + 4);
+        if (rc != GVX_OK) return rc;
+        m->n_lstm_ev = m->n_attn_ev = 0;
+    }
+    size_t evi = 0;
+    auto mark = [&](hipStream_t st) -> hipError_t { return kt ? hipEventRecord(m->kev[evi++], st) : hipSuccess; };
     for (int t = 0; t < T; ++t) {
         SkinnyJob jobs[2];
         fill_att_job(m, jobs[0], db.prenet + (size_t)t * B * P, P, t, B, db);
         if (t > 0) fill_dec_job(m, jobs[1], t - 1, B, db);
-        HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, s));
+        HIP_TRY(mark(s));
+        HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, SK_DECODER, s));
+        HIP_TRY(mark(s));
         AttnParams ap;
         fill_attn(m, ap, memory, lengths, t, B, L, align_out, (long)T * L, L, db);
         HIP_TRY(launch_attention(ap, s));
+        HIP_TRY(mark(s));
         launches += 2;
     }
+    if (kt) { m->n_lstm_ev = T; m->n_attn_ev = T; }
     {
         SkinnyJob job;
         fill_dec_job(m, job, T - 1, B, db);
-        HIP_TRY(launch_skinny(&job, 1, s));
+        HIP_TRY(launch_skinny(&job, 1, SK_DECODER, s));
         ++launches;
     }
     m->last_decoder_launches = launches;
@@ -712,6 +737,30 @@ int gvx_stage_timing_enable(gvx_model* m, int enable) {
     return GVX_OK;
 }
 
+int gvx_kernel_timing_enable(gvx_model* m, int enable) {
+    if (!m) return fail(GVX_ERR_INVALID_ARG, "null model");
+    m->ktiming = enable != 0;
+    return GVX_OK;
+}
+
+int gvx_kernel_times_ms(gvx_model* m, float* lstm_avg_ms, float* attn_avg_ms, int* n_steps) {
+    if (!m || !lstm_avg_ms || !attn_avg_ms) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (m->n_lstm_ev < 1) return fail(GVX_ERR_STATE, "no timed decoder loop has run");
+    const int T = m->n_lstm_ev;
+    HIP_TRY(hipEventSynchronize(m->kev[3 * (size_t)T - 1]));
+    double lstm = 0, attn = 0;
+    for (int t = 0; t < T; ++t) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, m->kev[3 * (size_t)t], m->kev[3 * (size_t)t + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, m->kev[3 * (size_t)t + 1], m->kev[3 * (size_t)t + 2]));
+        lstm += a; attn += b;
+    }
+    *lstm_avg_ms = (float)(lstm / T);
+    *attn_avg_ms = (float)(attn / T);
+    if (n_steps) *n_steps = T;
+    return GVX_OK;
+}
+
 int gvx_stage_times_ms(gvx_model* m, float* t5, int* launches) {
     if (!m || !t5) return fail(GVX_ERR_INVALID_ARG, "null argument");
     if (!m->ev_valid) return fail(GVX_ERR_STATE, "stage timing was not enabled");
@@ -757,28 +806,28 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
             job.N = P; job.nkg = M / 8; job.mode = 1; job.B = B; job.act = ACT_RELU;
             job.y = db.pre1; job.y_stride = P;
             job.keep = keep_masks + (size_t)t * B * P; job.keep_stride = P;
-            HIP_TRY(launch_skinny(&job, 1, s));
+            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
             job.Wp = m->dev_blob + m->blob.pre_w1_frag;
             job.x[0] = XSeg{db.pre1, (long)P, P};
             job.nkg = P / 8;
             job.y = db.prenet;
             job.keep = keep_masks + ((size_t)T + t) * B * P;
-            HIP_TRY(launch_skinny(&job, 1, s));
+            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
             SkinnyJob lj;
             fill_att_job(m, lj, db.prenet, P, t, B, db);
-            HIP_TRY(launch_skinny(&lj, 1, s));
+            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, s));
             AttnParams ap;
             fill_attn(m, ap, memory, lengths, t, B, L, align_out, (long)T * L, L, db);
             HIP_TRY(launch_attention(ap, s));
             fill_dec_job(m, lj, t, B, db);
-            HIP_TRY(launch_skinny(&lj, 1, s));
+            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, s));
             // mel + gate projection of this step
             std::memset(&job, 0, sizeof job);
             job.Wp = m->dev_blob + m->blob.proj_frag; job.bias = m->dev_blob + m->blob.proj_b;
             job.x[0] = XSeg{db.hc + (size_t)(t + 1) * B * (D + E), (long)(D + E), D + E};
             job.N = M + 1; job.nkg = (D + E) / 8; job.mode = 1; job.B = B; job.act = ACT_NONE;
             job.y = db.proj + (size_t)t * B * PS; job.y_stride = PS;
-            HIP_TRY(launch_skinny(&job, 1, s));
+            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
             HIP_TRY(launch_ar_emit(db.proj + (size_t)t * B * PS, PS, mel_out, gate_out, B, M, T, t, s));
             HIP_TRY(launch_ar_stop(db.proj + (size_t)t * B * PS, PS, M, gate_threshold, t, B, n_frames_out, n_done, s));
         }

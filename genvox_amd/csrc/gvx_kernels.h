@@ -65,7 +65,8 @@ struct SkinnyJob {
     int act;
     int B;
 };
-hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, hipStream_t s);
+enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_LINEAR = 2 };  // kernel name only; same code
+hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Location-sensitive attention, one step, one workgroup per batch row.

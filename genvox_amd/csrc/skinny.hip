@@ -39,7 +39,7 @@ struct SkinnyJobs {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 template <int MT>
-__global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkinnyJobs jobs) {
+__device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                                   // [SK_WAVES][MT][16][64]
     float* hs = smem + SK_WAVES * MT * 16 * 64;          // [MT*32][8] h' of this tile (LSTM + q slabs)
@@ -196,29 +196,52 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkinnyJobs jobs) {
     }
 }
 
+// Same body under three kernel names so that profiles separate the decoder step (the dominant kernel of the
+// path) from the encoder recurrence and the autoregressive GEMVs.
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT>(jobs); }
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT>(jobs); }
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void skinny_linear_kernel(SkinnyJobs jobs) { skinny_body<MT>(jobs); }
+
 static size_t skinny_lds(int MT) { return (size_t)(SK_WAVES * MT * 16 * 64 + MT * 32 * 8) * sizeof(float); }
 
-hipError_t skinny_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_lds(2));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_lds(1));
+template <typename K>
+static hipError_t set_lds(K kern, int MT) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_lds(MT));
 }
 
-hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, hipStream_t s) {
+hipError_t skinny_init() {
+    hipError_t e;
+    if ((e = set_lds(decoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
+    if ((e = set_lds(decoder_lstm_step_kernel<2>, 2)) != hipSuccess) return e;
+    if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
+    if ((e = set_lds(encoder_lstm_step_kernel<2>, 2)) != hipSuccess) return e;
+    if ((e = set_lds(skinny_linear_kernel<1>, 1)) != hipSuccess) return e;
+    return set_lds(skinny_linear_kernel<2>, 2);
+}
+
+hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s) {
     if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
     SkinnyJobs js;
     js.njobs = njobs;
     js.job[0] = jobs[0];
     js.job[1] = jobs[njobs - 1];
     js.tiles0 = (jobs[0].N + 31) / 32;
-    int tiles = js.tiles0 + (njobs > 1 ? (jobs[1].N + 31) / 32 : 0);
-    int B = jobs[0].B;
+    const int tiles = js.tiles0 + (njobs > 1 ? (jobs[1].N + 31) / 32 : 0);
+    const int B = jobs[0].B;
     if (njobs > 1 && jobs[1].B != B) return hipErrorInvalidValue;
     if (B < 1 || B > 64) return hipErrorInvalidValue;
-    if (B > 32) hipLaunchKernelGGL(skinny_kernel<2>, dim3(tiles), dim3(SK_THREADS), skinny_lds(2), s, js);
-    else hipLaunchKernelGGL(skinny_kernel<1>, dim3(tiles), dim3(SK_THREADS), skinny_lds(1), s, js);
+    const dim3 grid(tiles), block(SK_THREADS);
+    if (B > 32) {
+        const size_t lds = skinny_lds(2);
+        if (kind == SK_DECODER) decoder_lstm_step_kernel<2><<<grid, block, lds, s>>>(js);
+        else if (kind == SK_ENCODER) encoder_lstm_step_kernel<2><<<grid, block, lds, s>>>(js);
+        else skinny_linear_kernel<2><<<grid, block, lds, s>>>(js);
+    } else {
+        const size_t lds = skinny_lds(1);
+        if (kind == SK_DECODER) decoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
+        else if (kind == SK_ENCODER) encoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
+        else skinny_linear_kernel<1><<<grid, block, lds, s>>>(js);
+    }
     return hipGetLastError();
 }
 

@@ -181,6 +181,15 @@ class Tacotron2(nn.Module):
         names = ("encoder", "prenet", "decoder_loop", "projection", "postnet")
         return dict(zip(names, list(t))), n.value
 
+    def enable_kernel_timing(self, enable: bool = True) -> None:
+        self._ensure_packed()
+        _lib.check(_lib.load().gvx_kernel_timing_enable(self._handle, int(enable)))
+
+    def kernel_times_ms(self):
+        a, b, n = C.c_float(), C.c_float(), C.c_int()
+        _lib.check(_lib.load().gvx_kernel_times_ms(self._handle, C.byref(a), C.byref(b), C.byref(n)))
+        return {"decoder_lstm_step": a.value, "attention_step": b.value, "steps": n.value}
+
     def _keep_masks(self, given: Optional[torch.Tensor], n: int, dev) -> torch.Tensor:
         if given is not None:
             m = given.to(device=dev, dtype=torch.uint8).contiguous()

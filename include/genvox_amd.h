@@ -145,6 +145,12 @@ int gvx_prenet_masks_generate(uint8_t* masks_out, size_t n, uint64_t seed, void*
 int gvx_stage_timing_enable(gvx_model* model, int enable);
 int gvx_stage_times_ms(gvx_model* model, float* times5_out, int* decoder_launches_out);
 
+/* ---- Per-launch timing of the decoder step (measurement only): when enabled, the teacher-forced loop brackets
+ * every LSTM-step launch and every attention launch with HIP events on `stream`; gvx_kernel_times_ms synchronises
+ * and returns the average duration of each over the last call's T steps. */
+int gvx_kernel_timing_enable(gvx_model* model, int enable);
+int gvx_kernel_times_ms(gvx_model* model, float* lstm_avg_ms_out, float* attn_avg_ms_out, int* n_steps_out);
+
 #ifdef __cplusplus
 }
 #endif

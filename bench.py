@@ -45,6 +45,10 @@ def algorithmic_bytes_decoder_step(mc, B, L):
     return 4 * (18103953 + B * (645 * L + 9553))
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,9 +95,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    log(f"rank {rank}: weights bound, inputs resident; warmup {args.warmup}")
     for _ in range(args.warmup):
         model.forward(batch)
     sync_all()
+    log("timed region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = model.forward(batch)
@@ -104,6 +110,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out["mel_outputs_postnet"]).all()
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
 
     # ---- instrumented pass (not part of the timed region): per-launch and per-stage device times
     roofline, stages = None, None
@@ -141,16 +148,26 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tacotron2_ref
 
-        n_thr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+        # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribe
+        n_thr = max(1, min(int(os.environ.get("GVX_CPU_THREADS", "16")), os.cpu_count() or 1, len(os.sched_getaffinity(0))))
         torch.set_num_threads(n_thr)
-        Tc = min(T, 200)
         sd = gw.generate_state_dict(mc, ac, tc, seed=0)
-        sub = gw.synthetic_inputs(B, L, Tc, tc.n_tokens, ac.n_mels, seed=3)
-        cb = {k: torch.from_numpy(v) for k, v in sub.items()}
-        masks = torch.from_numpy(gw.prenet_keep_masks((Tc + 1) * B, mc.prenet_dim))
-        c0 = time.perf_counter()
-        tacotron2_ref.tacotron2_forward(sd, cb, masks, mask_padding=True)
-        cpu_s = time.perf_counter() - c0
+
+        def run_cpu(Tc):
+            sub = gw.synthetic_inputs(B, L, Tc, tc.n_tokens, ac.n_mels, seed=3)
+            cb = {k: torch.from_numpy(v) for k, v in sub.items()}
+            masks = torch.from_numpy(gw.prenet_keep_masks((Tc + 1) * B, mc.prenet_dim))
+            c0 = time.perf_counter()
+            tacotron2_ref.tacotron2_forward(sd, cb, masks, mask_padding=True)
+            return time.perf_counter() - c0
+
+        log(f"cpu baseline: oracle on {n_thr} threads")
+        Tc = min(T, 16)
+        probe_s = run_cpu(Tc)  # short probe sizes the sample to ~10-20 s of CPU work
+        log(f"cpu probe: {Tc} frames in {probe_s:.2f} s")
+        Tc = int(max(Tc, min(T, Tc * 15.0 / max(probe_s, 1e-3))))
+        cpu_s = run_cpu(Tc)
+        log(f"cpu sample: {Tc} frames in {cpu_s:.2f} s")
         cpu = {"value": round(B * Tc / cpu_s, 1), "unit": "mel-frames/s", "cores": n_thr, "kind": "port",
                "sample": f"oracle teacher-forced forward, batch {B} x {Tc} frames x {L} tokens (first {Tc} of {T} frames), "
                          f"{cpu_s:.1f} s, torch {torch.__version__} CPU"}

@@ -201,14 +201,23 @@ def tacotron2_forward(sd, batch: Dict[str, torch.Tensor], keep_masks: torch.Tens
 
 @torch.no_grad()
 def tacotron2_inference(sd, tokens: torch.Tensor, keep_masks: torch.Tensor, gate_threshold: float,
-                        max_decoder_steps: int) -> Dict[str, torch.Tensor]:
+                        max_decoder_steps: int, token_length: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """Autoregressive Tacotron2.inference (tacotron2.py:483-499) with Decoder.inference (:390-414).
 
     Batch 1 only, like the reference (its stop test at :405 is a scalar truth test).
-    keep_masks: uint8 [2, max_decoder_steps, P]; step t uses [0, t] then [1, t]."""
+    keep_masks: uint8 [2, max_decoder_steps, P]; step t uses [0, t] then [1, t].
+    token_length (not in the reference's inference, which never pads): the row is one row of a PADDED batch;
+    it is then treated exactly as Tacotron2.forward treats padded rows (:459-462): convs run over the pad-token
+    embeddings unmasked, packed BiLSTM, -inf attention mask past the length.  This is the semantics the batched
+    autoregressive extension is checked against."""
     assert tokens.shape[0] == 1
-    memory = encoder(sd, tokens, None)
-    st = _DecoderState(sd, memory, None)
+    if token_length is None:
+        memory = encoder(sd, tokens, None)
+        st = _DecoderState(sd, memory, None)
+    else:
+        lens = torch.tensor([token_length])
+        memory = encoder(sd, tokens, lens)
+        st = _DecoderState(sd, memory, lengths_to_pad_mask(lens, tokens.shape[1]))
     M = sd["decoder.linear_projection.linear_layer.weight"].shape[0]
     frame = torch.zeros(1, M)
     mels, gates, aligns = [], [], []

@@ -90,13 +90,14 @@ def test_batched_autoregressive_rows_match_batch1_runs():
     out = m.inference({"tokens": torch.from_numpy(tok), "token_lengths": torch.tensor(lens), "prenet_keep_masks": masks})
     n_frames = out["mel_lengths"].cpu().tolist()
     for b, n in enumerate(lens):
-        want = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(tok[b:b + 1, :n]), masks[:, :, b],
-                                                 float(fx["gate_threshold"]), steps)
+        # padded-row semantics of the reference's batched forward (conv over pad embeddings, packed LSTM, masked softmax)
+        want = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(tok[b:b + 1]), masks[:, :, b],
+                                                 float(fx["gate_threshold"]), steps, token_length=n)
         nf = want["mel_outputs"].shape[2]
         assert n_frames[b] == nf, (b, n_frames[b], nf)
         assert max_abs_diff(out["mel_outputs"][b:b + 1, :, :nf], want["mel_outputs"]) <= TOL
         assert max_abs_diff(out["gate_outputs"][b:b + 1, :nf], want["gate_outputs"]) <= TOL
-        assert max_abs_diff(out["alignments"][b:b + 1, :nf, :n], want["alignments"]) <= TOL
+        assert max_abs_diff(out["alignments"][b:b + 1, :nf], want["alignments"]) <= TOL
 
 
 def test_full_size_properties_and_long_horizon_parity():

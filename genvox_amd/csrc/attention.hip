@@ -38,19 +38,20 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 struct AttnLds {
-    int q_off, v_off, wc_off, cw_off, f_off, e_off, red_off, total;  // float offsets
+    int q_off, v_off, wc_off, cw_off, f_off, e_off, red_off, part_off, total;  // float offsets
 };
 __host__ __device__ inline AttnLds attn_lds_layout(int L, int a, int F, int kl) {
     AttnLds o;
     auto al = [](int x) { return (x + 3) & ~3; };
     int off = 0;
-    o.q_off = off; off += al(a * 4);                    // q partial sums [4][a]
+    o.q_off = off; off += al(a * 16);                   // q partial sums [<=16][a]
     o.v_off = off; off += al(a);
     o.wc_off = off; off += al(2 * (L + kl - 1));        // [2][L + kl - 1] with zero halo
     o.cw_off = off; off += al(2 * kl * AT_FP);          // conv weights [2][kl][AT_FP]
     o.f_off = off; off += AT_LC * AT_FP;                // location features of the current chunk
     o.e_off = off; off += al(L);                        // energies, then weights
     o.red_off = off; off += 4 * 512 + 32;               // context partials [4][E<=512] + scalars
+    o.part_off = off; off += AT_LC * 65;                // per-lane energy partials [AT_LC][64 (+1 pad)]
     o.total = off;
     return o;
 }
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(AttnParams p) {
     float* fb = smem + lo.f_off;
     float* es = smem + lo.e_off;
     float* red = smem + lo.red_off;
+    float* part = smem + lo.part_off;
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,12 +76,30 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(AttnParams p) {
     const int pad = (kl - 1) / 2, LW = L + kl - 1;
     const int len = p.lengths ? p.lengths[b] : L;
 
-    // ---- stage: q partial sums (4 parts), v, previous / cumulative weights with halo, conv weights
-    for (int idx = tid; idx < 4 * a; idx += AT_THREADS) {
-        const int part = idx / a, d = idx - part * a;
-        float s = 0.f;
-        for (int t = part; t < p.n_slabs; t += 4) s += p.q_slab[((long)t * p.B + b) * a + d];
-        qs[idx] = s;
+    // ---- stage: attention query = sum of the LSTM kernel's per-tile partial products.  Rows of a/4 float4;
+    // AT_THREADS/(a/4) slab rows are summed in parallel (<= 16 groups), 8 independent loads in flight per thread.
+    const int a4 = a >> 2;
+    const int qgroups = min(16, AT_THREADS / a4);
+    {
+        const int grp = tid / a4, d4 = tid - grp * a4;
+        if (grp < qgroups) {
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4* base = reinterpret_cast<const float4*>(p.q_slab + (long)b * a) + d4;
+            const long tstride = (long)p.B * a4;
+            int t = grp;
+            for (; t + 7 * qgroups < p.n_slabs; t += 8 * qgroups) {
+                float4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = base[(long)(t + i * qgroups) * tstride];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s4.x += v[i].x; s4.y += v[i].y; s4.z += v[i].z; s4.w += v[i].w; }
+            }
+            for (; t < p.n_slabs; t += qgroups) {
+                const float4 v = base[(long)t * tstride];
+                s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+            }
+            reinterpret_cast<float4*>(qs + grp * a)[d4] = s4;
+        }
     }
     for (int idx = tid; idx < a; idx += AT_THREADS) vs[idx] = p.v[idx];
     for (int idx = tid; idx < 2 * LW; idx += AT_THREADS) {
@@ -105,13 +125,27 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < DPL; ++i) {
         const int d = lane + 64 * i;
-        qv[i] = d < a ? (qs[d] + qs[a + d]) + (qs[2 * a + d] + qs[3 * a + d]) : 0.f;
+        float qsum = 0.f;
+        if (d < a) for (int g = 0; g < qgroups; ++g) qsum += qs[g * a + d];
+        qv[i] = qsum;
         vv[i] = d < a ? vs[d] : 0.f;
     }
 
     // ---- location features + energies, AT_LC positions at a time
     for (int l0 = 0; l0 < L; l0 += AT_LC) {
         const int lc = min(AT_LC, L - l0);
+        // processed-memory values of this wave's positions: issued now, consumed after the conv (latency hidden)
+        float pmv[AT_LC / AT_WAVES][DPL];
+#pragma unroll
+        for (int j = 0; j < AT_LC / AT_WAVES; ++j) {
+            const int ll = wave + j * AT_WAVES;
+            const float* pmrow = p.pm + ((long)b * L + l0 + min(ll, lc - 1)) * a;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                pmv[j][i] = d < a ? pmrow[d] : 0.f;
+            }
+        }
         {   // conv: thread = (position, quarter of the filters)
             const int ll = tid & (AT_LC - 1), cq = tid >> 7;  // 4 quarters of 8 filters
             float acc[8];
@@ -137,16 +171,16 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(AttnParams p) {
             *reinterpret_cast<float4*>(frow + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
         __syncthreads();
-        // energies: a wave takes positions wave, wave+8, ...; lane = attention dim(s)
-        for (int ll = wave; ll < lc; ll += AT_WAVES) {
-            const int l = l0 + ll;
-            float part = 0.f;
-            const float* pmrow = p.pm + ((long)b * L + l) * a;
+        // energies: a wave takes positions wave, wave+8, ...; lane = attention dim(s); per-lane partials go to LDS
+        // and are reduced over the 64 lanes in one batched pass (instead of 6 cross-lane shuffles per position)
+#pragma unroll
+        for (int j = 0; j < AT_LC / AT_WAVES; ++j) {
+            const int ll = wave + j * AT_WAVES;
+            float pe = 0.f;
+            const float* frow = fb + ll * AT_FP;
 #pragma unroll
             for (int i = 0; i < DPL; ++i) {
-                const int d = lane + 64 * i;
-                float s = qv[i] + (d < a ? pmrow[d] : 0.f);
-                const float* frow = fb + ll * AT_FP;
+                float s = qv[i] + pmv[j][i];
 #pragma unroll
                 for (int c4 = 0; c4 < AT_FP / 4; ++c4) {
                     const float4 fv = *reinterpret_cast<const float4*>(frow + 4 * c4);
@@ -155,10 +189,20 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(AttnParams p) {
                     s = fmaf(wd[i][4 * c4 + 2], fv.z, s);
                     s = fmaf(wd[i][4 * c4 + 3], fv.w, s);
                 }
-                part = fmaf(vv[i], fast_tanh(s), part);
+                pe = fmaf(vv[i], fast_tanh(s), pe);
             }
-            part = wave_sum(part);
-            if (lane == 0) es[l] = l < len ? part : -INFINITY;
+            part[ll * 65 + lane] = pe;
+        }
+        __syncthreads();
+        {   // thread = (position, quarter of the lanes): 16 partials each, then 2 shuffles
+            const int ll = tid >> 2, qd = tid & 3;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += part[ll * 65 + qd * 16 + i];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            const int l = l0 + ll;
+            if (qd == 0 && ll < lc) es[l] = l < len ? s : -INFINITY;
         }
         __syncthreads();
     }
@@ -192,7 +236,7 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(AttnParams p) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e4 < e4n) {
             const float4* mrow = reinterpret_cast<const float4*>(p.memory + (long)b * L * E) + e4;
-#pragma unroll 4
+#pragma unroll 8
             for (int l = lp; l < len; l += 4) {
                 const float w = es[l];
                 const float4 mv = mrow[(long)l * e4n];

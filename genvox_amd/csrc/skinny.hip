@@ -28,7 +28,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int SK_WAVES = 8;
 constexpr int SK_THREADS = SK_WAVES * 64;
-constexpr int SK_UNROLL = 4;  // k-groups in flight per wave and per batch tile
 
 struct SkinnyJobs {
     SkinnyJob job[2];
@@ -38,7 +37,7 @@ struct SkinnyJobs {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int MT>
+template <int MT, int DEPTH>
 __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                                   // [SK_WAVES][MT][16][64]
@@ -47,25 +46,28 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     const int jsel = (jobs.njobs > 1 && (int)blockIdx.x >= jobs.tiles0) ? 1 : 0;
     const SkinnyJob& J = jobs.job[jsel];
     const int tile = (int)blockIdx.x - (jsel ? jobs.tiles0 : 0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, counted waits
     const int bl = lane & 31, h = lane >> 5;
 
-    // ---- main loop: this wave's K slice
+    // ---- main loop: this wave's K slice, software pipelined DEPTH k-groups deep.
+    // Per k-group a wave issues one 1-KiB weight load (HBM / Infinity Cache) and MT x-loads (L2); with DEPTH
+    // groups in flight per wave and 8 waves per CU about DEPTH*8 KiB of weights are outstanding per CU, which is
+    // what it takes to cover the ~2 us loaded-memory latency at ~30 GB/s per CU.  No load is conditional (indices
+    // are clamped instead) so the compiler can retire them with counted s_waitcnt vmcnt(N).
     const int per = (J.nkg + SK_WAVES - 1) / SK_WAVES;
     const int kg_begin = wave * per;
     const int kg_end = min(J.nkg, kg_begin + per);
     const int e0 = J.x[0].len, e1 = e0 + J.x[1].len;
 
-    const float* xb[MT][3];
-    bool row_ok[MT];
+    const float* xb0[MT]; const float* xb1[MT]; const float* xb2[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int b = mt * 32 + bl;
-        row_ok[mt] = b < J.B;
-        const long bb = row_ok[mt] ? b : 0;
-        xb[mt][0] = J.x[0].p ? J.x[0].p + bb * J.x[0].stride + 4 * h : nullptr;
-        xb[mt][1] = J.x[1].p ? J.x[1].p + bb * J.x[1].stride + 4 * h - e0 : nullptr;
-        xb[mt][2] = J.x[2].p ? J.x[2].p + bb * J.x[2].stride + 4 * h - e1 : nullptr;
+        const long bb = b < J.B ? b : 0;  // rows past B read row 0; their results are never stored
+        xb0[mt] = J.x[0].p + bb * J.x[0].stride + 4 * h;
+        xb1[mt] = (J.x[1].p ? J.x[1].p : J.x[0].p) + bb * J.x[1].stride + 4 * h - e0;
+        xb2[mt] = (J.x[2].p ? J.x[2].p : J.x[0].p) + bb * J.x[2].stride + 4 * h - e1;
     }
     const float4* wp = reinterpret_cast<const float4*>(J.Wp) + ((long)tile * J.nkg) * 64 + lane;
 
@@ -75,32 +77,50 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[mt][q] = 0.f;
 
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int kg = kg_begin; kg < kg_end; kg += SK_UNROLL) {
-        float4 wv[SK_UNROLL], xv[MT][SK_UNROLL];
-#pragma unroll
-        for (int u = 0; u < SK_UNROLL; ++u) {
-            const int g = kg + u;
-            const bool ok = g < kg_end;
-            wv[u] = ok ? wp[(long)g * 64] : zero4;
-            const int k = 8 * g;
-            const int sidx = (k < e0) ? 0 : ((k < e1) ? 1 : 2);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float* base = sidx == 0 ? xb[mt][0] : (sidx == 1 ? xb[mt][1] : xb[mt][2]);
-                xv[mt][u] = (ok && row_ok[mt]) ? *reinterpret_cast<const float4*>(base + k) : zero4;
-            }
+    if (kg_begin < kg_end) {
+        float4 wv[DEPTH], xv[MT][DEPTH];
+        const int g_last = kg_end - 1;
+#define SK_LOAD(slot, gg)                                                                         \
+        {                                                                                             \
+            const int g_ = min((gg), g_last);                                                         \
+            wv[slot] = wp[(long)g_ * 64];                                                             \
+            const int k_ = 8 * g_;                                                                    \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                       \
+                const float* base_ = k_ < e0 ? xb0[mt] : (k_ < e1 ? xb1[mt] : xb2[mt]);               \
+                xv[mt][slot] = *reinterpret_cast<const float4*>(base_ + k_);                          \
+            }                                                                                         \
         }
 #pragma unroll
-        for (int u = 0; u < SK_UNROLL; ++u) {
+        for (int u = 0; u < DEPTH; ++u) SK_LOAD(u, kg_begin + u)
+#define SK_MFMA(slot)                                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                               \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].x, xv[mt][slot].x, acc[mt], 0, 0, 0); \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].y, xv[mt][slot].y, acc[mt], 0, 0, 0); \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].z, xv[mt][slot].z, acc[mt], 0, 0, 0); \
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].w, xv[mt][slot].w, acc[mt], 0, 0, 0); \
+        }
+        int base = kg_begin;
+        // steady state: every slot is valid and so is its refill -> branch-free body, counted waits
+        for (; base + 2 * DEPTH <= kg_end; base += DEPTH) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u].x, xv[mt][u].x, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u].y, xv[mt][u].y, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u].z, xv[mt][u].z, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u].w, xv[mt][u].w, acc[mt], 0, 0, 0);
+            for (int u = 0; u < DEPTH; ++u) {
+                SK_MFMA(u)
+                SK_LOAD(u, base + u + DEPTH)
+                // keep the refill right behind the MFMAs that freed its registers: left alone, the scheduler sinks
+                // all refills to the end of the pass and the wave drains to vmcnt(0) every DEPTH groups
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // drain: at most two passes
+        for (; base < kg_end; base += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                if (base + u < kg_end) SK_MFMA(u)
+                if (base + DEPTH < kg_end) SK_LOAD(u, base + u + DEPTH)
+            }
+        }
+#undef SK_MFMA
+#undef SK_LOAD
     }
 
     // ---- cross-wave K reduction through LDS
@@ -198,9 +218,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 
 // Same body under three kernel names so that profiles separate the decoder step (the dominant kernel of the
 // path) from the encoder recurrence and the autoregressive GEMVs.
-template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT>(jobs); }
-template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT>(jobs); }
-template <int MT> __global__ __launch_bounds__(SK_THREADS) void skinny_linear_kernel(SkinnyJobs jobs) { skinny_body<MT>(jobs); }
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? 8 : 6)>(jobs); }
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? 8 : 6)>(jobs); }
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void skinny_linear_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? 8 : 6)>(jobs); }
 
 static size_t skinny_lds(int MT) { return (size_t)(SK_WAVES * MT * 16 * 64 + MT * 32 * 8) * sizeof(float); }
 

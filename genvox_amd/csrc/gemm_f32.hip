@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     for (int i = 0; i < A_V4; ++i) {
         int m = m0 + ld_row + 32 * i;
         a_ok[i] = m < p.M;
-        a_ptr[i] = p.A + (a_ok[i] ? row_off(p.amap, m) : 0) + 4 * ld_c4;
+        a_ptr[i] = p.A + (a_ok[i] ? row_off(p.amap, m) : 0);
     }
 #pragma unroll
     for (int i = 0; i < B_V4; ++i) {
@@ -71,10 +71,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_tile = [&](int k0) {
-        const bool k_ok = (k0 + 4 * ld_c4) < p.K;
+        const int k = k0 + 4 * ld_c4;
+        const bool k_ok = k < p.K;
+        const long a_koff = (long)(k >> 3) * p.a_kblk + (k & 7);
 #pragma unroll
         for (int i = 0; i < A_V4; ++i)
-            a_reg[i] = (a_ok[i] && k_ok) ? *reinterpret_cast<const float4*>(a_ptr[i] + k0) : zero4;
+            a_reg[i] = (a_ok[i] && k_ok) ? *reinterpret_cast<const float4*>(a_ptr[i] + a_koff) : zero4;
 #pragma unroll
         for (int i = 0; i < B_V4; ++i)
             b_reg[i] = (b_ok[i] && k_ok) ? *reinterpret_cast<const float4*>(b_ptr[i] + k0) : zero4;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
                 if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == ACT_TANH) v = tanhf(v);
                 if (p.keep) v = p.keep[(long)m * p.keep_ld + n] ? 2.f * v : 0.f;
-                p.C[c_off + n] = v;
+                p.C[c_off + (long)(n >> 3) * p.c_nblk + (n & 7)] = v;
             }
         }
     }

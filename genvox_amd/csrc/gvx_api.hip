@@ -73,7 +73,7 @@ inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 
 
 struct WsPlan {  // byte offsets into the caller's workspace
     size_t xa, xb, xg, enc_h, enc_c, flags, memory;
-    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj;
+    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies;
     size_t ya, yb;
     size_t total;
 };
@@ -102,7 +102,8 @@ struct gvx_model {
     }
     // derived
     int H() const { return d.embed_dim / 2; }
-    int PS() const { return (d.n_mels + 1 + 3) & ~3; }  // padded row stride of the mel+gate projection
+    int PS() const { return (d.n_mels + 1 + 3) & ~3; }  // padded row stride of the mel+gate projection (row-major)
+    int PSB() const { return (d.n_mels + 1 + 7) & ~7; } // floats per row of the blocked per-step projection vector
 };
 
 namespace {
@@ -160,7 +161,8 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.hc = take((size_t)(T + 1) * B * (D + E));
     w.w_cum = take((size_t)B * L);
     w.q_slab = take((size_t)(A / 8) * B * d.att_dim);
-    w.proj = take((size_t)B * T * m->PS());
+    w.proj = take((size_t)B * T * m->PSB());
+    w.energies = take((size_t)B * L);
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
     w.yb = take((size_t)B * (T + 2 * pp) * cmax);
@@ -408,8 +410,8 @@ int check_common(const gvx_model* m, int B, int L, int T, void* ws, size_t ws_by
     if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(GVX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     const size_t need = make_ws_plan(m, B, L, T).total;
     if (ws_bytes < need) return fail(GVX_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
-    if (attention_lds_bytes(L, m->d.att_dim, m->d.att_loc_filters, m->d.att_loc_kernel) > 160 * 1024)
-        return fail(GVX_ERR_UNSUPPORTED, "L = %d is too long for the attention kernel's LDS budget", L);
+    if (!attention_supported(L, m->d.att_dim, m->d.att_loc_filters, m->d.att_loc_kernel, m->d.embed_dim))
+        return fail(GVX_ERR_UNSUPPORTED, "L = %d is too long for the attention kernels' LDS budget", L);
     return GVX_OK;
 }
 
@@ -469,14 +471,14 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
             float* h_cur = enc_h + ((size_t)dir * 2 + (step & 1)) * B * H;
             float* h_nxt = enc_h + ((size_t)dir * 2 + ((step + 1) & 1)) * B * H;
             J.Wp = m->dev_blob + m->blob.enc_whh_frag[dir];
-            J.x[0] = XSeg{h_cur, (long)H, H};
+            J.x[0] = XSeg{h_cur, H};
             J.N = 4 * H; J.nkg = H / 8; J.mode = 0; J.B = B;
             J.c = enc_c + (size_t)dir * B * H;
-            J.h_out = h_nxt; J.h_out_stride = H;
+            J.h_out = h_nxt;
             J.addend = xg + (size_t)dir * 4 * H; J.add_bs = (long)L * 8 * H; J.add_ts = 8 * H;
             J.lengths = lengths; J.step = step; J.reverse = dir; J.seq_len = L;
             J.seq_out = memory_out + (size_t)dir * H; J.seq_bs = (long)L * E; J.seq_ts = E;
-            J.h_prev = h_cur; J.h_prev_stride = H;
+            J.h_prev = h_cur;
         }
         HIP_TRY(launch_skinny(jobs, 2, SK_ENCODER, s));
     }
@@ -484,7 +486,7 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
 }
 
 struct DecoderBuffers {
-    float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj;
+    float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj, *energies;
 };
 
 DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
@@ -492,7 +494,7 @@ DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
     b.pm = ws_ptr<float>(ws, wp.pm); b.frames = ws_ptr<float>(ws, wp.frames); b.pre1 = ws_ptr<float>(ws, wp.pre1);
     b.prenet = ws_ptr<float>(ws, wp.prenet); b.h_a = ws_ptr<float>(ws, wp.h_a); b.c_a = ws_ptr<float>(ws, wp.c_a);
     b.c_d = ws_ptr<float>(ws, wp.c_d); b.hc = ws_ptr<float>(ws, wp.hc); b.w_cum = ws_ptr<float>(ws, wp.w_cum);
-    b.q_slab = ws_ptr<float>(ws, wp.q_slab); b.proj = ws_ptr<float>(ws, wp.proj);
+    b.q_slab = ws_ptr<float>(ws, wp.q_slab); b.proj = ws_ptr<float>(ws, wp.proj); b.energies = ws_ptr<float>(ws, wp.energies);
     return b;
 }
 
@@ -514,18 +516,19 @@ int decoder_init_states(gvx_model* m, const float* memory, int B, int L, const D
     return GVX_OK;
 }
 
-void fill_att_job(const gvx_model* m, SkinnyJob& J, const float* prenet_t, long prenet_stride, int t, int B, const DecoderBuffers& db) {
+// attention LSTM of step t: x = [prenet(t) ; ctx(t-1) ; h_a(t-1)] (all blocked vectors)
+void fill_att_job(const gvx_model* m, SkinnyJob& J, const float* prenet_t, int t, int B, const DecoderBuffers& db) {
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim;
     std::memset(&J, 0, sizeof J);
     const float* hc_t = db.hc + (size_t)t * B * (D + E);
     J.Wp = m->dev_blob + m->blob.att_frag; J.bias = m->dev_blob + m->blob.att_bias;
-    J.x[0] = XSeg{prenet_t, prenet_stride, P};
-    J.x[1] = XSeg{hc_t + D, (long)(D + E), E};                       // context of step t-1
-    J.x[2] = XSeg{db.h_a + (size_t)(t & 1) * B * A, (long)A, A};     // h_a of step t-1
+    J.x[0] = XSeg{prenet_t, P};
+    J.x[1] = XSeg{hc_t + (size_t)D * B, E};                   // context part of slot t: k-groups D/8 ...
+    J.x[2] = XSeg{db.h_a + (size_t)(t & 1) * B * A, A};       // h_a of step t-1
     J.N = 4 * A; J.nkg = (P + E + A) / 8; J.mode = 0; J.B = B;
     J.c = db.c_a;
-    J.h_out = db.h_a + (size_t)((t + 1) & 1) * B * A; J.h_out_stride = A;
+    J.h_out = db.h_a + (size_t)((t + 1) & 1) * B * A;
     J.Wq_t = m->dev_blob + m->blob.wq_t; J.q_slab = db.q_slab; J.att_dim = d.att_dim;
 }
 
@@ -537,12 +540,12 @@ void fill_dec_job(const gvx_model* m, SkinnyJob& J, int t, int B, const DecoderB
     const float* hc_t = db.hc + (size_t)t * B * (D + E);
     float* hc_n = db.hc + (size_t)(t + 1) * B * (D + E);
     J.Wp = m->dev_blob + m->blob.dec_frag; J.bias = m->dev_blob + m->blob.dec_bias;
-    J.x[0] = XSeg{db.h_a + (size_t)((t + 1) & 1) * B * A, (long)A, A};
-    J.x[1] = XSeg{hc_n + D, (long)(D + E), E};
-    J.x[2] = XSeg{hc_t, (long)(D + E), D};
+    J.x[0] = XSeg{db.h_a + (size_t)((t + 1) & 1) * B * A, A};
+    J.x[1] = XSeg{hc_n + (size_t)D * B, E};
+    J.x[2] = XSeg{hc_t, D};
     J.N = 4 * D; J.nkg = (A + E + D) / 8; J.mode = 0; J.B = B;
     J.c = db.c_d;
-    J.h_out = hc_n; J.h_out_stride = D + E;
+    J.h_out = hc_n;
 }
 
 void fill_attn(const gvx_model* m, AttnParams& p, const float* memory, const int32_t* lengths, int t, int B, int L,
@@ -556,8 +559,10 @@ void fill_attn(const gvx_model* m, AttnParams& p, const float* memory, const int
     p.loc_conv = m->dev_blob + m->blob.loc_conv; p.loc_dense = m->dev_blob + m->blob.loc_dense; p.v = m->dev_blob + m->blob.v;
     p.pm = db.pm; p.memory = memory; p.lengths = lengths;
     p.w_out = align_out + (size_t)t * align_ts; p.w_out_bs = align_bs;
-    p.ctx_out = db.hc + (size_t)(t + 1) * B * (D + E) + D; p.ctx_bs = D + E;
+    p.ctx_out = db.hc + (size_t)(t + 1) * B * (D + E) + (size_t)D * B;
+    p.energies = db.energies;
     p.B = B; p.L = L; p.a = d.att_dim; p.F = d.att_loc_filters; p.kl = d.att_loc_kernel; p.E = E;
+    p.G = attention_groups(B, L);
 }
 
 int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
@@ -581,7 +586,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         HIP_TRY(launch_gemm(g, s));
         g.A = db.pre1; g.amap = RowMap{rows, 0, (long)P};
         g.W = m->dev_blob + m->blob.pre_w1; g.ldw = P;
-        g.C = db.prenet;
+        g.C = db.prenet; g.cmap = RowMap{B, (long)B * P, 8}; g.c_nblk = (long)B * 8;  // step t: blocked [P/8][B][8]
         g.keep = keep_masks + (size_t)rows * P;
         g.K = P;
         HIP_TRY(launch_gemm(g, s));
@@ -602,7 +607,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     auto mark = [&](hipStream_t st) -> hipError_t { return kt ? hipEventRecord(m->kev[evi++], st) : hipSuccess; };
     for (int t = 0; t < T; ++t) {
         SkinnyJob jobs[2];
-        fill_att_job(m, jobs[0], db.prenet + (size_t)t * B * P, P, t, B, db);
+        fill_att_job(m, jobs[0], db.prenet + (size_t)t * B * P, t, B, db);
         if (t > 0) fill_dec_job(m, jobs[1], t - 1, B, db);
         HIP_TRY(mark(s));
         HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, SK_DECODER, s));
@@ -626,7 +631,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     {
         const int PS = m->PS();
         GemmParams g{};
-        g.A = db.hc + (size_t)B * (D + E); g.amap = RowMap{T * B, 0, (long)(D + E)};
+        g.A = db.hc + (size_t)B * (D + E); g.amap = RowMap{B, (long)B * (D + E), 8}; g.a_kblk = (long)B * 8;  // slots 1..T, blocked
         g.W = m->dev_blob + m->blob.proj_w; g.ldw = D + E;
         g.C = db.proj; g.cmap = RowMap{B, (long)PS, (long)T * PS};  // row (t,b) -> proj[b][t][:]
         g.bias = m->dev_blob + m->blob.proj_b;
@@ -783,10 +788,10 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, D = d.dec_rnn_dim, T = max_steps;
     const WsPlan wp = make_ws_plan(m, B, L, T);
     const DecoderBuffers db = decoder_buffers(ws, wp);
-    const int PS = m->PS();
+    const int PSB = m->PSB();
     int32_t* flags = ws_ptr<int32_t>(ws, wp.flags);
     int32_t* n_done = flags + 1;
-    // db.proj is used time-major here: proj[t][b][PS]; frames: one zero go-frame [B][M]
+    // db.proj holds one blocked projection vector [PSB/8][B][8] per step; db.frames: one zero go-frame
     rc = decoder_init_states(m, memory, B, L, db, s);
     if (rc != GVX_OK) return rc;
     HIP_TRY(zero_async(db.frames, (size_t)B * M * sizeof(float), s));
@@ -798,23 +803,24 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     while (t < T) {
         const int t_end = t + CHUNK < T ? t + CHUNK : T;
         for (; t < t_end; ++t) {
+            float* proj_t = db.proj + (size_t)t * B * PSB;
             // Prenet on the previous mel frame (Decoder.inference, models/tts/tacotron2.py:398)
             SkinnyJob job;
             std::memset(&job, 0, sizeof job);
             job.Wp = m->dev_blob + m->blob.pre_w0_frag;
-            job.x[0] = t == 0 ? XSeg{db.frames, (long)M, M} : XSeg{db.proj + (size_t)(t - 1) * B * PS, (long)PS, M};
+            job.x[0] = XSeg{t == 0 ? db.frames : db.proj + (size_t)(t - 1) * B * PSB, M};
             job.N = P; job.nkg = M / 8; job.mode = 1; job.B = B; job.act = ACT_RELU;
-            job.y = db.pre1; job.y_stride = P;
+            job.y = db.pre1;
             job.keep = keep_masks + (size_t)t * B * P; job.keep_stride = P;
             HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
             job.Wp = m->dev_blob + m->blob.pre_w1_frag;
-            job.x[0] = XSeg{db.pre1, (long)P, P};
+            job.x[0] = XSeg{db.pre1, P};
             job.nkg = P / 8;
             job.y = db.prenet;
             job.keep = keep_masks + ((size_t)T + t) * B * P;
             HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
             SkinnyJob lj;
-            fill_att_job(m, lj, db.prenet, P, t, B, db);
+            fill_att_job(m, lj, db.prenet, t, B, db);
             HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, s));
             AttnParams ap;
             fill_attn(m, ap, memory, lengths, t, B, L, align_out, (long)T * L, L, db);
@@ -824,19 +830,19 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
             // mel + gate projection of this step
             std::memset(&job, 0, sizeof job);
             job.Wp = m->dev_blob + m->blob.proj_frag; job.bias = m->dev_blob + m->blob.proj_b;
-            job.x[0] = XSeg{db.hc + (size_t)(t + 1) * B * (D + E), (long)(D + E), D + E};
+            job.x[0] = XSeg{db.hc + (size_t)(t + 1) * B * (D + E), D + E};
             job.N = M + 1; job.nkg = (D + E) / 8; job.mode = 1; job.B = B; job.act = ACT_NONE;
-            job.y = db.proj + (size_t)t * B * PS; job.y_stride = PS;
+            job.y = proj_t;
             HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
-            HIP_TRY(launch_ar_emit(db.proj + (size_t)t * B * PS, PS, mel_out, gate_out, B, M, T, t, s));
-            HIP_TRY(launch_ar_stop(db.proj + (size_t)t * B * PS, PS, M, gate_threshold, t, B, n_frames_out, n_done, s));
+            HIP_TRY(launch_ar_emit(proj_t, mel_out, gate_out, B, M, T, t, s));
+            HIP_TRY(launch_ar_stop(proj_t, M, gate_threshold, t, B, n_frames_out, n_done, s));
         }
         HIP_TRY(hipMemcpyAsync(&done_host, n_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (done_host >= B) break;
     }
     // rows that never fired ran into the cap ("Warning! Reached max decoder steps", models/tts/tacotron2.py:407-409)
-    HIP_TRY(launch_ar_stop(db.proj, PS, M, -1.f, t - 1, B, n_frames_out, n_done, s));
+    HIP_TRY(launch_ar_stop(db.proj, M, -1.f, t - 1, B, n_frames_out, n_done, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (steps_run_out) *steps_run_out = t;
     return GVX_OK;

@@ -21,10 +21,14 @@ struct RowMap {
     long s1, s0;   // offset(m) = (m / R) * s1 + (m % R) * s0   (in floats)
 };
 
+// Recurrent vectors (LSTM inputs/outputs, context, Prenet output) live in a k-group-blocked layout
+//   v[b][k]  at  base + (k >> 3) * B * 8 + b * 8 + (k & 7)
+// so that one wave-wide 16-byte-per-lane load of an MFMA x-fragment (32 rows x 8 k) is 1 KiB contiguous.
+// The GEMM reads/writes that layout through a_kblk / c_nblk (= B*8); 8 means plain row-major.
 struct GemmParams {
-    const float* A; RowMap amap;
+    const float* A; RowMap amap; long a_kblk = 8;   // element (m,k) at A + amap(m) + (k>>3)*a_kblk + (k&7)
     const float* W; long ldw;          // W row n at W + n*ldw (K contiguous)
-    float* C; RowMap cmap;
+    float* C; RowMap cmap; long c_nblk = 8;         // element (m,n) at C + cmap(m) + (n>>3)*c_nblk + (n&7)
     const float* bias;                 // [N] or nullptr
     const uint8_t* keep; long keep_ld; // Prenet keep mask [M][N] {0,1} or nullptr; kept values are doubled
     int M, N, K;                       // K % 4 == 0
@@ -38,7 +42,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // Epilogue LSTM: fused cell update (i,f,g,o), optional attention-query partial slabs.
 // Epilogue LINEAR: bias + activation + keep mask.
 // ---------------------------------------------------------------------------------------------
-struct XSeg { const float* p; long stride; int len; };   // x[b][k] = p[b*stride + k], len % 8 == 0
+struct XSeg { const float* p; int len; };   // blocked vector: x[b][k] = p[(k>>3)*B*8 + b*8 + (k&7)], len % 8 == 0
 
 struct SkinnyJob {
     const float* Wp;        // packed fragments [ntiles][nkg][64 lanes][4]
@@ -48,20 +52,19 @@ struct SkinnyJob {
     int nkg;                // K / 8
     int mode;               // 0 = LSTM cell, 1 = linear
     // --- LSTM epilogue
-    float* c;               // [B][H] cell state, updated in place
-    float* h_out; long h_out_stride;     // h'[b][j] -> h_out[b*stride + j]
-    float* h_out2; long h_out2_stride;   // optional second copy
+    float* c;               // [B][H] cell state (row-major, private to the owning workgroup), updated in place
+    float* h_out;           // h' as a blocked vector [H/8][B][8]
     // encoder extras (all nullptr/0 for the decoder)
     const float* addend; long add_bs, add_ts;  // pre-activation addend[b][t_b][n] (x-projection incl. bias)
     const int32_t* lengths; int step; int reverse; int seq_len;  // packed-sequence semantics
-    float* seq_out; long seq_bs, seq_ts;       // seq_out[b][t_b][j]
-    const float* h_prev; long h_prev_stride;   // carried over for inactive rows
+    float* seq_out; long seq_bs, seq_ts;       // seq_out[b][t_b][j] (row-major encoder output)
+    const float* h_prev;                       // blocked; carried over for inactive rows
     // attention query partial products: slab[tile][b][a] = sum_{j in tile} Wq[a][j] * h'[b][j]
     const float* Wq_t;      // [H/8][att_dim][8] (tile-major repack of query_layer.weight) or nullptr
     float* q_slab; int att_dim;
     // --- linear epilogue
-    float* y; long y_stride;            // y[b*stride + n]
-    const uint8_t* keep; long keep_stride;
+    float* y;               // blocked output [ceil(N/8)][B][8]
+    const uint8_t* keep; long keep_stride;  // keep[b*stride + n]
     int act;
     int B;
 };
@@ -69,24 +72,30 @@ enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_LINEAR = 2 };  // ker
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
-// Location-sensitive attention, one step, one workgroup per batch row.
+// Location-sensitive attention, one decoder step, split over G workgroups per batch row:
+//   attn_energy  (grid G x B): query (sum of LSTM partial slabs), location conv + dense, tanh, v-dot
+//                              -> energies[b][l] for the workgroup's chunk of positions
+//   attn_context (grid G x B): masked softmax over the row (recomputed per workgroup, it is tiny),
+//                              context columns slice; slice 0 also emits the alignment row and w_cum.
 // ---------------------------------------------------------------------------------------------
 struct AttnParams {
     const float* q_slab; int n_slabs;       // [n_slabs][B][a]
     const float* w_prev; long w_prev_bs;    // previous alignment row b at w_prev + b*bs, or nullptr (step 0)
-    float* w_cum;                           // [B][L], updated in place
+    float* w_cum;                           // [B][L], updated in place by the context kernel
     const float* loc_conv;                  // [F][2][kl]
     const float* loc_dense;                 // [a][F]
     const float* v;                         // [a]
     const float* pm;                        // [B][L][a]
     const float* memory;                    // [B][L][E]
     const int32_t* lengths;                 // [B] or nullptr
+    float* energies;                        // [B][L] scratch between the two kernels
     float* w_out; long w_out_bs;            // new alignment row b -> w_out + b*bs   (length L)
-    float* ctx_out; long ctx_bs;            // context row b -> ctx_out + b*bs       (length E)
-    int B, L, a, F, kl, E;
+    float* ctx_out;                         // blocked context vector [E/8][B][8]
+    int B, L, a, F, kl, E, G;
 };
-hipError_t launch_attention(const AttnParams& p, hipStream_t s);
-size_t attention_lds_bytes(int L, int a, int F, int kl);
+hipError_t launch_attention(const AttnParams& p, hipStream_t s);   // both kernels
+int attention_groups(int B, int L);                                // G for a batch / length
+bool attention_supported(int L, int a, int F, int kl, int E);
 
 // ---------------------------------------------------------------------------------------------
 // Small data-movement kernels.
@@ -107,11 +116,11 @@ hipError_t launch_zero_halo(float* buf, int B, int T, int halo, int C, hipStream
 hipError_t launch_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths, int B, int M, int T,
                                hipStream_t s);
 hipError_t launch_mask_gen(uint8_t* out, size_t n, uint64_t seed, hipStream_t s);
-// AR: gate logits of step t -> per-row finished flags / frame counts / all-finished counter
-hipError_t launch_ar_stop(const float* proj_t, long proj_stride, int gate_col, float threshold, int t, int B,
+// AR: gate logits of step t (blocked projection vector) -> per-row finished flags / frame counts / all-finished counter
+hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, int t, int B,
                           int32_t* n_frames, int32_t* n_done, hipStream_t s);
-// AR: scatter step-t projection [B][M+1] into mel_out [B][M][Tmax], gate_out [B][Tmax]
-hipError_t launch_ar_emit(const float* proj_t, long proj_stride, float* mel_out, float* gate_out, int B, int M, int Tmax, int t,
+// AR: scatter the blocked step-t projection into mel_out [B][M][Tmax], gate_out [B][Tmax]
+hipError_t launch_ar_emit(const float* proj_t, float* mel_out, float* gate_out, int B, int M, int Tmax, int t,
                           hipStream_t s);
 
 }  // namespace gvx

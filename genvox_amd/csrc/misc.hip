@@ -177,12 +177,12 @@ hipError_t launch_mask_gen(uint8_t* out, size_t n, uint64_t seed, hipStream_t s)
 }
 
 // ---- autoregressive bookkeeping (models/tts/tacotron2.py:405-409, per row) ----------------------------
-__global__ void ar_stop_kernel(const float* proj_t, long proj_stride, int gate_col, float threshold, int t, int B,
-                               int32_t* n_frames, int32_t* n_done) {
+// proj_t is a blocked vector [ceil((M+1)/8)][B][8]: element (b, n) at (n>>3)*B*8 + b*8 + (n&7)
+__global__ void ar_stop_kernel(const float* proj_t, int gate_col, float threshold, int t, int B, int32_t* n_frames, int32_t* n_done) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     if (n_frames[b] != 0) return;  // already finished
-    const float g = proj_t[(long)b * proj_stride + gate_col];
+    const float g = proj_t[(long)(gate_col >> 3) * B * 8 + b * 8 + (gate_col & 7)];
     const float sg = 1.f / (1.f + expf(-g));
     if (sg > threshold) {
         n_frames[b] = t + 1;
@@ -190,25 +190,23 @@ __global__ void ar_stop_kernel(const float* proj_t, long proj_stride, int gate_c
     }
 }
 
-hipError_t launch_ar_stop(const float* proj_t, long proj_stride, int gate_col, float threshold, int t, int B,
-                          int32_t* n_frames, int32_t* n_done, hipStream_t s) {
-    hipLaunchKernelGGL(ar_stop_kernel, dim3((B + 63) / 64), dim3(64), 0, s, proj_t, proj_stride, gate_col, threshold, t, B,
-                       n_frames, n_done);
+hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, int t, int B, int32_t* n_frames, int32_t* n_done,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(ar_stop_kernel, dim3((B + 63) / 64), dim3(64), 0, s, proj_t, gate_col, threshold, t, B, n_frames, n_done);
     return hipGetLastError();
 }
 
-__global__ void ar_emit_kernel(const float* proj_t, long proj_stride, float* mel_out, float* gate_out, int M, int Tmax, int t) {
+__global__ void ar_emit_kernel(const float* proj_t, float* mel_out, float* gate_out, int B, int M, int Tmax, int t) {
     const int b = blockIdx.x;
     for (int m = threadIdx.x; m <= M; m += blockDim.x) {
-        const float v = proj_t[(long)b * proj_stride + m];
+        const float v = proj_t[(long)(m >> 3) * B * 8 + b * 8 + (m & 7)];
         if (m < M) mel_out[((long)b * M + m) * Tmax + t] = v;
         else gate_out[(long)b * Tmax + t] = v;
     }
 }
 
-hipError_t launch_ar_emit(const float* proj_t, long proj_stride, float* mel_out, float* gate_out, int B, int M, int Tmax, int t,
-                          hipStream_t s) {
-    hipLaunchKernelGGL(ar_emit_kernel, dim3(B), dim3(128), 0, s, proj_t, proj_stride, mel_out, gate_out, M, Tmax, t);
+hipError_t launch_ar_emit(const float* proj_t, float* mel_out, float* gate_out, int B, int M, int Tmax, int t, hipStream_t s) {
+    hipLaunchKernelGGL(ar_emit_kernel, dim3(B), dim3(128), 0, s, proj_t, mel_out, gate_out, B, M, Tmax, t);
     return hipGetLastError();
 }
 

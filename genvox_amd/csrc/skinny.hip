@@ -3,16 +3,18 @@
 //   encoder BiLSTM recurrence (one launch per time step covers both directions),
 //   the per-step Prenet / projection GEMVs of the autoregressive mode.
 //
-// Roofline: these are weight-streaming kernels. Every step re-reads the full recurrent matrices
-// (72 MB fp32 for the two decoder cells) while each weight is used only B times, so the kernel is
-// bound by HBM/Infinity-Cache bandwidth at B = 32 and is balanced against the fp32 MFMA rate at B = 64.
+// Roofline: weight-streaming kernels. Every step re-reads the full recurrent matrices (71.3 MB fp32 for the
+// two decoder cells) while each weight is used only B times, so the kernel is bound by HBM / Infinity-Cache
+// bandwidth at B = 32 and is balanced against the fp32 MFMA rate at B = 64.
 //
 // Mapping (one workgroup of 8 waves per 32 output rows, normally one per CU):
 //   * the weight matrix is pre-packed in MFMA-fragment order [tile][k-group][lane][4], so each wave
 //     instruction reads 1 KiB contiguous - perfectly coalesced, streamed exactly once per step;
 //   * K is split over the 8 waves (no barrier in the main loop, each wave streams its own slice straight
 //     to VGPRs - an LDS round trip would be pure overhead for an operand nobody else reuses);
-//   * x (the concatenated [input ; context ; hidden] rows, <= 3 segments) comes from L2;
+//   * x (the concatenated [input ; context ; hidden] vectors, <= 3 segments) is kept in the k-group-blocked
+//     layout [K/8][B][8], so the x fragment of a k-group (32 rows x 8 k) is also ONE contiguous 1-KiB load
+//     (row-major x costs 32 cache lines per load instruction and thrashes the 32-KiB L1: 4x over-fetch);
 //   * v_mfma_f32_32x32x2_f32 with A = W (rows = outputs), B = x^T (cols = batch rows): lane (b, half)
 //     ends up holding the four gate pre-activations i,f,g,o of hidden units 2g+half in accumulator
 //     registers 4g..4g+3, because gate rows are packed as row = 4*j + gate.  The LSTM cell update is
@@ -49,25 +51,27 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, counted waits
     const int bl = lane & 31, h = lane >> 5;
+    const int B = J.B;
+    const long blk = (long)B * 8;  // floats per k-group of a blocked vector
 
     // ---- main loop: this wave's K slice, software pipelined DEPTH k-groups deep.
-    // Per k-group a wave issues one 1-KiB weight load (HBM / Infinity Cache) and MT x-loads (L2); with DEPTH
+    // Per k-group a wave issues one 1-KiB weight load (HBM / Infinity Cache) and MT 1-KiB x-loads (L2); with DEPTH
     // groups in flight per wave and 8 waves per CU about DEPTH*8 KiB of weights are outstanding per CU, which is
     // what it takes to cover the ~2 us loaded-memory latency at ~30 GB/s per CU.  No load is conditional (indices
     // are clamped instead) so the compiler can retire them with counted s_waitcnt vmcnt(N).
     const int per = (J.nkg + SK_WAVES - 1) / SK_WAVES;
     const int kg_begin = wave * per;
     const int kg_end = min(J.nkg, kg_begin + per);
-    const int e0 = J.x[0].len, e1 = e0 + J.x[1].len;
+    const int g0 = J.x[0].len >> 3, g1 = g0 + (J.x[1].len >> 3);  // k-group boundaries of the segments
 
     const float* xb0[MT]; const float* xb1[MT]; const float* xb2[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int b = mt * 32 + bl;
-        const long bb = b < J.B ? b : 0;  // rows past B read row 0; their results are never stored
-        xb0[mt] = J.x[0].p + bb * J.x[0].stride + 4 * h;
-        xb1[mt] = (J.x[1].p ? J.x[1].p : J.x[0].p) + bb * J.x[1].stride + 4 * h - e0;
-        xb2[mt] = (J.x[2].p ? J.x[2].p : J.x[0].p) + bb * J.x[2].stride + 4 * h - e1;
+        const long bb = b < B ? b : 0;  // rows past B read row 0; their results are never stored
+        xb0[mt] = J.x[0].p + bb * 8 + 4 * h;
+        xb1[mt] = (J.x[1].p ? J.x[1].p : J.x[0].p) + bb * 8 + 4 * h - g0 * blk;
+        xb2[mt] = (J.x[2].p ? J.x[2].p : J.x[0].p) + bb * 8 + 4 * h - g1 * blk;
     }
     const float4* wp = reinterpret_cast<const float4*>(J.Wp) + ((long)tile * J.nkg) * 64 + lane;
 
@@ -84,14 +88,11 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         {                                                                                             \
             const int g_ = min((gg), g_last);                                                         \
             wv[slot] = wp[(long)g_ * 64];                                                             \
-            const int k_ = 8 * g_;                                                                    \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                       \
-                const float* base_ = k_ < e0 ? xb0[mt] : (k_ < e1 ? xb1[mt] : xb2[mt]);               \
-                xv[mt][slot] = *reinterpret_cast<const float4*>(base_ + k_);                          \
+                const float* base_ = g_ < g0 ? xb0[mt] : (g_ < g1 ? xb1[mt] : xb2[mt]);               \
+                xv[mt][slot] = *reinterpret_cast<const float4*>(base_ + (long)g_ * blk);              \
             }                                                                                         \
         }
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) SK_LOAD(u, kg_begin + u)
 #define SK_MFMA(slot)                                                                                  \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                               \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].x, xv[mt][slot].x, acc[mt], 0, 0, 0); \
@@ -99,6 +100,8 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].z, xv[mt][slot].z, acc[mt], 0, 0, 0); \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].w, xv[mt][slot].w, acc[mt], 0, 0, 0); \
         }
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) SK_LOAD(u, kg_begin + u)
         int base = kg_begin;
         // steady state: every slot is valid and so is its refill -> branch-free body, counted waits
         for (; base + 2 * DEPTH <= kg_end; base += DEPTH) {
@@ -145,12 +148,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         const int nloc = 8 * g + 4 * h;          // first of the lane's 4 consecutive packed rows in the tile
         const int n = tile * 32 + nloc;
         if (J.mode == 0) {
-            // LSTM cell: rows n..n+3 are gates i,f,g,o of hidden unit j
+            // LSTM cell: rows n..n+3 are gates i,f,g,o of hidden unit j = tile*8 + jloc
             const int jloc = 2 * g + h;
             const int j = tile * 8 + jloc;
             const int H = J.N >> 2;
             float hval = 0.f;
-            if (b < J.B) {
+            if (b < B) {
                 bool active = true;
                 int tb = 0;
                 if (J.seq_out) {
@@ -158,6 +161,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                     active = J.step < len;
                     tb = J.reverse ? (len - 1 - J.step) : J.step;
                 }
+                const long hoff = (long)tile * blk + b * 8 + jloc;  // blocked: k-group = tile, k & 7 = jloc
                 if (active) {
                     float pre[4];
 #pragma unroll
@@ -173,14 +177,13 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                     J.c[(long)b * H + j] = c_new;
                     if (J.seq_out) J.seq_out[(long)b * J.seq_bs + (long)tb * J.seq_ts + j] = hval;
                 } else {
-                    hval = J.h_prev[(long)b * J.h_prev_stride + j];
+                    hval = J.h_prev[hoff];
                 }
-                J.h_out[(long)b * J.h_out_stride + j] = hval;
-                if (J.h_out2) J.h_out2[(long)b * J.h_out2_stride + j] = hval;
+                J.h_out[hoff] = hval;
             }
             if (J.q_slab) hs[b * 8 + jloc] = hval;
         } else {
-            if (b < J.B) {
+            if (b < B) {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int nn = n + qq;
@@ -190,7 +193,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                         if (J.act == ACT_RELU) v = fmaxf(v, 0.f);
                         else if (J.act == ACT_TANH) v = tanhf(v);
                         if (J.keep) v = J.keep[(long)b * J.keep_stride + nn] ? 2.f * v : 0.f;
-                        J.y[(long)b * J.y_stride + nn] = v;
+                        J.y[(long)(nn >> 3) * blk + b * 8 + (nn & 7)] = v;  // blocked output
                     }
                 }
             }
@@ -202,7 +205,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         __syncthreads();
         const int a = J.att_dim;
         const float* wq = J.Wq_t + (long)tile * a * 8;
-        for (int idx = tid; idx < J.B * a; idx += SK_THREADS) {
+        for (int idx = tid; idx < B * a; idx += SK_THREADS) {
             const int b = idx / a, d = idx - b * a;
             const float4 w0 = *reinterpret_cast<const float4*>(wq + d * 8);
             const float4 w1 = *reinterpret_cast<const float4*>(wq + d * 8 + 4);
@@ -211,7 +214,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             float v = w0.x * h0.x;
             v = fmaf(w0.y, h0.y, v); v = fmaf(w0.z, h0.z, v); v = fmaf(w0.w, h0.w, v);
             v = fmaf(w1.x, h1.x, v); v = fmaf(w1.y, h1.y, v); v = fmaf(w1.z, h1.z, v); v = fmaf(w1.w, h1.w, v);
-            J.q_slab[((long)tile * J.B + b) * a + d] = v;
+            J.q_slab[((long)tile * B + b) * a + d] = v;
         }
     }
 }

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgenvox_amd.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("GVX_LIB", "libgenvox_amd.so"))  # GVX_LIB: diagnostic builds only
 
 
 class GvxError(RuntimeError):

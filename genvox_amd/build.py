@@ -26,15 +26,19 @@ def _newer(a: str, b: str) -> bool:
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> str:
+    """stamps=True builds the diagnostic library libgenvox_amd_stamps.so (phase timestamps, tools/stamps.py)."""
     objs, jobs = [], []
+    flags = CXXFLAGS + (["-DGVX_STAMPS"] if stamps else [])
+    lib = LIB.replace(".so", "_stamps.so") if stamps else LIB
+    sfx = ".stamps.o" if stamps else ".o"
     headers = [os.path.join(CSRC, "gvx_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "genvox_amd.h")]
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", sfx))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in headers):
-            jobs.append([HIPCC, *CXXFLAGS, "-c", s, "-o", o])
+            jobs.append([HIPCC, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -44,11 +48,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])
-    return LIB
+    if jobs or not os.path.exists(lib):
+        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib])
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

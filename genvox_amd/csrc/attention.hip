@@ -62,11 +62,10 @@ __host__ __device__ inline EnergyLds energy_lds_layout(int Lg, int a, int kl) {
 template <int DPL>
 __global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int L = p.L, a = p.a, F = p.F, kl = p.kl;
+    const int L = p.L, a = p.a, kl = p.kl;
     const int Lg = chunk_len(L, p.G);
     const EnergyLds lo = energy_lds_layout(Lg, a, kl);
     float* qs = smem + lo.q_off;
-    float* vs = smem + lo.v_off;
     float* wc = smem + lo.wc_off;
     float* cw = smem + lo.cw_off;
     float* fb = smem + lo.f_off;
@@ -79,77 +78,119 @@ __global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
     if (l_begin >= l_end) return;  // uniform per workgroup
     const int pad = (kl - 1) / 2, LW = Lg + kl - 1;
     const int len = p.lengths ? p.lengths[b] : L;
+    GVX_STAMP(1, 0);
 
-    // ---- query: sum of the LSTM kernel's per-tile partial slabs, EN_QG slab rows in parallel, float4 per thread
+    // Every input of this kernel was written by another kernel (or is first-touch for this CU), so each dependent
+    // round trip costs ~1 us.  All global loads are therefore issued up front, back to back, and consumed afterwards.
+    // (1) query partial slabs: qg slab rows in parallel, float4 per thread
     const int a4 = a >> 2;
-    const int qg = min(EN_QG, AT_THREADS / a4);  // slab rows summed in parallel
+    const int qg = min(EN_QG, AT_THREADS / a4);
+    const int grp = tid / a4, d4 = tid - grp * a4;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int QV = 16;
+    float4 qld[QV];
+    const bool q_fast = grp < qg && p.n_slabs == QV * qg;   // default dims: 128 slabs = 16 x 8
     {
-        const int grp = tid / a4, d4 = tid - grp * a4;
-        if (grp < qg) {
-            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4* base = reinterpret_cast<const float4*>(p.q_slab + (long)b * a) + d4;
-            const long tstride = (long)p.B * a4;
-            int t = grp;
-            for (; t + 7 * qg < p.n_slabs; t += 8 * qg) {
-                float4 v[8];
+        const float4* base = reinterpret_cast<const float4*>(p.q_slab + (long)b * a) + d4;
+        const long tstride = (long)p.B * a4;
+        if (q_fast) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = base[(long)(t + i * qg) * tstride];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { s4.x += v[i].x; s4.y += v[i].y; s4.z += v[i].z; s4.w += v[i].w; }
-            }
-            for (; t < p.n_slabs; t += qg) {
+            for (int i = 0; i < QV; ++i) qld[i] = base[(long)(grp + i * qg) * tstride];
+        } else if (grp < qg) {
+            for (int t = grp; t < p.n_slabs; t += qg) {
                 const float4 v = base[(long)t * tstride];
                 s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
             }
-            reinterpret_cast<float4*>(qs + grp * a)[d4] = s4;
         }
     }
-    for (int idx = tid; idx < a; idx += AT_THREADS) vs[idx] = p.v[idx];
-    // previous / cumulative weights of the chunk with a zero-filled halo of (kl-1)/2 positions
-    for (int idx = tid; idx < 2 * LW; idx += AT_THREADS) {
-        const int ch = idx / LW, i = idx - ch * LW, l = l_begin + i - pad;
+    // (2) previous / cumulative weights of the chunk with a zero-filled halo of (kl-1)/2 positions
+    float wcv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * AT_THREADS;
+        const int ch = idx / LW, ii = idx - ch * LW, l = l_begin + ii - pad;
+        float val = 0.f;
+        if (idx < 2 * LW && l >= 0 && l < L)
+            val = ch == 0 ? (p.w_prev ? p.w_prev[(long)b * p.w_prev_bs + l] : 0.f) : p.w_cum[(long)b * L + l];
+        wcv[i] = val;
+    }
+    // (3) location conv weights, pre-transposed [2][kl][AT_FP] (zero padded) -> straight float4 copies
+    const int cw4 = (2 * kl * AT_FP) >> 2;
+    float4 cwv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * AT_THREADS;
+        cwv[i] = idx < cw4 ? reinterpret_cast<const float4*>(p.loc_conv_t)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // (4) dense location weights, pre-transposed [AT_FP][a]: lane d reads consecutive addresses (coalesced)
+    float wd[DPL][AT_FP];
+    float vv[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int d = min(lane + 64 * i, a - 1);
+#pragma unroll
+        for (int c = 0; c < AT_FP; ++c) wd[i][c] = p.loc_dense_t[(long)c * a + d];
+        vv[i] = (lane + 64 * i) < a ? p.v[d] : 0.f;
+    }
+    // (5) processed-memory values of this wave's positions (first pass)
+    float pmv[EN_LC / AT_WAVES][DPL];
+#pragma unroll
+    for (int j = 0; j < EN_LC / AT_WAVES; ++j) {
+        const int l = min(l_begin + wave + j * AT_WAVES, l_end - 1);
+        const float* pmrow = p.pm + ((long)b * L + l) * a;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) pmv[j][i] = pmrow[min(lane + 64 * i, a - 1)];
+    }
+    GVX_STAMP(1, 1);
+
+    // ---- consume: stage to LDS
+    if (q_fast) {
+#pragma unroll
+        for (int i = 0; i < QV; ++i) { s4.x += qld[i].x; s4.y += qld[i].y; s4.z += qld[i].z; s4.w += qld[i].w; }
+    }
+    if (grp < qg) reinterpret_cast<float4*>(qs + grp * a)[d4] = s4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * AT_THREADS;
+        if (idx < 2 * LW) wc[idx] = wcv[i];
+    }
+    for (int idx = tid + 4 * AT_THREADS; idx < 2 * LW; idx += AT_THREADS) {  // long chunks only
+        const int ch = idx / LW, ii = idx - ch * LW, l = l_begin + ii - pad;
         float val = 0.f;
         if (l >= 0 && l < L) val = ch == 0 ? (p.w_prev ? p.w_prev[(long)b * p.w_prev_bs + l] : 0.f) : p.w_cum[(long)b * L + l];
         wc[idx] = val;
     }
-    for (int idx = tid; idx < 2 * kl * AT_FP; idx += AT_THREADS) {
-        const int c = idx % AT_FP, ck = idx / AT_FP;  // ck = ch*kl + k
-        cw[idx] = c < F ? p.loc_conv[(long)c * 2 * kl + ck] : 0.f;
-    }
-    // dense location weights: lane owns attention dims d = lane + 64*i (kept in registers for the whole kernel)
-    float wd[DPL][AT_FP];
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int d = lane + 64 * i;
-#pragma unroll
-        for (int c = 0; c < AT_FP; ++c) wd[i][c] = (d < a && c < F) ? p.loc_dense[(long)d * F + c] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * AT_THREADS;
+        if (idx < cw4) reinterpret_cast<float4*>(cw)[idx] = cwv[i];
     }
+    for (int idx = tid + 2 * AT_THREADS; idx < cw4; idx += AT_THREADS)
+        reinterpret_cast<float4*>(cw)[idx] = reinterpret_cast<const float4*>(p.loc_conv_t)[idx];
+    GVX_STAMP(1, 2);
     __syncthreads();
-    float qv[DPL], vv[DPL];
+    GVX_STAMP(1, 3);
+    float qv[DPL];
 #pragma unroll
     for (int i = 0; i < DPL; ++i) {
-        const int d = lane + 64 * i;
+        const int d = min(lane + 64 * i, a - 1);
         float qsum = 0.f;
-        if (d < a)
-            for (int gq = 0; gq < qg; ++gq) qsum += qs[gq * a + d];
+        for (int gq = 0; gq < qg; ++gq) qsum += qs[gq * a + d];
         qv[i] = qsum;
-        vv[i] = d < a ? vs[d] : 0.f;
     }
 
     for (int l0 = l_begin; l0 < l_end; l0 += EN_LC) {
         const int lc = min(EN_LC, l_end - l0);
-        // processed-memory values of this wave's positions: issued now, consumed after the conv (latency hidden)
-        float pmv[EN_LC / AT_WAVES][DPL];
+        if (l0 != l_begin) {  // later passes (long chunks): fetch their processed-memory rows now
 #pragma unroll
-        for (int j = 0; j < EN_LC / AT_WAVES; ++j) {
-            const int ll = wave + j * AT_WAVES;
-            const float* pmrow = p.pm + ((long)b * L + l0 + min(ll, lc - 1)) * a;
+            for (int j = 0; j < EN_LC / AT_WAVES; ++j) {
+                const int l = min(l0 + wave + j * AT_WAVES, l_end - 1);
+                const float* pmrow = p.pm + ((long)b * L + l) * a;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const int d = lane + 64 * i;
-                pmv[j][i] = d < a ? pmrow[d] : 0.f;
+                for (int i = 0; i < DPL; ++i) pmv[j][i] = pmrow[min(lane + 64 * i, a - 1)];
             }
         }
+        GVX_STAMP(1, 4);
         {   // location conv: thread = (position, group of 4 filters)
             const int ll = tid & (EN_LC - 1), fg = tid >> 5;  // 8 groups of 4 filters
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
@@ -157,6 +198,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
                 for (int ch = 0; ch < 2; ++ch) {
                     const float* xrow = wc + ch * LW + (l0 - l_begin) + ll;
                     const float* wrow = cw + (ch * kl) * AT_FP + fg * 4;
+#pragma unroll 8
                     for (int k = 0; k < kl; ++k) {
                         const float x = xrow[k];
                         const float4 w = *reinterpret_cast<const float4*>(wrow + k * AT_FP);
@@ -168,6 +210,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
             *reinterpret_cast<float4*>(fb + ll * AT_FP + fg * 4) = make_float4(acc0, acc1, acc2, acc3);
         }
         __syncthreads();
+        GVX_STAMP(1, 5);
         // energies: a wave takes positions wave, wave+4, ...; lane = attention dim(s); per-lane partials go to LDS
         // and are reduced over the 64 lanes in one batched pass (instead of 6 cross-lane shuffles per position)
 #pragma unroll
@@ -191,6 +234,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
             part[ll * 65 + lane] = pe;
         }
         __syncthreads();
+        GVX_STAMP(1, 6);
         {   // thread = (position, eighth of the lanes): 8 partials each, then 3 shuffles
             const int ll = tid >> 3, sg = tid & 7;
             float s = 0.f;
@@ -203,6 +247,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
             if (sg == 0 && ll < lc) p.energies[(long)b * L + l] = l < len ? s : -INFINITY;
         }
         __syncthreads();
+        GVX_STAMP(1, 7);
     }
 }
 
@@ -216,6 +261,9 @@ __host__ __device__ inline ContextLds context_lds_layout(int L) {
     return o;
 }
 
+constexpr int CX_EV = 4;    // energies per lane held in registers (rows up to 256 positions; longer rows re-read)
+constexpr int CX_MV = 16;   // memory float4 loads in flight per thread
+
 __global__ __launch_bounds__(AT_THREADS) void attn_context_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = p.L, E = p.E, B = p.B;
@@ -226,20 +274,57 @@ __global__ __launch_bounds__(AT_THREADS) void attn_context_kernel(AttnParams p) 
     const int g = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int len = p.lengths ? p.lengths[b] : L;
+    GVX_STAMP(2, 0);
+
+    // ---- issue everything first: the row's energies, and the first CX_MV positions of this thread's memory column.
+    // The memory loads do not depend on the softmax, so both round trips overlap.
+    const float* erow = p.energies + (long)b * L;
+    float ev[CX_EV];
+#pragma unroll
+    for (int i = 0; i < CX_EV; ++i) {
+        const int l = lane + 64 * i;
+        ev[i] = l < L ? erow[l] : -INFINITY;
+    }
+    const int e4n = E >> 2;
+    const int cols = (e4n + p.G - 1) / p.G;       // float4 columns per workgroup
+    const int c_begin = g * cols, c_end = min(e4n, c_begin + cols);
+    const int cc = tid & 31, pg = tid >> 5;        // thread = (float4 column, position residue mod 8)
+    const float4* mbase = reinterpret_cast<const float4*>(p.memory + (long)b * L * E);
+    float4 mv[CX_MV];
+    {
+        const int e4 = min(c_begin + cc, e4n - 1);
+#pragma unroll
+        for (int i = 0; i < CX_MV; ++i) mv[i] = mbase[(long)min(pg + 8 * i, L - 1) * e4n + e4];
+    }
 
     // ---- masked softmax over the whole row; every wave computes the normaliser, wave 0 publishes the weights
     {
-        const float* erow = p.energies + (long)b * L;
         float m = -INFINITY;
-        for (int l = lane; l < L; l += 64) m = fmaxf(m, erow[l]);
+#pragma unroll
+        for (int i = 0; i < CX_EV; ++i) m = fmaxf(m, ev[i]);
+        for (int l = lane + 64 * CX_EV; l < L; l += 64) m = fmaxf(m, erow[l]);
         m = wave_max(m);
         float s = 0.f;
-        for (int l = lane; l < L; l += 64) s += expf(erow[l] - m);
+        float ex[CX_EV];
+#pragma unroll
+        for (int i = 0; i < CX_EV; ++i) { ex[i] = expf(ev[i] - m); s += ex[i]; }
+        for (int l = lane + 64 * CX_EV; l < L; l += 64) s += expf(erow[l] - m);
         s = wave_sum(s);
         const float inv = 1.f / s;
         if (wave == 0) {
-            for (int l = lane; l < L; l += 64) {
+#pragma unroll
+            for (int i = 0; i < CX_EV; ++i) {
+                const int l = lane + 64 * i;
+                if (l < L) {
+                    const float w = ex[i] * inv;
+                    ws[l] = w;
+                    if (g == 0) {
+                        p.w_out[(long)b * p.w_out_bs + l] = w;
+                        p.w_cum[(long)b * L + l] += w;
+                    }
+                }
+            }
+            for (int l = lane + 64 * CX_EV; l < L; l += 64) {
                 const float w = expf(erow[l] - m) * inv;
                 ws[l] = w;
                 if (g == 0) {
@@ -250,26 +335,28 @@ __global__ __launch_bounds__(AT_THREADS) void attn_context_kernel(AttnParams p) 
         }
     }
     __syncthreads();
+    GVX_STAMP(2, 1);
 
-    // ---- context columns slice: thread = (float4 column, position residue mod 8)
-    const int e4n = E >> 2;
-    const int cols = (e4n + p.G - 1) / p.G;       // float4 columns per workgroup
-    const int c_begin = g * cols, c_end = min(e4n, c_begin + cols);
-    const int cc = tid & 31, pg = tid >> 5;
+    // ---- context columns slice (weights past the row's length are exactly 0, so clamped loads are harmless)
     for (int c0 = c_begin; c0 < c_end; c0 += 32) {
         const int e4 = c0 + cc;
+        const int e4c = min(e4, e4n - 1);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e4 < c_end) {
-            const float4* mrow = reinterpret_cast<const float4*>(p.memory + (long)b * L * E) + e4;
-#pragma unroll 8
-            for (int l = pg; l < len; l += 8) {
-                const float w = ws[l];
-                const float4 mv = mrow[(long)l * e4n];
-                acc.x = fmaf(w, mv.x, acc.x); acc.y = fmaf(w, mv.y, acc.y);
-                acc.z = fmaf(w, mv.z, acc.z); acc.w = fmaf(w, mv.w, acc.w);
+        for (int lb = 0; lb < L; lb += 8 * CX_MV) {
+            if (c0 != c_begin || lb != 0) {
+#pragma unroll
+                for (int i = 0; i < CX_MV; ++i) mv[i] = mbase[(long)min(lb + pg + 8 * i, L - 1) * e4n + e4c];
+            }
+#pragma unroll
+            for (int i = 0; i < CX_MV; ++i) {
+                const int l = lb + pg + 8 * i;
+                const float w = l < L ? ws[l] : 0.f;
+                acc.x = fmaf(w, mv[i].x, acc.x); acc.y = fmaf(w, mv[i].y, acc.y);
+                acc.z = fmaf(w, mv[i].z, acc.z); acc.w = fmaf(w, mv[i].w, acc.w);
             }
         }
         red[pg * 32 + cc] = acc;
+        GVX_STAMP(2, 2);
         __syncthreads();
         if (tid < 32 && e4 < c_end) {
             float4 o = red[tid];
@@ -282,6 +369,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_context_kernel(AttnParams p) 
             *reinterpret_cast<float4*>(p.ctx_out + (long)(e >> 3) * B * 8 + b * 8 + (e & 7)) = o;
         }
         __syncthreads();
+        GVX_STAMP(2, 3);
     }
 }
 
@@ -323,5 +411,11 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     attn_context_kernel<<<grid, block, lds_c, s>>>(p);
     return hipGetLastError();
 }
+
+#ifdef GVX_STAMPS
+hipError_t read_stamps_attention(unsigned long long* host96) {
+    return hipMemcpyFromSymbol(host96, HIP_SYMBOL(gvx_stamps), sizeof(unsigned long long) * 96);
+}
+#endif
 
 }  // namespace gvx

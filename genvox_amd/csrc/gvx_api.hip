@@ -25,6 +25,10 @@
 #include <vector>
 
 namespace gvx {
+#ifdef GVX_STAMPS
+hipError_t read_stamps_skinny(unsigned long long* host96);
+hipError_t read_stamps_attention(unsigned long long* host96);
+#endif
 hipError_t skinny_init();
 hipError_t gemm_init();
 hipError_t attention_init();
@@ -73,7 +77,7 @@ inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 
 
 struct WsPlan {  // byte offsets into the caller's workspace
     size_t xa, xb, xg, enc_h, enc_c, flags, memory;
-    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies;
+    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy;
     size_t ya, yb;
     size_t total;
 };
@@ -88,6 +92,16 @@ struct gvx_model {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     int last_decoder_launches = 0;
+    // hipGraph cache of the teacher-forced step loop, keyed by every pointer / size the captured launches bake in
+    struct LoopKey {
+        const void* ws; const void* memory; int B, L, T; bool has_len;
+        bool operator==(const LoopKey& o) const {
+            return ws == o.ws && memory == o.memory && B == o.B && L == o.L && T == o.T && has_len == o.has_len;
+        }
+    };
+    std::vector<std::pair<LoopKey, hipGraphExec_t>> loop_graphs;
+    hipStream_t cap_stream = nullptr;  // private stream used only to record captures (the caller's may be the null stream)
+    bool use_graph = true;
     // per-launch timing of the decoder step kernels (measurement only)
     bool ktiming = false;
     std::vector<hipEvent_t> kev;
@@ -123,8 +137,8 @@ Blob make_blob_layout(const gvx_dims& d) {
     b.att_frag = take(frag_floats(4 * A, P + E + A)); b.att_bias = take((size_t)4 * A);
     b.wq_t = take((size_t)A * d.att_dim);
     b.wmem = take((size_t)d.att_dim * E); b.v = take(d.att_dim);
-    b.loc_conv = take((size_t)d.att_loc_filters * 2 * d.att_loc_kernel);
-    b.loc_dense = take((size_t)d.att_dim * d.att_loc_filters);
+    b.loc_conv = take((size_t)2 * d.att_loc_kernel * 32);   // transposed [2][kl][32]
+    b.loc_dense = take((size_t)32 * d.att_dim);             // transposed [32][a]
     b.dec_frag = take(frag_floats(4 * D, A + E + D)); b.dec_bias = take((size_t)4 * D);
     b.proj_w = take((size_t)(M + 1) * (D + E)); b.proj_b = take(M + 1);
     b.proj_frag = take(frag_floats(M + 1, D + E));
@@ -163,6 +177,8 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.q_slab = take((size_t)(A / 8) * B * d.att_dim);
     w.proj = take((size_t)B * T * m->PSB());
     w.energies = take((size_t)B * L);
+    w.align_tm = take((size_t)T * B * L);   // alignments of the step loop, time-major [T][B][L]
+    w.len_copy = take((size_t)B);           // token lengths copied next to the loop's other operands
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
     w.yb = take((size_t)B * (T + 2 * pp) * cmax);
@@ -271,6 +287,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     gvx_model* m = new gvx_model();
     m->d = *dims;
     m->blob = make_blob_layout(*dims);
+    if (const char* e = std::getenv("GVX_NO_GRAPH")) m->use_graph = !(e[0] == '1');
     *out = m;
     return GVX_OK;
 }
@@ -280,6 +297,8 @@ void gvx_model_destroy(gvx_model* m) {
     if (m->ev_valid)
         for (auto& e : m->ev) (void)hipEventDestroy(e);
     for (auto& e : m->kev) (void)hipEventDestroy(e);
+    for (auto& g : m->loop_graphs) (void)hipGraphExecDestroy(g.second);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
 }
 
@@ -348,9 +367,11 @@ int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, vo
         std::memcpy(out + bl.v, src, sizeof(float) * a);
         const int64_t nconv = (int64_t)d.att_loc_filters * 2 * d.att_loc_kernel;
         if (!(src = wt.get(att + "location_layer.location_conv.conv.weight", nconv, &rc))) return rc;
-        std::memcpy(out + bl.loc_conv, src, sizeof(float) * nconv);
+        for (int c = 0; c < d.att_loc_filters; ++c)
+            for (int ck = 0; ck < 2 * d.att_loc_kernel; ++ck) out[bl.loc_conv + (size_t)ck * 32 + c] = src[(size_t)c * 2 * d.att_loc_kernel + ck];
         if (!(src = wt.get(att + "location_layer.location_dense.linear_layer.weight", (int64_t)a * d.att_loc_filters, &rc))) return rc;
-        std::memcpy(out + bl.loc_dense, src, sizeof(float) * a * d.att_loc_filters);
+        for (int dd = 0; dd < a; ++dd)
+            for (int c = 0; c < d.att_loc_filters; ++c) out[bl.loc_dense + (size_t)c * a + dd] = src[(size_t)dd * d.att_loc_filters + c];
     }
     {   // decoder LSTM: x = [h_a ; context ; h_d]
         std::vector<float> wcat;
@@ -486,7 +507,8 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
 }
 
 struct DecoderBuffers {
-    float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj, *energies;
+    float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj, *energies, *align_tm;
+    int32_t* len_copy;
 };
 
 DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
@@ -495,6 +517,7 @@ DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
     b.prenet = ws_ptr<float>(ws, wp.prenet); b.h_a = ws_ptr<float>(ws, wp.h_a); b.c_a = ws_ptr<float>(ws, wp.c_a);
     b.c_d = ws_ptr<float>(ws, wp.c_d); b.hc = ws_ptr<float>(ws, wp.hc); b.w_cum = ws_ptr<float>(ws, wp.w_cum);
     b.q_slab = ws_ptr<float>(ws, wp.q_slab); b.proj = ws_ptr<float>(ws, wp.proj); b.energies = ws_ptr<float>(ws, wp.energies);
+    b.align_tm = ws_ptr<float>(ws, wp.align_tm); b.len_copy = ws_ptr<int32_t>(ws, wp.len_copy);
     return b;
 }
 
@@ -556,7 +579,7 @@ void fill_attn(const gvx_model* m, AttnParams& p, const float* memory, const int
     p.q_slab = db.q_slab; p.n_slabs = d.att_rnn_dim / 8;
     p.w_prev = t > 0 ? align_out + (size_t)(t - 1) * align_ts : nullptr; p.w_prev_bs = align_bs;
     p.w_cum = db.w_cum;
-    p.loc_conv = m->dev_blob + m->blob.loc_conv; p.loc_dense = m->dev_blob + m->blob.loc_dense; p.v = m->dev_blob + m->blob.v;
+    p.loc_conv_t = m->dev_blob + m->blob.loc_conv; p.loc_dense_t = m->dev_blob + m->blob.loc_dense; p.v = m->dev_blob + m->blob.v;
     p.pm = db.pm; p.memory = memory; p.lengths = lengths;
     p.w_out = align_out + (size_t)t * align_ts; p.w_out_bs = align_bs;
     p.ctx_out = db.hc + (size_t)(t + 1) * B * (D + E) + (size_t)D * B;
@@ -595,7 +618,14 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     if (rc != GVX_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(m->ev[2], s));
     // ---- T decoder steps.  Launch 1 of step t: attention-LSTM(t) together with decoder-LSTM(t-1), which is off
-    // the critical chain (only the next step's projection needs it).  Launch 2: attention(t).
+    // the critical chain (only the next step's projection needs it).  Launches 2, 3: attention energies / context.
+    // The loop only touches workspace operands (alignments go to a time-major workspace buffer, the lengths are
+    // copied in), so its 3T+1 launches are captured once per (workspace, shape) into a hipGraph and replayed.
+    const int32_t* len_ws = nullptr;
+    if (lengths) {
+        HIP_TRY(hipMemcpyAsync(db.len_copy, lengths, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        len_ws = db.len_copy;
+    }
     int launches = 0;
     const bool kt = m->ktiming;
     if (kt) {
@@ -605,26 +635,57 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     }
     size_t evi = 0;
     auto mark = [&](hipStream_t st) -> hipError_t { return kt ? hipEventRecord(m->kev[evi++], st) : hipSuccess; };
-    for (int t = 0; t < T; ++t) {
-        SkinnyJob jobs[2];
-        fill_att_job(m, jobs[0], db.prenet + (size_t)t * B * P, t, B, db);
-        if (t > 0) fill_dec_job(m, jobs[1], t - 1, B, db);
-        HIP_TRY(mark(s));
-        HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, SK_DECODER, s));
-        HIP_TRY(mark(s));
-        AttnParams ap;
-        fill_attn(m, ap, memory, lengths, t, B, L, align_out, (long)T * L, L, db);
-        HIP_TRY(launch_attention(ap, s));
-        HIP_TRY(mark(s));
-        launches += 2;
-    }
-    if (kt) { m->n_lstm_ev = T; m->n_attn_ev = T; }
-    {
+    auto enqueue_loop = [&](hipStream_t st) -> int {
+        for (int t = 0; t < T; ++t) {
+            SkinnyJob jobs[2];
+            fill_att_job(m, jobs[0], db.prenet + (size_t)t * B * P, t, B, db);
+            if (t > 0) fill_dec_job(m, jobs[1], t - 1, B, db);
+            HIP_TRY(mark(st));
+            HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, SK_DECODER, st));
+            HIP_TRY(mark(st));
+            AttnParams ap;
+            fill_attn(m, ap, memory, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
+            HIP_TRY(launch_attention(ap, st));
+            HIP_TRY(mark(st));
+            launches += 3;
+        }
         SkinnyJob job;
         fill_dec_job(m, job, T - 1, B, db);
-        HIP_TRY(launch_skinny(&job, 1, SK_DECODER, s));
+        HIP_TRY(launch_skinny(&job, 1, SK_DECODER, st));
         ++launches;
+        return GVX_OK;
+    };
+    if (m->use_graph && !kt) {
+        const gvx_model::LoopKey key{ws, memory, B, L, T, lengths != nullptr};
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : m->loop_graphs)
+            if (g.first == key) exec = g.second;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_loop(m->cap_stream);
+            hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
+            if (rc != GVX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            HIP_TRY(ce);
+            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            HIP_TRY(hipGraphDestroy(graph));
+            if (m->loop_graphs.size() >= 8) {  // bounded cache
+                (void)hipGraphExecDestroy(m->loop_graphs.front().second);
+                m->loop_graphs.erase(m->loop_graphs.begin());
+            }
+            m->loop_graphs.emplace_back(key, exec);
+        } else {
+            launches = 3 * T + 1;
+        }
+        HIP_TRY(hipGraphLaunch(exec, s));
+    } else {
+        rc = enqueue_loop(s);
+        if (rc != GVX_OK) return rc;
     }
+    if (kt) { m->n_lstm_ev = T; m->n_attn_ev = T; }
+    // alignments: time-major workspace [T][B][L] -> caller's [B][T][L]
+    HIP_TRY(launch_permute01(db.align_tm, align_out, T, B, L, s));
     m->last_decoder_launches = launches;
     if (timed) HIP_TRY(hipEventRecord(m->ev[3], s));
     // ---- mel + gate projection hoisted out of the loop: one GEMM over all T*B rows of hc[1..T]
@@ -847,5 +908,16 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     if (steps_run_out) *steps_run_out = t;
     return GVX_OK;
 }
+
+#ifdef GVX_STAMPS
+int gvx_debug_read_stamps(unsigned long long* host96) {
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long tmp[96];
+    HIP_TRY(gvx::read_stamps_skinny(host96));       // row 0 is the LSTM kernel's
+    HIP_TRY(gvx::read_stamps_attention(tmp));        // rows 1, 2 are the attention kernels'
+    for (int i = 32; i < 96; ++i) host96[i] = tmp[i];
+    return GVX_OK;
+}
+#endif
 
 }  // extern "C"

@@ -4,6 +4,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Diagnostic build only (-DGVX_STAMPS, python -m genvox_amd.build --stamps): workgroup (0,0), thread 0 records the
+// 100-MHz wall clock at phase boundaries into a device array that tools/stamps.py reads back.  Never defined in the
+// shipped library; no stamp executes in the measured kernels.
+#ifdef GVX_STAMPS
+// each translation unit that stamps owns a file-local array (no relocatable device code needed)
+namespace gvx { namespace { __device__ unsigned long long gvx_stamps[3][32]; } }
+#define GVX_STAMP(k, i)                                                                         \
+    do {                                                                                        \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) gvx::gvx_stamps[k][i] = wall_clock64(); \
+    } while (0)
+#else
+#define GVX_STAMP(k, i) do { } while (0)
+#endif
+
 namespace gvx {
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
@@ -82,8 +96,8 @@ struct AttnParams {
     const float* q_slab; int n_slabs;       // [n_slabs][B][a]
     const float* w_prev; long w_prev_bs;    // previous alignment row b at w_prev + b*bs, or nullptr (step 0)
     float* w_cum;                           // [B][L], updated in place by the context kernel
-    const float* loc_conv;                  // [F][2][kl]
-    const float* loc_dense;                 // [a][F]
+    const float* loc_conv_t;                // [2][kl][32] (filters innermost, zero padded to 32)
+    const float* loc_dense_t;               // [32][a]     (filters outermost, zero padded to 32)
     const float* v;                         // [a]
     const float* pm;                        // [B][L][a]
     const float* memory;                    // [B][L][E]
@@ -115,6 +129,8 @@ hipError_t launch_residual_to_channels_first(const float* mel, const float* y, f
 hipError_t launch_zero_halo(float* buf, int B, int T, int halo, int C, hipStream_t s);
 hipError_t launch_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths, int B, int M, int T,
                                hipStream_t s);
+// dst[b][t][:] = src[t][b][:]  (rows of n floats, n % 4 == 0 not required)
+hipError_t launch_permute01(const float* src, float* dst, int T, int B, int n, hipStream_t s);
 hipError_t launch_mask_gen(uint8_t* out, size_t n, uint64_t seed, hipStream_t s);
 // AR: gate logits of step t (blocked projection vector) -> per-row finished flags / frame counts / all-finished counter
 hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, int t, int B,

@@ -100,6 +100,24 @@ hipError_t launch_residual_to_channels_first(const float* mel, const float* y, f
     return launch_tr3(p, B, s);
 }
 
+// ---- [T][B][n] -> [B][T][n] row permutation (alignments out of the time-major step-loop buffer) ---------------
+__global__ void permute01_kernel(const float* src, float* dst, int T, int B, int n) {
+    const long rows = (long)T * B;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int t = (int)(r / B), b = (int)(r - (long)t * B);
+        const float* sp = src + r * n;
+        float* dp = dst + ((long)b * T + t) * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) dp[i] = sp[i];
+    }
+}
+
+hipError_t launch_permute01(const float* src, float* dst, int T, int B, int n, hipStream_t s) {
+    const long rows = (long)T * B;
+    const int grid = (int)(rows < 4096 ? rows : 4096);
+    hipLaunchKernelGGL(permute01_kernel, dim3(grid), dim3(128), 0, s, src, dst, T, B, n);
+    return hipGetLastError();
+}
+
 // ---- zero halo rows of a channels-last buffer ---------------------------------------------------------
 __global__ void zero_halo_kernel(float* buf, int T, int halo, int C) {
     const int b = blockIdx.x;

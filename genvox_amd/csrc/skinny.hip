@@ -37,7 +37,10 @@ struct SkinnyJobs {
     int tiles0;  // tiles of job 0
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 forms (abs error ~1e-7): the cell update sits on the per-step critical path after the
+// workgroup barrier, where the libm expf/tanhf sequences cost ~1 us per step.
+__device__ __forceinline__ float sigmoidf_(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - __fdividef(2.f, __expf(2.f * x) + 1.f); }
 
 template <int MT, int DEPTH>
 __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
@@ -48,11 +51,22 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     const int jsel = (jobs.njobs > 1 && (int)blockIdx.x >= jobs.tiles0) ? 1 : 0;
     const SkinnyJob& J = jobs.job[jsel];
     const int tile = (int)blockIdx.x - (jsel ? jobs.tiles0 : 0);
+    GVX_STAMP(0, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, counted waits
     const int bl = lane & 31, h = lane >> 5;
     const int B = J.B;
     const long blk = (long)B * 8;  // floats per k-group of a blocked vector
+
+    // epilogue operands of this wave's unit (cell state, bias): fetched now so their latency hides under the main loop
+    float c_pref = 0.f;
+    float4 bias_pref = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (J.mode == 0 && wave < 4 * MT) {
+        const int mt_ = wave >> 2, g_ = wave & 3;
+        const int b_ = mt_ * 32 + bl, j_ = tile * 8 + 2 * g_ + h;
+        if (b_ < B) c_pref = J.c[(long)b_ * (J.N >> 2) + j_];
+        if (J.bias) bias_pref = *reinterpret_cast<const float4*>(J.bias + tile * 32 + 8 * g_ + 4 * h);
+    }
 
     // ---- main loop: this wave's K slice, software pipelined DEPTH k-groups deep.
     // Per k-group a wave issues one 1-KiB weight load (HBM / Infinity Cache) and MT 1-KiB x-loads (L2); with DEPTH
@@ -126,12 +140,14 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 #undef SK_LOAD
     }
 
+    GVX_STAMP(0, 1);
     // ---- cross-wave K reduction through LDS
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) red[((wave * MT + mt) * 16 + q) * 64 + lane] = acc[mt][q];
     __syncthreads();
+    GVX_STAMP(0, 2);
 
     // unit u = (mt, g): register group g (4 registers) of batch tile mt; one unit per wave
     for (int u = wave; u < 4 * MT; u += SK_WAVES) {
@@ -163,17 +179,14 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                 }
                 const long hoff = (long)tile * blk + b * 8 + jloc;  // blocked: k-group = tile, k & 7 = jloc
                 if (active) {
-                    float pre[4];
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        float v = s[qq];
-                        if (J.bias) v += J.bias[n + qq];
-                        if (J.addend) v += J.addend[(long)b * J.add_bs + (long)tb * J.add_ts + n + qq];
-                        pre[qq] = v;
+                    float pre[4] = {s[0] + bias_pref.x, s[1] + bias_pref.y, s[2] + bias_pref.z, s[3] + bias_pref.w};
+                    if (J.addend) {
+                        const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b * J.add_bs + (long)tb * J.add_ts + n);
+                        pre[0] += ad.x; pre[1] += ad.y; pre[2] += ad.z; pre[3] += ad.w;
                     }
-                    const float c_old = J.c[(long)b * H + j];
-                    const float c_new = sigmoidf_(pre[1]) * c_old + sigmoidf_(pre[0]) * tanhf(pre[2]);
-                    hval = sigmoidf_(pre[3]) * tanhf(c_new);
+                    const float c_old = c_pref;
+                    const float c_new = sigmoidf_(pre[1]) * c_old + sigmoidf_(pre[0]) * tanhf_(pre[2]);
+                    hval = sigmoidf_(pre[3]) * tanhf_(c_new);
                     J.c[(long)b * H + j] = c_new;
                     if (J.seq_out) J.seq_out[(long)b * J.seq_bs + (long)tb * J.seq_ts + j] = hval;
                 } else {
@@ -200,6 +213,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         }
     }
 
+    GVX_STAMP(0, 3);
     // ---- attention query partial products for this tile's 8 hidden units
     if (J.mode == 0 && J.q_slab) {
         __syncthreads();
@@ -217,6 +231,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             J.q_slab[((long)tile * B + b) * a + d] = v;
         }
     }
+    GVX_STAMP(0, 4);
 }
 
 // Same body under three kernel names so that profiles separate the decoder step (the dominant kernel of the
@@ -267,5 +282,11 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
     }
     return hipGetLastError();
 }
+
+#ifdef GVX_STAMPS
+hipError_t read_stamps_skinny(unsigned long long* host96) {
+    return hipMemcpyFromSymbol(host96, HIP_SYMBOL(gvx_stamps), sizeof(unsigned long long) * 96);
+}
+#endif
 
 }  // namespace gvx

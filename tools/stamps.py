@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Developer diagnostic (GPU box): phase timestamps inside the decoder-step kernels (stamps build).
+    python -m genvox_amd.build --stamps && GVX_LIB=libgenvox_amd_stamps.so python tools/stamps.py [B]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from genvox_amd import _lib, weights as gw
+from genvox_amd.configs import AudioConfig, Tacotron2Config, TextConfig
+from genvox_amd.tacotron2 import Tacotron2
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+T, L = 60, 128
+mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
+m = Tacotron2(mc, ac, tc)
+m.load_state_dict(gw.generate_state_dict(mc, ac, tc, 0))
+m = m.to("cuda:0")
+batch = {k: torch.from_numpy(v).cuda() for k, v in gw.synthetic_inputs(B, L, T, 40, 80).items()}
+for _ in range(2):
+    m.forward(batch)
+torch.cuda.synchronize()
+lib = C.CDLL(_lib.LIB_PATH)
+buf = (C.c_ulonglong * 96)()
+assert lib.gvx_debug_read_stamps(buf) == 0
+names = {0: ["start", "mainloop done", "red synced", "cell done", "qslab done"],
+         1: ["start", "q issued+summed", "staged wc/cw", "wd loaded+sync", "pm issued", "conv done", "energies done", "reduced"],
+         2: ["start", "softmax done", "ctx partial", "ctx written"]}
+for k, title in enumerate(["decoder_lstm_step (wg 0)", "attn_energy (wg 0,0)", "attn_context (wg 0,0)"]):
+    v = [buf[k * 32 + i] for i in range(len(names[k]))]
+    print(title)
+    for i in range(1, len(v)):
+        print(f"   {names[k][i]:22s} +{(v[i] - v[i - 1]) * 10} ns   (t = {(v[i] - v[0]) * 10} ns)")

@@ -46,6 +46,14 @@ SIGNATURES = {
     "gvx_prenet_masks_generate": (_i, [_vp, _sz, C.c_uint64, _vp]),
     "gvx_stage_timing_enable": (_i, [_vp, _i]),
     "gvx_stage_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
+    "gvx_gl_plan_create": (_i, [_i, _i, C.POINTER(_vp)]),
+    "gvx_gl_plan_destroy": (None, [_vp]),
+    "gvx_gl_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "gvx_stft": (_i, [_vp, _vp, _vp, _i, C.c_long, _vp, _vp, _sz, _vp]),
+    "gvx_istft": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "gvx_mel_to_magnitude": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
+    "gvx_griffin_lim": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_wav_finalize": (_i, [_vp, _i, C.c_long, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _vp, _vp, _vp]),
     "gvx_kernel_timing_enable": (_i, [_vp, _i]),
     "gvx_kernel_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i)]),
 }

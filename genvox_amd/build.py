@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgenvox_amd.so")
-SOURCES = ["gemm_f32.hip", "skinny.hip", "attention.hip", "misc.hip", "gvx_api.hip"]
+SOURCES = ["gemm_f32.hip", "skinny.hip", "attention.hip", "misc.hip", "griffinlim.hip", "gvx_api.hip"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(lib):
-        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib])
+        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib", "-o", lib])
     return lib
 
 

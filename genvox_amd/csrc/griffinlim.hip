@@ -1,0 +1,502 @@
+// Batched mel -> waveform vocoder on the GPU: dB->amplitude + pseudo-inverse mel projection, fast Griffin-Lim on
+// rocFFT batched real transforms, overlap-add inverse STFT, and the clip / trim / normalise / Butterworth tail.
+// Replaces the mel->wav half of the reference's NumPy audio library, which is strictly per utterance with Python
+// loops over frames (utils/audio/base.py:38-88, :143-169; core/processors.py:81-96).
+//
+// Layouts: the reference's spectrogram layout is [bins][frames]; internally everything is frame-major
+// ([B*T][bins] complex, [B*T][n_fft] real) because that is what a batched 1-D FFT wants (one contiguous transform
+// per frame).  The C ABI takes and returns the reference's layout and transposes once on the way in / out.
+//
+// Per Griffin-Lim iteration (all HBM-bound, fp32 / complex64):
+//   C2R (rocFFT, batch B*T)  ->  overlap-add + window-sum normalisation (gather form, frames added in ascending
+//   order like the reference)  ->  re-framing * window  ->  R2C (rocFFT)  ->  momentum update / magnitude projection.
+#include "../../include/genvox_amd.h"
+#include "gvx_kernels.h"
+
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+
+namespace {
+
+int gl_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return gvx::set_error(code, buf);
+}
+#define GL_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return gl_fail(GVX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define GL_FFT(expr)                                                                          \
+    do {                                                                                      \
+        rocfft_status _s = (expr);                                                            \
+        if (_s != rocfft_status_success) return gl_fail(GVX_ERR_HIP, "%s failed: rocfft status %d", #expr, (int)_s); \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct FftPair {
+    rocfft_plan r2c = nullptr, c2r = nullptr;
+    size_t work_bytes = 0;
+};
+
+}  // namespace
+
+struct gvx_gl_plan {
+    int n_fft, hop, bins;
+    std::map<long, FftPair> plans;  // keyed by batch count (B*T)
+    rocfft_execution_info info = nullptr;
+};
+
+namespace {
+
+int get_plans(gvx_gl_plan* p, long batch, FftPair** out) {
+    auto it = p->plans.find(batch);
+    if (it != p->plans.end()) { *out = &it->second; return GVX_OK; }
+    FftPair fp;
+    const size_t len[1] = {(size_t)p->n_fft};
+    const size_t one[1] = {1};
+    const size_t off[1] = {0};
+    rocfft_plan_description d1 = nullptr, d2 = nullptr;
+    GL_FFT(rocfft_plan_description_create(&d1));
+    GL_FFT(rocfft_plan_description_set_data_layout(d1, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, off, off,
+                                                   1, one, (size_t)p->n_fft, 1, one, (size_t)p->bins));
+    GL_FFT(rocfft_plan_create(&fp.r2c, rocfft_placement_notinplace, rocfft_transform_type_real_forward, rocfft_precision_single, 1,
+                              len, (size_t)batch, d1));
+    GL_FFT(rocfft_plan_description_create(&d2));
+    GL_FFT(rocfft_plan_description_set_data_layout(d2, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, off, off,
+                                                   1, one, (size_t)p->bins, 1, one, (size_t)p->n_fft));
+    GL_FFT(rocfft_plan_create(&fp.c2r, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, rocfft_precision_single, 1,
+                              len, (size_t)batch, d2));
+    rocfft_plan_description_destroy(d1);
+    rocfft_plan_description_destroy(d2);
+    size_t w1 = 0, w2 = 0;
+    GL_FFT(rocfft_plan_get_work_buffer_size(fp.r2c, &w1));
+    GL_FFT(rocfft_plan_get_work_buffer_size(fp.c2r, &w2));
+    fp.work_bytes = w1 > w2 ? w1 : w2;
+    auto ins = p->plans.emplace(batch, fp);
+    *out = &ins.first->second;
+    return GVX_OK;
+}
+
+struct GlWs {  // byte offsets
+    size_t mag, ang, reb0, reb1, fr, y, wss, amp, fft_work, total;
+};
+
+GlWs gl_plan_ws(const gvx_gl_plan* p, int B, int T, int M, size_t fft_work) {
+    GlWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t frames = (size_t)B * T;
+    const size_t n = (size_t)p->n_fft + (size_t)(T - 1) * p->hop;
+    w.mag = take(frames * p->bins * sizeof(float));
+    w.ang = take(frames * p->bins * sizeof(float2));
+    w.reb0 = take(frames * p->bins * sizeof(float2));
+    w.reb1 = take(frames * p->bins * sizeof(float2));
+    w.fr = take(frames * p->n_fft * sizeof(float));
+    w.y = take((size_t)B * n * sizeof(float));
+    w.wss = take(n * sizeof(float));
+    w.amp = take(frames * (size_t)(M > 0 ? M : 1) * sizeof(float));
+    w.fft_work = take(fft_work);
+    w.total = off;
+    return w;
+}
+
+template <typename T>
+T* wsp(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
+
+// ---- kernels ------------------------------------------------------------------------------------------------
+
+// amp_t[(b*T + t)][m] = inv_log(mel_db[b][m][t] + log(max(amin, ref)))     (utils/audio/base.py:38-52, power=False, scale=1)
+__global__ void db_to_amp_transpose_kernel(const float* mel_db, float* amp_t, int M, int T, int log10_kind, float log_ref) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, m0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, t = t0 + tx;
+        float v = 0.f;
+        if (m < M && t < T) {
+            const float db = mel_db[((long)b * M + m) * T + t] + log_ref;
+            v = log10_kind ? powf(10.f, db) : expf(db);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, m = m0 + tx;
+        if (m < M && t < T) amp_t[((long)b * T + t) * M + m] = tile[tx][r];
+    }
+}
+
+// generic [B][ni][nj] -> [B][nj][ni] for float (scale 1) or float2 elements
+template <typename E>
+__global__ void transpose_kernel(const E* src, E* dst, int ni, int nj) {
+    __shared__ E tile[32][33];
+    const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + tx;
+        if (i < ni && j < nj) tile[r][tx] = src[((long)b * ni + i) * nj + j];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r, i = i0 + tx;
+        if (i < ni && j < nj) dst[((long)b * nj + j) * ni + i] = tile[tx][r];
+    }
+}
+
+template <typename E>
+hipError_t launch_transpose(const E* src, E* dst, int B, int ni, int nj, hipStream_t s) {
+    dim3 grid((nj + 31) / 32, (ni + 31) / 32, B);
+    transpose_kernel<E><<<grid, dim3(32, 8), 0, s>>>(src, dst, ni, nj);
+    return hipGetLastError();
+}
+
+// window sum of squares along the signal (utils/audio/base.py:81-84), frames added in ascending order, float32
+__global__ void wss_kernel(const float* win, float* wss, int n_fft, int hop, int T, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long t_lo = (i - n_fft + hop) / hop;  // ceil((i - n_fft + 1) / hop) for i - n_fft + 1 > 0
+    if (i - n_fft + 1 <= 0) t_lo = 0;
+    long t_hi = i / hop;
+    if (t_hi > T - 1) t_hi = T - 1;
+    float s = 0.f;
+    for (long t = t_lo; t <= t_hi; ++t) {
+        const float w = win[i - t * hop];
+        s += w * w;
+    }
+    wss[i] = s;
+}
+
+// angles = (mag, 0)   (utils/audio/base.py:151-154)
+__global__ void gl_init_kernel(const float* mag, float2* ang, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ang[i] = make_float2(mag[i], 0.f);
+}
+
+// y[b][i] = (sum_t win[i - t*hop] * fr[b][t][i - t*hop] / n_fft) / wss[i]      (utils/audio/base.py:71-88)
+__global__ void gl_ola_kernel(const float* fr, const float* win, const float* wss, float* y, int n_fft, int hop, int T, long n) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long t_lo = (i - n_fft + hop) / hop;
+    if (i - n_fft + 1 <= 0) t_lo = 0;
+    long t_hi = i / hop;
+    if (t_hi > T - 1) t_hi = T - 1;
+    const float inv_n = 1.f / (float)n_fft;
+    const float* frb = fr + (long)b * T * n_fft;
+    float s = 0.f;
+    for (long t = t_lo; t <= t_hi; ++t) {
+        const long k = i - t * hop;
+        s += win[k] * (frb[t * n_fft + k] * inv_n);
+    }
+    const float w = wss[i];
+    y[(long)b * n + i] = w > 1.17549435e-38f ? s / w : s;
+}
+
+// xf[b][t][k] = win[k] * y[b][t*hop + k]      (utils/audio/base.py:58-69)
+__global__ void gl_frame_kernel(const float* y, const float* win, float* xf, int n_fft, int hop, int T, long n) {
+    const long bt = blockIdx.x;  // b*T + t
+    const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
+    const float* yb = y + (long)b * n + (long)t * hop;
+    float* o = xf + bt * n_fft;
+    if ((n & 3) || (reinterpret_cast<uintptr_t>(y) & 15)) {  // rows not 16-byte aligned: scalar path
+        for (int k = threadIdx.x; k < n_fft; k += blockDim.x) o[k] = win[k] * yb[k];
+        return;
+    }
+    for (int k = threadIdx.x * 4; k < n_fft; k += blockDim.x * 4) {
+        const float4 w = *reinterpret_cast<const float4*>(win + k);
+        const float4 v = *reinterpret_cast<const float4*>(yb + k);  // hop % 4 == 0 and n_fft % 4 == 0 keep this aligned
+        *reinterpret_cast<float4*>(o + k) = make_float4(w.x * v.x, w.y * v.y, w.z * v.z, w.w * v.w);
+    }
+}
+
+// angles = rebuilt - c*prev; angles /= |angles| + tiny; angles *= mag      (utils/audio/base.py:158-160)
+__global__ void gl_update_kernel(const float2* reb, const float2* prev, const float* mag, float2* ang, float c, int first, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float2 r = reb[i];
+        float2 a = r;
+        if (!first) {
+            const float2 p = prev[i];
+            a.x = r.x - c * p.x;
+            a.y = r.y - c * p.y;
+        }
+        const float d = hypotf(a.x, a.y) + 1.17549435e-38f;
+        const float m = mag[i];
+        ang[i] = make_float2(a.x / d * m, a.y / d * m);
+    }
+}
+
+// phase = angle(angles); spec = mag * (cos phase + i sin phase)     (base.py:162, :54-56; core/processors.py:89-90)
+__global__ void gl_final_kernel(const float2* ang, const float* mag, float2* spec, float* phase_t, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float2 a = ang[i];
+        const float ph = atan2f(a.y, a.x);
+        const float m = mag[i];
+        if (phase_t) phase_t[i] = ph;
+        if (spec) spec[i] = make_float2(m * cosf(ph), m * sinf(ph));
+    }
+}
+
+// clip spurious samples, trim, peak, normalise to float32, IIR low-pass in float64 (core/processors.py:91-95,
+// utils/audio/base.py:20-22, :164-169; scipy.signal.lfilter = direct form II transposed)
+__global__ void wav_peak_kernel(const float* y, long n, int trim, unsigned int* peak_bits) {
+    const int b = blockIdx.y;
+    const long n_out = n - 2L * trim;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (long)gridDim.x * blockDim.x) {
+        float v = y[(long)b * n + trim + i];
+        if (v > 1.f || v < -1.f) v = 0.f;
+        m = fmaxf(m, fabsf(v));
+    }
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(peak_bits + b, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+
+struct IirCoef { double b[8], a[8]; int order; };
+
+__global__ void wav_filter_kernel(const float* y, long n, int trim, const unsigned int* peak_bits, IirCoef c, double* out, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const long n_out = n - 2L * trim;
+    const float peak = __uint_as_float(peak_bits[b]);
+    double z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* yb = y + (long)b * n + trim;
+    double* ob = out + (long)b * n_out;
+    // the recurrence is strictly sequential per utterance; the loads are not: fetch the next 16 samples while the
+    // current 16 go through the filter (one thread = one utterance, a wave = 64 utterances in lock step)
+    constexpr int CH = 16;
+    float cur[CH], nxt[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) cur[k] = k < n_out ? yb[k] : 0.f;
+    for (long i0 = 0; i0 < n_out; i0 += CH) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) nxt[k] = (i0 + CH + k) < n_out ? yb[i0 + CH + k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (i0 + k < n_out) {
+                float v = cur[k];
+                if (v > 1.f || v < -1.f) v = 0.f;
+                const double x = (double)(v / peak);  // float32 division, then float64 filtering, like the reference
+                const double yo = c.b[0] * x + z[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) {
+                    if (q <= c.order) z[q - 1] = c.b[q] * x + (q < c.order ? z[q] : 0.0) - c.a[q] * yo;
+                }
+                ob[i0 + k] = yo;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
+    }
+}
+
+int run_fft(gvx_gl_plan* p, rocfft_plan plan, void* in, void* out, void* work, size_t work_bytes, hipStream_t s) {
+    if (!p->info) GL_FFT(rocfft_execution_info_create(&p->info));
+    if (work_bytes) GL_FFT(rocfft_execution_info_set_work_buffer(p->info, work, work_bytes));
+    GL_FFT(rocfft_execution_info_set_stream(p->info, s));
+    void* ib[1] = {in};
+    void* ob[1] = {out};
+    GL_FFT(rocfft_execute(plan, ib, ob, p->info));
+    return GVX_OK;
+}
+
+inline int blocks_for(long n, int per = 256, int cap = 8192) {
+    long b = (n + per - 1) / per;
+    return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
+// frame-major spectrum -> signal: C2R + overlap-add
+int istft_frames(gvx_gl_plan* p, FftPair* fp, float2* spec_t, const float* win, int B, int T, void* ws, const GlWs& w, hipStream_t s) {
+    const long n = (long)p->n_fft + (long)(T - 1) * p->hop;
+    int rc = run_fft(p, fp->c2r, spec_t, wsp<float>(ws, w.fr), wsp<char>(ws, w.fft_work), fp->work_bytes, s);
+    if (rc != GVX_OK) return rc;
+    gl_ola_kernel<<<dim3((unsigned)((n + 255) / 256), B), 256, 0, s>>>(wsp<float>(ws, w.fr), win, wsp<float>(ws, w.wss), wsp<float>(ws, w.y),
+                                                                     p->n_fft, p->hop, T, n);
+    GL_HIP(hipGetLastError());
+    return GVX_OK;
+}
+
+int check_gl(const gvx_gl_plan* p, int B, int T, const void* ws, size_t ws_bytes, size_t need) {
+    if (!p) return gl_fail(GVX_ERR_INVALID_ARG, "null plan");
+    if (B < 1 || T < 1) return gl_fail(GVX_ERR_INVALID_ARG, "B and T must be >= 1");
+    if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return gl_fail(GVX_ERR_WORKSPACE, "workspace must be non-null and 256-byte aligned");
+    if (ws_bytes < need) return gl_fail(GVX_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+    return GVX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gvx_gl_plan_create(int n_fft, int hop, gvx_gl_plan** out) {
+    if (!out) return gl_fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (n_fft < 8 || (n_fft & 3) || hop < 4 || (hop & 3) || hop > n_fft)
+        return gl_fail(GVX_ERR_UNSUPPORTED, "n_fft = %d, hop = %d: both must be multiples of 4 with hop <= n_fft", n_fft, hop);
+    static bool setup_done = false;
+    if (!setup_done) {
+        GL_FFT(rocfft_setup());
+        setup_done = true;
+    }
+    gvx_gl_plan* p = new gvx_gl_plan();
+    p->n_fft = n_fft; p->hop = hop; p->bins = n_fft / 2 + 1;
+    *out = p;
+    return GVX_OK;
+}
+
+void gvx_gl_plan_destroy(gvx_gl_plan* p) {
+    if (!p) return;
+    for (auto& kv : p->plans) {
+        if (kv.second.r2c) rocfft_plan_destroy(kv.second.r2c);
+        if (kv.second.c2r) rocfft_plan_destroy(kv.second.c2r);
+    }
+    if (p->info) rocfft_execution_info_destroy(p->info);
+    delete p;
+}
+
+size_t gvx_gl_workspace_bytes(gvx_gl_plan* p, int B, int T, int n_mels) {
+    if (!p || B < 1 || T < 1) return 0;
+    FftPair* fp = nullptr;
+    if (get_plans(p, (long)B * T, &fp) != GVX_OK) return 0;
+    return gl_plan_ws(p, B, T, n_mels, fp->work_bytes).total;
+}
+
+int gvx_stft(gvx_gl_plan* p, const float* signal, const float* window, int B, long n_samples, float* spec_out, void* ws, size_t ws_bytes,
+             void* stream) {
+    if (!p || !signal || !window || !spec_out) return gl_fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (n_samples < p->n_fft) return gl_fail(GVX_ERR_INVALID_ARG, "signal shorter than one frame");
+    const int T = (int)((n_samples - p->n_fft) / p->hop + 1);
+    FftPair* fp = nullptr;
+    int rc = get_plans(p, (long)B * T, &fp);
+    if (rc != GVX_OK) return rc;
+    const GlWs w = gl_plan_ws(p, B, T, 0, fp->work_bytes);
+    rc = check_gl(p, B, T, ws, ws_bytes, w.total);
+    if (rc != GVX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    gl_frame_kernel<<<dim3((unsigned)((long)B * T)), 256, 0, s>>>(signal, window, wsp<float>(ws, w.fr), p->n_fft, p->hop, T, n_samples);
+    GL_HIP(hipGetLastError());
+    rc = run_fft(p, fp->r2c, wsp<float>(ws, w.fr), wsp<float2>(ws, w.reb0), wsp<char>(ws, w.fft_work), fp->work_bytes, s);
+    if (rc != GVX_OK) return rc;
+    GL_HIP(launch_transpose<float2>(wsp<float2>(ws, w.reb0), reinterpret_cast<float2*>(spec_out), B, T, p->bins, s));
+    return GVX_OK;
+}
+
+int gvx_istft(gvx_gl_plan* p, const float* spec, const float* window, int B, int T, float* signal_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !spec || !window || !signal_out) return gl_fail(GVX_ERR_INVALID_ARG, "null argument");
+    FftPair* fp = nullptr;
+    int rc = get_plans(p, (long)B * T, &fp);
+    if (rc != GVX_OK) return rc;
+    const GlWs w = gl_plan_ws(p, B, T, 0, fp->work_bytes);
+    rc = check_gl(p, B, T, ws, ws_bytes, w.total);
+    if (rc != GVX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)p->n_fft + (long)(T - 1) * p->hop;
+    GL_HIP(launch_transpose<float2>(reinterpret_cast<const float2*>(spec), wsp<float2>(ws, w.ang), B, p->bins, T, s));
+    wss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(window, wsp<float>(ws, w.wss), p->n_fft, p->hop, T, n);
+    GL_HIP(hipGetLastError());
+    rc = istft_frames(p, fp, wsp<float2>(ws, w.ang), window, B, T, ws, w, s);
+    if (rc != GVX_OK) return rc;
+    GL_HIP(hipMemcpyAsync(signal_out, wsp<float>(ws, w.y), (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return GVX_OK;
+}
+
+int gvx_mel_to_magnitude(gvx_gl_plan* p, const float* mel_db, const float* inv_basis, int B, int n_mels, int T, int log10_kind, float ref,
+                         float* mag_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !mel_db || !inv_basis || !mag_out) return gl_fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (n_mels & 3) return gl_fail(GVX_ERR_UNSUPPORTED, "n_mels must be a multiple of 4");
+    FftPair* fp = nullptr;
+    int rc = get_plans(p, (long)B * T, &fp);
+    if (rc != GVX_OK) return rc;
+    const GlWs w = gl_plan_ws(p, B, T, n_mels, fp->work_bytes);
+    rc = check_gl(p, B, T, ws, ws_bytes, w.total);
+    if (rc != GVX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const float refc = ref > 1e-5f ? ref : 1e-5f;
+    const float log_ref = log10_kind ? log10f(refc) : logf(refc);
+    db_to_amp_transpose_kernel<<<dim3((T + 31) / 32, (n_mels + 31) / 32, B), dim3(32, 8), 0, s>>>(mel_db, wsp<float>(ws, w.amp), n_mels, T,
+                                                                                                 log10_kind, log_ref);
+    GL_HIP(hipGetLastError());
+    // mel2fft (utils/audio/base.py:143-145): mag_t[(b,t)][bin] = sum_m inv_basis[bin][m] * amp_t[(b,t)][m]
+    gvx::GemmParams g{};
+    g.A = wsp<float>(ws, w.amp); g.amap = gvx::RowMap{B * T, 0, (long)n_mels};
+    g.W = inv_basis; g.ldw = n_mels;
+    g.C = wsp<float>(ws, w.mag); g.cmap = gvx::RowMap{B * T, 0, (long)p->bins};
+    g.M = B * T; g.N = p->bins; g.K = n_mels; g.act = gvx::ACT_NONE;
+    GL_HIP(gvx::launch_gemm(g, s));
+    GL_HIP(launch_transpose<float>(wsp<float>(ws, w.mag), mag_out, B, T, p->bins, s));
+    return GVX_OK;
+}
+
+int gvx_griffin_lim(gvx_gl_plan* p, const float* mag, const float* window, int B, int T, int n_iter, float momentum, float* phase_out,
+                    float* wav_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !mag || !window) return gl_fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (n_iter < 0) return gl_fail(GVX_ERR_INVALID_ARG, "n_iter must be >= 0");
+    FftPair* fp = nullptr;
+    int rc = get_plans(p, (long)B * T, &fp);
+    if (rc != GVX_OK) return rc;
+    const GlWs w = gl_plan_ws(p, B, T, 0, fp->work_bytes);
+    rc = check_gl(p, B, T, ws, ws_bytes, w.total);
+    if (rc != GVX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)p->n_fft + (long)(T - 1) * p->hop;
+    const long nbin = (long)B * T * p->bins;
+    float* mag_t = wsp<float>(ws, w.mag);
+    float2* ang = wsp<float2>(ws, w.ang);
+    float2* reb[2] = {wsp<float2>(ws, w.reb0), wsp<float2>(ws, w.reb1)};
+    GL_HIP(launch_transpose<float>(mag, mag_t, B, p->bins, T, s));
+    wss_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(window, wsp<float>(ws, w.wss), p->n_fft, p->hop, T, n);
+    GL_HIP(hipGetLastError());
+    gl_init_kernel<<<blocks_for(nbin), 256, 0, s>>>(mag_t, ang, nbin);
+    GL_HIP(hipGetLastError());
+    const float c = momentum / (1.f + momentum);
+    for (int it = 0; it < n_iter; ++it) {
+        rc = istft_frames(p, fp, ang, window, B, T, ws, w, s);  // inverse = istft(angles)
+        if (rc != GVX_OK) return rc;
+        gl_frame_kernel<<<dim3((unsigned)((long)B * T)), 256, 0, s>>>(wsp<float>(ws, w.y), window, wsp<float>(ws, w.fr), p->n_fft, p->hop, T, n);
+        GL_HIP(hipGetLastError());
+        float2* cur = reb[it & 1];
+        rc = run_fft(p, fp->r2c, wsp<float>(ws, w.fr), cur, wsp<char>(ws, w.fft_work), fp->work_bytes, s);  // rebuilt = stft(inverse)
+        if (rc != GVX_OK) return rc;
+        gl_update_kernel<<<blocks_for(nbin), 256, 0, s>>>(cur, reb[(it + 1) & 1], mag_t, ang, c, it == 0, nbin);
+        GL_HIP(hipGetLastError());
+    }
+    // phase = angle(angles); final spectrum = mag * exp(i phase) (not `angles` itself: they differ where mag < 0)
+    float2* spec_t = reb[0];
+    float* phase_t = reinterpret_cast<float*>(reb[1]);
+    gl_final_kernel<<<blocks_for(nbin), 256, 0, s>>>(ang, mag_t, wav_out ? spec_t : nullptr, phase_out ? phase_t : nullptr, nbin);
+    GL_HIP(hipGetLastError());
+    if (phase_out) GL_HIP(launch_transpose<float>(phase_t, phase_out, B, T, p->bins, s));
+    if (wav_out) {
+        rc = istft_frames(p, fp, spec_t, window, B, T, ws, w, s);
+        if (rc != GVX_OK) return rc;
+        GL_HIP(hipMemcpyAsync(wav_out, wsp<float>(ws, w.y), (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return GVX_OK;
+}
+
+int gvx_wav_finalize(const float* wav, int B, long n_samples, int trim, const double* b_coef, const double* a_coef, int order,
+                     double* out, unsigned int* scratch_B, void* stream) {
+    if (!wav || !b_coef || !a_coef || !out || !scratch_B) return gl_fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (order < 1 || order > 7) return gl_fail(GVX_ERR_UNSUPPORTED, "filter order %d not in [1, 7]", order);
+    if (n_samples <= 2L * trim) return gl_fail(GVX_ERR_INVALID_ARG, "signal shorter than the trim");
+    hipStream_t s = (hipStream_t)stream;
+    IirCoef c{};
+    c.order = order;
+    for (int k = 0; k <= order; ++k) { c.b[k] = b_coef[k] / a_coef[0]; c.a[k] = a_coef[k] / a_coef[0]; }
+    GL_HIP(hipMemsetAsync(scratch_B, 0, (size_t)B * sizeof(unsigned int), s));
+    wav_peak_kernel<<<dim3(64, B), 256, 0, s>>>(wav, n_samples, trim, scratch_B);
+    GL_HIP(hipGetLastError());
+    wav_filter_kernel<<<(B + 63) / 64, 64, 0, s>>>(wav, n_samples, trim, scratch_B, c, out, B);
+    GL_HIP(hipGetLastError());
+    return GVX_OK;
+}
+
+}  // extern "C"

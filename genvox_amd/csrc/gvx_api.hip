@@ -37,8 +37,13 @@ hipError_t attention_init();
 using namespace gvx;
 
 namespace {
-
 thread_local std::string g_err;
+}
+namespace gvx {
+int set_error(int code, const char* msg) { g_err = msg; return code; }
+}
+
+namespace {
 
 int fail(int code, const char* fmt, ...) {
     char buf[1024];

@@ -20,6 +20,9 @@ namespace gvx { namespace { __device__ unsigned long long gvx_stamps[3][32]; } }
 
 namespace gvx {
 
+// error reporting shared by every translation unit of the C ABI (thread-local message, returns `code`)
+int set_error(int code, const char* msg);
+
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
 // ---------------------------------------------------------------------------------------------

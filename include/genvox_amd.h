@@ -145,6 +145,38 @@ int gvx_prenet_masks_generate(uint8_t* masks_out, size_t n, uint64_t seed, void*
 int gvx_stage_timing_enable(gvx_model* model, int enable);
 int gvx_stage_times_ms(gvx_model* model, float* times5_out, int* decoder_launches_out);
 
+/* =====================================================================================================
+ * Vocoder: mel (dB) -> waveform.  Replaces the mel->wav half of utils/audio/base.py and
+ * AudioProcessor.convert_mel2wav (core/processors.py:81-96), batched over utterances.
+ * Spectrograms use the reference's layout [B][bins][frames] (bins = n_fft/2 + 1); complex values are
+ * interleaved (re, im) floats.  `window` is the float32 periodic Hann window [n_fft] (device).
+ * A gvx_gl_plan owns the rocFFT plans (one pair per distinct B*T, created on first use).
+ * ===================================================================================================== */
+typedef struct gvx_gl_plan gvx_gl_plan;
+int gvx_gl_plan_create(int n_fft, int hop, gvx_gl_plan** out);
+void gvx_gl_plan_destroy(gvx_gl_plan* plan);
+size_t gvx_gl_workspace_bytes(gvx_gl_plan* plan, int B, int T, int n_mels);
+
+/* stft (utils/audio/base.py:58-69): signal [B][n_samples] -> spec_out complex [B][bins][T], T = (n_samples-n_fft)/hop+1 */
+int gvx_stft(gvx_gl_plan* plan, const float* signal, const float* window, int B, long n_samples, float* spec_out,
+             void* workspace, size_t workspace_bytes, void* stream);
+/* istft (utils/audio/base.py:71-88): spec complex [B][bins][T] -> signal_out [B][n_fft + (T-1)*hop] */
+int gvx_istft(gvx_gl_plan* plan, const float* spec, const float* window, int B, int T, float* signal_out,
+              void* workspace, size_t workspace_bytes, void* stream);
+/* db_to_amplitude + mel2fft (utils/audio/base.py:38-52 with power=False/scale=1, :143-145):
+ * mel_db [B][n_mels][T], inv_basis [bins][n_mels] -> mag_out [B][bins][T].  log10_kind: 0 = np.log, 1 = np.log10. */
+int gvx_mel_to_magnitude(gvx_gl_plan* plan, const float* mel_db, const float* inv_basis, int B, int n_mels, int T, int log10_kind,
+                         float ref, float* mag_out, void* workspace, size_t workspace_bytes, void* stream);
+/* fast Griffin-Lim (utils/audio/base.py:147-162) + final synthesis istft(mag * exp(i phase)) (core/processors.py:89-90).
+ * mag [B][bins][T]; phase_out [B][bins][T] or NULL; wav_out [B][n_fft + (T-1)*hop] or NULL. */
+int gvx_griffin_lim(gvx_gl_plan* plan, const float* mag, const float* window, int B, int T, int n_iter, float momentum,
+                    float* phase_out, float* wav_out, void* workspace, size_t workspace_bytes, void* stream);
+/* tail of convert_mel2wav (core/processors.py:91-95): samples with |y| > 1 -> 0, drop `trim` samples at both ends,
+ * divide by the peak (float32), IIR filter b/a (HOST doubles, order+1 each; scipy.signal.lfilter semantics, float64).
+ * out: float64 [B][n_samples - 2*trim]; scratch_B: B uint32 of device scratch. */
+int gvx_wav_finalize(const float* wav, int B, long n_samples, int trim, const double* b_coef, const double* a_coef, int order,
+                     double* out, unsigned int* scratch_B, void* stream);
+
 /* ---- Per-launch timing of the decoder step (measurement only): when enabled, the teacher-forced loop brackets
  * every LSTM-step launch and every attention launch with HIP events on `stream`; gvx_kernel_times_ms synchronises
  * and returns the average duration of each over the last call's T steps. */

@@ -70,6 +70,10 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build the gfx950 library first (python -m genvox_amd.build, or "
             f"__graft_entry__.build()). genvox_amd has no CPU or eager fallback.")
+    # torch ships its own libamdhip64; it must be the one already loaded when this library's dependency on the HIP
+    # runtime is resolved, otherwise the process ends up with two runtimes and device pointers / streams do not mix.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree

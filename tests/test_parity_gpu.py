@@ -139,3 +139,48 @@ def test_full_size_properties_and_long_horizon_parity():
     for k in KEYS:
         d = max_abs_diff(out[k][rows], want[k])
         assert d <= TOL, f"{k}: {d}"
+
+
+@pytest.mark.parametrize("B,L,T,dims", [
+    (40, 50, 6, "full"),      # B > 32: two batch tiles per MFMA pass (MT = 2), G = 2 attention groups
+    (64, 16, 4, "full"),      # maximum rows per call, minimum useful L (G = 2)
+    (2, 300, 5, "full"),      # long rows: several passes per attention workgroup, context prefetch reloads
+    (1, 7, 3, "small"),       # single short row, reduced dims
+    (33, 21, 3, "small"),     # MT = 2 with reduced dims and ragged lengths
+])
+def test_shapes_against_oracle(B, L, T, dims):
+    case = TF_CASES["tf_full" if dims == "full" else "tf_small"]
+    name = "tf_full" if dims == "full" else "tf_small"
+    m, (mc, ac, tc) = gpu_model(name, case)
+    sd = case_state_dict(name)
+    rng = np.random.default_rng(B * 1000 + L)
+    tl = np.sort(rng.integers(max(1, L // 3), L + 1, size=B))[::-1].copy()
+    tl[0] = L
+    ml = rng.integers(1, T + 1, size=B)
+    ml[rng.integers(0, B)] = T
+    inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=9, token_lengths=tl, mel_lengths=ml)
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    masks = torch.from_numpy(gw.prenet_keep_masks((T + 1) * B, mc.prenet_dim, seed=B + L))
+    want = tacotron2_ref.tacotron2_forward(sd, batch, masks, mask_padding=True)
+    got = m.forward({**batch, "prenet_keep_masks": masks})
+    for k in KEYS:
+        d = max_abs_diff(got[k], want[k])
+        assert d <= TOL, f"B={B} L={L} T={T} {k}: {d}"
+
+
+def test_autoregressive_batch_over_32_rows():
+    """B = 36 autoregressive rows (MT = 2 path of the per-step GEMVs), first and last row against batch-1 oracle runs."""
+    name = "ar_small_gate"
+    case, fx = AR_CASES[name], load_fixture(name)
+    steps = 10
+    m, (mc, ac, tc) = gpu_model(name, case, max_decoder_steps=steps, gate_threshold=1.0)
+    sd = case_state_dict(name)
+    B, L = 36, 11
+    tok = (gw.hashed_uniform(5, "ar36", B * L) * tc.n_tokens).astype(np.int64).reshape(B, L)
+    masks = torch.from_numpy(gw.prenet_keep_masks(steps * B, mc.prenet_dim, seed=3)).reshape(2, steps, B, mc.prenet_dim)
+    out = m.inference({"tokens": torch.from_numpy(tok), "prenet_keep_masks": masks})
+    assert out["mel_outputs"].shape == (B, ac.n_mels, steps)
+    for b in (0, 17, 35):
+        want = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(tok[b:b + 1]), masks[:, :, b], 1.0, steps)
+        for k in KEYS:
+            assert max_abs_diff(out[k][b:b + 1], want[k]) <= TOL, (b, k)

@@ -33,7 +33,7 @@ __device__ __forceinline__ long row_off(const RowMap& m, int row) {
 }
 
 template <int WR, int WC, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int BM = WR * TM * 32;
     constexpr int BN = WC * TN * 32;
     constexpr int A_V4 = BM / 32;  // float4 loads per thread for the A tile
@@ -65,30 +65,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     for (int i = 0; i < B_V4; ++i) {
         int n = n0 + ld_row + 32 * i;
         b_ok[i] = n < p.N;
-        b_ptr[i] = p.W + (b_ok[i] ? (long)n * p.ldw : 0) + 4 * ld_c4;
+        b_ptr[i] = p.W + (b_ok[i] ? (long)n * p.ldw : 0);
     }
     float4 a_reg[A_V4], b_reg[B_V4];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    auto load_tile = [&](int k0) {
-        const int k = k0 + 4 * ld_c4;
-        const bool k_ok = k < p.K;
-        const long a_koff = (long)(k >> 3) * p.a_kblk + (k & 7);
-#pragma unroll
-        for (int i = 0; i < A_V4; ++i)
-            a_reg[i] = (a_ok[i] && k_ok) ? *reinterpret_cast<const float4*>(a_ptr[i] + a_koff) : zero4;
-#pragma unroll
-        for (int i = 0; i < B_V4; ++i)
-            b_reg[i] = (b_ok[i] && k_ok) ? *reinterpret_cast<const float4*>(b_ptr[i] + k0) : zero4;
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_V4; ++i)
-            *reinterpret_cast<float4*>(&As[(buf * BM + ld_row + 32 * i) * LDS_LD + 4 * ld_c4]) = a_reg[i];
-#pragma unroll
-        for (int i = 0; i < B_V4; ++i)
-            *reinterpret_cast<float4*>(&Bs[(buf * BN + ld_row + 32 * i) * LDS_LD + 4 * ld_c4]) = b_reg[i];
-    };
+    // global -> registers for the k-tile starting at K0.  Rows past M / N read row 0 (in bounds): their products land in
+    // accumulator rows / columns the epilogue never stores, so only the k tail is masked (per component: a float4
+    // select makes LLVM build a scratch lookup table).
+#define GEMM_LOAD_TILE(K0)                                                                                  \
+    {                                                                                                       \
+        const int k_ = (K0) + 4 * ld_c4;                                                                    \
+        const bool k_ok_ = k_ < p.K;                                                                        \
+        const long a_koff_ = (long)(k_ >> 3) * p.a_kblk + (k_ & 7);                                         \
+        _Pragma("unroll") for (int i = 0; i < A_V4; ++i) {                                                  \
+            const float4 v_ = *reinterpret_cast<const float4*>(a_ptr[i] + (k_ok_ ? a_koff_ : 0));           \
+            a_reg[i].x = k_ok_ ? v_.x : 0.f; a_reg[i].y = k_ok_ ? v_.y : 0.f;                               \
+            a_reg[i].z = k_ok_ ? v_.z : 0.f; a_reg[i].w = k_ok_ ? v_.w : 0.f;                               \
+        }                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < B_V4; ++i) {                                                  \
+            const float4 v_ = *reinterpret_cast<const float4*>(b_ptr[i] + (k_ok_ ? k_ : 0));               \
+            b_reg[i].x = k_ok_ ? v_.x : 0.f; b_reg[i].y = k_ok_ ? v_.y : 0.f;                               \
+            b_reg[i].z = k_ok_ ? v_.z : 0.f; b_reg[i].w = k_ok_ ? v_.w : 0.f;                               \
+        }                                                                                                   \
+    }
+#define GEMM_STORE_TILE(BUF)                                                                                \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < A_V4; ++i)                                                    \
+            *reinterpret_cast<float4*>(&As[((BUF) * BM + ld_row + 32 * i) * LDS_LD + 4 * ld_c4]) = a_reg[i]; \
+        _Pragma("unroll") for (int i = 0; i < B_V4; ++i)                                                    \
+            *reinterpret_cast<float4*>(&Bs[((BUF) * BN + ld_row + 32 * i) * LDS_LD + 4 * ld_c4]) = b_reg[i]; \
+    }
+#define GEMM_COMPUTE_TILE(BUF)                                                                              \
+    {                                                                                                       \
+        const float* a_base = &As[((BUF) * BM + wr * TM * 32 + r) * LDS_LD + 4 * h];                        \
+        const float* b_base = &Bs[((BUF) * BN + wc * TN * 32 + r) * LDS_LD + 4 * h];                        \
+        _Pragma("unroll") for (int kg = 0; kg < BK / 8; ++kg) {                                             \
+            float4 af[TM], bf[TN];                                                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+                af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDS_LD + 8 * kg);                \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
+                bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDS_LD + 8 * kg);                \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0); \
+                }                                                                                           \
+        }                                                                                                   \
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -98,35 +123,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+    // rows that do not exist read row 0 / weight row 0 (in bounds) and are zeroed by the select above
     const int nkt = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    GEMM_LOAD_TILE(0)
+    GEMM_STORE_TILE(0)
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    int kt = 0;
+    for (; kt + 1 < nkt; ++kt) {            // steady state: prefetch tile kt+1 while computing tile kt (no branches inside)
         const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile((kt + 1) * BK);
-        const float* a_base = &As[(cur * BM + wr * TM * 32 + r) * LDS_LD + 4 * h];
-        const float* b_base = &Bs[(cur * BN + wc * TN * 32 + r) * LDS_LD + 4 * h];
-#pragma unroll
-        for (int kg = 0; kg < BK / 8; ++kg) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDS_LD + 8 * kg);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDS_LD + 8 * kg);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        GEMM_LOAD_TILE((kt + 1) * BK)
+        GEMM_COMPUTE_TILE(cur)
+        GEMM_STORE_TILE(cur ^ 1)
         __syncthreads();
     }
+    GEMM_COMPUTE_TILE(kt & 1)               // last tile
+#undef GEMM_LOAD_TILE
+#undef GEMM_STORE_TILE
+#undef GEMM_COMPUTE_TILE
 
     // epilogue: D[row][col] with col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
 #pragma unroll

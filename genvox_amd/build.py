@@ -29,9 +29,13 @@ def _newer(a: str, b: str) -> bool:
 def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> str:
     """stamps=True builds the diagnostic library libgenvox_amd_stamps.so (phase timestamps, tools/stamps.py)."""
     objs, jobs = [], []
-    flags = CXXFLAGS + (["-DGVX_STAMPS"] if stamps else [])
+    flags = CXXFLAGS + (["-DGVX_STAMPS"] if stamps else []) + os.environ.get("GVX_EXTRA_FLAGS", "").split()
     lib = LIB.replace(".so", "_stamps.so") if stamps else LIB
+    if os.environ.get("GVX_LIB_NAME"):
+        lib = os.path.join(HERE, os.environ["GVX_LIB_NAME"])
     sfx = ".stamps.o" if stamps else ".o"
+    if os.environ.get("GVX_LIB_NAME"):
+        sfx = "." + os.environ["GVX_LIB_NAME"] + ".o"
     headers = [os.path.join(CSRC, "gvx_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "genvox_amd.h")]
     for src in SOURCES:
         s = os.path.join(CSRC, src)

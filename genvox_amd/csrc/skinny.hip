@@ -31,6 +31,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #ifndef SK_DEPTH1
 #define SK_DEPTH1 8
 #endif
+#ifndef SK_SPLIT_OLD
+#define SK_SPLIT_OLD 32   // 32/64 = even split
+#endif
 #ifndef SK_NWAVES
 #define SK_NWAVES 8
 #endif
@@ -93,9 +96,25 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     // groups in flight per wave and 8 waves per CU about DEPTH*8 KiB of weights are outstanding per CU, which is
     // what it takes to cover the ~2 us loaded-memory latency at ~30 GB/s per CU.  No load is conditional (indices
     // are clamped instead) so the compiler can retire them with counted s_waitcnt vmcnt(N).
-    const int per = (J.nkg + SK_WAVES - 1) / SK_WAVES;
-    const int kg_begin = wave * per;
-    const int kg_end = min(J.nkg, kg_begin + per);
+    // K split over the waves.  Measured (tools/stamps.py): with an even split the four younger waves of a workgroup
+    // (the second wave on each SIMD) finish their slice ~3 us after the four older ones and everybody waits at the
+    // reduction barrier.  SK_SPLIT_OLD/64 of the k-groups go to waves 0-3, the rest to waves 4-7 (static, so the
+    // summation order - and therefore every output bit - stays reproducible).
+    int kg_begin, kg_end;
+    if (SK_WAVES == 8 && J.nkg >= 64) {
+        const int half = SK_WAVES / 2;
+        const int n_old = ((J.nkg * SK_SPLIT_OLD) / 64 + half - 1) / half * half;   // k-groups of waves 0-3 together
+        const int per_old = n_old / half, per_young = (J.nkg - n_old + half - 1) / half;
+        if (wave < half) { kg_begin = wave * per_old; kg_end = kg_begin + per_old; }
+        else { kg_begin = n_old + (wave - half) * per_young; kg_end = min(J.nkg, kg_begin + per_young); }
+    } else {
+        const int per = (J.nkg + SK_WAVES - 1) / SK_WAVES;
+        kg_begin = wave * per;
+        kg_end = min(J.nkg, kg_begin + per);
+    }
+#ifdef SK_PRIO_YOUNG
+    if (wave >= SK_WAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     const int g0 = J.x[0].len >> 3, g1 = g0 + (J.x[1].len >> 3);  // k-group boundaries of the segments
 
     const float* xb0[MT]; const float* xb1[MT]; const float* xb2[MT];
@@ -161,6 +180,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     }
 
     GVX_STAMP(0, 1);
+#ifdef GVX_STAMPS
+    // per-wave end-of-main-loop times of one attention-LSTM tile (block 0) and one decoder-LSTM tile (block tiles0)
+    if (lane == 0 && (blockIdx.x == 0 || (int)blockIdx.x == jobs.tiles0))
+        gvx::gvx_stamps[blockIdx.x == 0 ? 1 : 2][8 + wave] = wall_clock64();
+    if (threadIdx.x == 0 && (int)blockIdx.x == jobs.tiles0) gvx::gvx_stamps[2][7] = gvx::gvx_stamps[0][0];
+#endif
     // ---- cross-wave K reduction through LDS
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)

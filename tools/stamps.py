@@ -33,3 +33,14 @@ for k, title in enumerate(["decoder_lstm_step (wg 0)", "attn_energy (wg 0,0)", "
     print(title)
     for i in range(1, len(v)):
         print(f"   {names[k][i]:22s} +{(v[i] - v[i - 1]) * 10} ns   (t = {(v[i] - v[0]) * 10} ns)")
+
+# per-wave main-loop end times (rows 1/2, slots 8..15 are written by the LSTM kernel's block 0 / first decoder tile)
+import ctypes as C2
+lib2 = C.CDLL(_lib.LIB_PATH)
+raw = (C.c_ulonglong * 96)()
+lib2.gvx_debug_read_stamps_skinny.argtypes = [C.c_void_p]
+if lib2.gvx_debug_read_stamps_skinny(raw) == 0:
+    t0 = raw[0]
+    for row, nm in ((1, "attention-LSTM tile 0"), (2, "decoder-LSTM tile 0")):
+        ends = [(raw[row * 32 + 8 + w] - t0) * 10 for w in range(8)]
+        print(f"{nm}: per-wave main-loop end (ns after block 0 start): {ends}  spread {max(ends) - min(ends)} ns")

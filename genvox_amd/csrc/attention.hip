@@ -19,11 +19,12 @@
 
 namespace gvx {
 
-constexpr int AT_THREADS = 256;
-constexpr int AT_WAVES = AT_THREADS / 64;
+constexpr int AT_THREADS = 256;              // context kernel
+constexpr int EN_THREADS = 512;              // energy kernel: 8 waves (conv / energy phases are VALU+LDS work that scales with waves)
+constexpr int EN_WAVES = EN_THREADS / 64;
 constexpr int EN_LC = 32;    // positions per pass of the energy kernel
 constexpr int AT_FP = 32;    // max location filters (register/LDS row width)
-constexpr int EN_QG = 8;     // slab rows summed in parallel for the query
+constexpr int EN_QG = 16;    // slab rows summed in parallel for the query
 
 __device__ __forceinline__ float fast_tanh(float x) {
     // 1 - 2/(exp(2x)+1): v_exp_f32 + v_rcp_f32, abs error ~1e-7; saturates correctly at +-inf
@@ -44,31 +45,28 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __host__ __device__ inline int chunk_len(int L, int G) { return (L + G - 1) / G; }
 
-struct EnergyLds { int q_off, v_off, wc_off, cw_off, f_off, part_off, total; };
-__host__ __device__ inline EnergyLds energy_lds_layout(int Lg, int a, int kl) {
+struct EnergyLds { int q_off, part_off, total; };
+__host__ __device__ inline EnergyLds energy_lds_layout(int a) {
     EnergyLds o;
     auto al = [](int x) { return (x + 3) & ~3; };
     int off = 0;
     o.q_off = off; off += al(EN_QG * a);
-    o.v_off = off; off += al(a);
-    o.wc_off = off; off += al(2 * (Lg + kl - 1));   // [2][chunk + halo]
-    o.cw_off = off; off += al(2 * kl * AT_FP);      // conv weights [2][kl][AT_FP]
-    o.f_off = off; off += EN_LC * AT_FP;
     o.part_off = off; off += EN_LC * 65;
     o.total = off;
     return o;
 }
 
+// energies[b][l] = v . tanh(q + pm[l,:] + loc[l,:])  for the workgroup's chunk of positions.  The location features
+// loc were produced by extra workgroups of the preceding LSTM launch (skinny.hip, loc_body); q is the sum of that
+// launch's per-tile partial slabs.  What is left here is one round trip of coalesced loads, a+L tanh per position and
+// a 64-lane reduction.
 template <int DPL>
-__global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
+__global__ __launch_bounds__(EN_THREADS) void attn_energy_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int L = p.L, a = p.a, kl = p.kl;
+    const int L = p.L, a = p.a;
     const int Lg = chunk_len(L, p.G);
-    const EnergyLds lo = energy_lds_layout(Lg, a, kl);
+    const EnergyLds lo = energy_lds_layout(a);
     float* qs = smem + lo.q_off;
-    float* wc = smem + lo.wc_off;
-    float* cw = smem + lo.cw_off;
-    float* fb = smem + lo.f_off;
     float* part = smem + lo.part_off;
 
     const int g = blockIdx.x, b = blockIdx.y;
@@ -76,20 +74,17 @@ __global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l_begin = g * Lg, l_end = min(L, l_begin + Lg);
     if (l_begin >= l_end) return;  // uniform per workgroup
-    const int pad = (kl - 1) / 2, LW = Lg + kl - 1;
     const int len = p.lengths ? p.lengths[b] : L;
     GVX_STAMP(1, 0);
 
-    // Every input of this kernel was written by another kernel (or is first-touch for this CU), so each dependent
-    // round trip costs ~1 us.  All global loads are therefore issued up front, back to back, and consumed afterwards.
-    // (1) query partial slabs: qg slab rows in parallel, float4 per thread
+    // ---- issue all loads of the first pass up front (each dependent round trip to fresh data costs ~1 us)
     const int a4 = a >> 2;
-    const int qg = min(EN_QG, AT_THREADS / a4);
+    const int qg = min(EN_QG, EN_THREADS / a4);
     const int grp = tid / a4, d4 = tid - grp * a4;
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int QV = 16;
+    constexpr int QV = 8;
     float4 qld[QV];
-    const bool q_fast = grp < qg && p.n_slabs == QV * qg;   // default dims: 128 slabs = 16 x 8
+    const bool q_fast = grp < qg && p.n_slabs == QV * qg;   // default dims: 128 slabs = 8 x 16
     {
         const float4* base = reinterpret_cast<const float4*>(p.q_slab + (long)b * a) + d4;
         const long tstride = (long)p.B * a4;
@@ -103,73 +98,28 @@ __global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
             }
         }
     }
-    // (2) previous / cumulative weights of the chunk with a zero-filled halo of (kl-1)/2 positions
-    float wcv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + i * AT_THREADS;
-        const int ch = idx / LW, ii = idx - ch * LW, l = l_begin + ii - pad;
-        float val = 0.f;
-        if (idx < 2 * LW && l >= 0 && l < L)
-            val = ch == 0 ? (p.w_prev ? p.w_prev[(long)b * p.w_prev_bs + l] : 0.f) : p.w_cum[(long)b * L + l];
-        wcv[i] = val;
-    }
-    // (3) location conv weights, pre-transposed [2][kl][AT_FP] (zero padded) -> straight float4 copies
-    const int cw4 = (2 * kl * AT_FP) >> 2;
-    float4 cwv[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * AT_THREADS;
-        cwv[i] = idx < cw4 ? reinterpret_cast<const float4*>(p.loc_conv_t)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // (4) dense location weights, pre-transposed [AT_FP][a]: lane d reads consecutive addresses (coalesced)
-    float wd[DPL][AT_FP];
     float vv[DPL];
+    float pmv[EN_LC / EN_WAVES][DPL], lcv[EN_LC / EN_WAVES][DPL];
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int d = min(lane + 64 * i, a - 1);
+    for (int i = 0; i < DPL; ++i) vv[i] = (lane + 64 * i) < a ? p.v[min(lane + 64 * i, a - 1)] : 0.f;
 #pragma unroll
-        for (int c = 0; c < AT_FP; ++c) wd[i][c] = p.loc_dense_t[(long)c * a + d];
-        vv[i] = (lane + 64 * i) < a ? p.v[d] : 0.f;
-    }
-    // (5) processed-memory values of this wave's positions (first pass)
-    float pmv[EN_LC / AT_WAVES][DPL];
+    for (int j = 0; j < EN_LC / EN_WAVES; ++j) {
+        const long row = ((long)b * L + min(l_begin + wave + j * EN_WAVES, l_end - 1)) * a;
 #pragma unroll
-    for (int j = 0; j < EN_LC / AT_WAVES; ++j) {
-        const int l = min(l_begin + wave + j * AT_WAVES, l_end - 1);
-        const float* pmrow = p.pm + ((long)b * L + l) * a;
-#pragma unroll
-        for (int i = 0; i < DPL; ++i) pmv[j][i] = pmrow[min(lane + 64 * i, a - 1)];
+        for (int i = 0; i < DPL; ++i) {
+            const int d = min(lane + 64 * i, a - 1);
+            pmv[j][i] = p.pm[row + d];
+            lcv[j][i] = p.loc[row + d];
+        }
     }
     GVX_STAMP(1, 1);
-
-    // ---- consume: stage to LDS
     if (q_fast) {
 #pragma unroll
         for (int i = 0; i < QV; ++i) { s4.x += qld[i].x; s4.y += qld[i].y; s4.z += qld[i].z; s4.w += qld[i].w; }
     }
     if (grp < qg) reinterpret_cast<float4*>(qs + grp * a)[d4] = s4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + i * AT_THREADS;
-        if (idx < 2 * LW) wc[idx] = wcv[i];
-    }
-    for (int idx = tid + 4 * AT_THREADS; idx < 2 * LW; idx += AT_THREADS) {  // long chunks only
-        const int ch = idx / LW, ii = idx - ch * LW, l = l_begin + ii - pad;
-        float val = 0.f;
-        if (l >= 0 && l < L) val = ch == 0 ? (p.w_prev ? p.w_prev[(long)b * p.w_prev_bs + l] : 0.f) : p.w_cum[(long)b * L + l];
-        wc[idx] = val;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * AT_THREADS;
-        if (idx < cw4) reinterpret_cast<float4*>(cw)[idx] = cwv[i];
-    }
-    for (int idx = tid + 2 * AT_THREADS; idx < cw4; idx += AT_THREADS)
-        reinterpret_cast<float4*>(cw)[idx] = reinterpret_cast<const float4*>(p.loc_conv_t)[idx];
-    GVX_STAMP(1, 2);
     __syncthreads();
-    GVX_STAMP(1, 3);
+    GVX_STAMP(1, 2);
     float qv[DPL];
 #pragma unroll
     for (int i = 0; i < DPL; ++i) {
@@ -181,73 +131,42 @@ __global__ __launch_bounds__(AT_THREADS) void attn_energy_kernel(AttnParams p) {
 
     for (int l0 = l_begin; l0 < l_end; l0 += EN_LC) {
         const int lc = min(EN_LC, l_end - l0);
-        if (l0 != l_begin) {  // later passes (long chunks): fetch their processed-memory rows now
+        if (l0 != l_begin) {  // later passes (long chunks)
 #pragma unroll
-            for (int j = 0; j < EN_LC / AT_WAVES; ++j) {
-                const int l = min(l0 + wave + j * AT_WAVES, l_end - 1);
-                const float* pmrow = p.pm + ((long)b * L + l) * a;
+            for (int j = 0; j < EN_LC / EN_WAVES; ++j) {
+                const long row = ((long)b * L + min(l0 + wave + j * EN_WAVES, l_end - 1)) * a;
 #pragma unroll
-                for (int i = 0; i < DPL; ++i) pmv[j][i] = pmrow[min(lane + 64 * i, a - 1)];
-            }
-        }
-        GVX_STAMP(1, 4);
-        {   // location conv: thread = (position, group of 4 filters)
-            const int ll = tid & (EN_LC - 1), fg = tid >> 5;  // 8 groups of 4 filters
-            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-            if (ll < lc) {
-                for (int ch = 0; ch < 2; ++ch) {
-                    const float* xrow = wc + ch * LW + (l0 - l_begin) + ll;
-                    const float* wrow = cw + (ch * kl) * AT_FP + fg * 4;
-#pragma unroll 8
-                    for (int k = 0; k < kl; ++k) {
-                        const float x = xrow[k];
-                        const float4 w = *reinterpret_cast<const float4*>(wrow + k * AT_FP);
-                        acc0 = fmaf(w.x, x, acc0); acc1 = fmaf(w.y, x, acc1);
-                        acc2 = fmaf(w.z, x, acc2); acc3 = fmaf(w.w, x, acc3);
-                    }
+                for (int i = 0; i < DPL; ++i) {
+                    const int d = min(lane + 64 * i, a - 1);
+                    pmv[j][i] = p.pm[row + d];
+                    lcv[j][i] = p.loc[row + d];
                 }
             }
-            *reinterpret_cast<float4*>(fb + ll * AT_FP + fg * 4) = make_float4(acc0, acc1, acc2, acc3);
         }
-        __syncthreads();
-        GVX_STAMP(1, 5);
-        // energies: a wave takes positions wave, wave+4, ...; lane = attention dim(s); per-lane partials go to LDS
-        // and are reduced over the 64 lanes in one batched pass (instead of 6 cross-lane shuffles per position)
 #pragma unroll
-        for (int j = 0; j < EN_LC / AT_WAVES; ++j) {
-            const int ll = wave + j * AT_WAVES;
+        for (int j = 0; j < EN_LC / EN_WAVES; ++j) {
+            const int ll = wave + j * EN_WAVES;
             float pe = 0.f;
-            const float* frow = fb + ll * AT_FP;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                float s = qv[i] + pmv[j][i];
-#pragma unroll
-                for (int c4 = 0; c4 < AT_FP / 4; ++c4) {
-                    const float4 fv = *reinterpret_cast<const float4*>(frow + 4 * c4);
-                    s = fmaf(wd[i][4 * c4 + 0], fv.x, s);
-                    s = fmaf(wd[i][4 * c4 + 1], fv.y, s);
-                    s = fmaf(wd[i][4 * c4 + 2], fv.z, s);
-                    s = fmaf(wd[i][4 * c4 + 3], fv.w, s);
-                }
-                pe = fmaf(vv[i], fast_tanh(s), pe);
-            }
+            for (int i = 0; i < DPL; ++i) pe = fmaf(vv[i], fast_tanh((qv[i] + lcv[j][i]) + pmv[j][i]), pe);
             part[ll * 65 + lane] = pe;
         }
         __syncthreads();
-        GVX_STAMP(1, 6);
-        {   // thread = (position, eighth of the lanes): 8 partials each, then 3 shuffles
-            const int ll = tid >> 3, sg = tid & 7;
+        GVX_STAMP(1, 3);
+        {   // thread = (position, sixteenth of the lanes): 4 partials each, then 4 shuffles
+            const int ll = tid >> 4, sg = tid & 15;
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += part[ll * 65 + sg * 8 + i];
+            for (int i = 0; i < 4; ++i) s += part[ll * 65 + sg * 4 + i];
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 8);
             const int l = l0 + ll;
             if (sg == 0 && ll < lc) p.energies[(long)b * L + l] = l < len ? s : -INFINITY;
         }
         __syncthreads();
-        GVX_STAMP(1, 7);
+        GVX_STAMP(1, 4);
     }
 }
 
@@ -381,9 +300,8 @@ int attention_groups(int B, int L) {
 
 bool attention_supported(int L, int a, int F, int kl, int E) {
     if (F > AT_FP || a > 256 || (E & 7) || (a & 3) || a < 4) return false;
-    const size_t lds_e = (size_t)energy_lds_layout(chunk_len(L, 1), a, kl).total * sizeof(float);
     const size_t lds_c = (size_t)context_lds_layout(L).total * sizeof(float);
-    return lds_e <= 160 * 1024 && lds_c <= 160 * 1024;
+    return lds_c <= 160 * 1024 && (size_t)(2 * (L + kl) + 2 * kl * 32 + 32 * 32 + 8) * sizeof(float) <= 160 * 1024;
 }
 
 hipError_t attention_init() {
@@ -399,13 +317,13 @@ hipError_t attention_init() {
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (!attention_supported(p.L, p.a, p.F, p.kl, p.E) || p.G < 1) return hipErrorInvalidValue;
-    const size_t lds_e = (size_t)energy_lds_layout(chunk_len(p.L, p.G), p.a, p.kl).total * sizeof(float);
+    const size_t lds_e = (size_t)energy_lds_layout(p.a).total * sizeof(float);
     const size_t lds_c = (size_t)context_lds_layout(p.L).total * sizeof(float);
-    const dim3 grid(p.G, p.B), block(AT_THREADS);
+    const dim3 grid(p.G, p.B), block(AT_THREADS), eblock(EN_THREADS);
     const int dpl = (p.a + 63) / 64;
-    if (dpl == 1) attn_energy_kernel<1><<<grid, block, lds_e, s>>>(p);
-    else if (dpl == 2) attn_energy_kernel<2><<<grid, block, lds_e, s>>>(p);
-    else attn_energy_kernel<4><<<grid, block, lds_e, s>>>(p);
+    if (dpl == 1) attn_energy_kernel<1><<<grid, eblock, lds_e, s>>>(p);
+    else if (dpl == 2) attn_energy_kernel<2><<<grid, eblock, lds_e, s>>>(p);
+    else attn_energy_kernel<4><<<grid, eblock, lds_e, s>>>(p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     attn_context_kernel<<<grid, block, lds_c, s>>>(p);

@@ -82,7 +82,7 @@ inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 
 
 struct WsPlan {  // byte offsets into the caller's workspace
     size_t xa, xb, xg, enc_h, enc_c, flags, memory;
-    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy;
+    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy, loc;
     size_t ya, yb;
     size_t total;
 };
@@ -154,7 +154,7 @@ Blob make_blob_layout(const gvx_dims& d) {
     b.wq_t = take((size_t)A * d.att_dim);
     b.wmem = take((size_t)d.att_dim * E); b.v = take(d.att_dim);
     b.loc_conv = take((size_t)2 * d.att_loc_kernel * 32);   // transposed [2][kl][32]
-    b.loc_dense = take((size_t)32 * d.att_dim);             // transposed [32][a]
+    b.loc_dense = take((size_t)32 * d.att_dim);             // transposed [32/4][a][4]
     b.dec_frag = take(frag_floats(4 * D, A + E + D)); b.dec_bias = take((size_t)4 * D);
     b.proj_w = take((size_t)(M + 1) * (D + E)); b.proj_b = take(M + 1);
     b.proj_frag = take(frag_floats(M + 1, D + E));
@@ -195,6 +195,7 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.energies = take((size_t)B * L);
     w.align_tm = take((size_t)T * B * L);   // alignments of the step loop, time-major [T][B][L]
     w.len_copy = take((size_t)B);           // token lengths copied next to the loop's other operands
+    w.loc = take((size_t)B * L * d.att_dim);  // location features of the current step
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
     w.yb = take((size_t)B * (T + 2 * pp) * cmax);
@@ -390,7 +391,7 @@ int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, vo
             for (int ck = 0; ck < 2 * d.att_loc_kernel; ++ck) out[bl.loc_conv + (size_t)ck * 32 + c] = src[(size_t)c * 2 * d.att_loc_kernel + ck];
         if (!(src = wt.get(att + "location_layer.location_dense.linear_layer.weight", (int64_t)a * d.att_loc_filters, &rc))) return rc;
         for (int dd = 0; dd < a; ++dd)
-            for (int c = 0; c < d.att_loc_filters; ++c) out[bl.loc_dense + (size_t)c * a + dd] = src[(size_t)dd * d.att_loc_filters + c];
+            for (int c = 0; c < d.att_loc_filters; ++c) out[bl.loc_dense + ((size_t)(c >> 2) * a + dd) * 4 + (c & 3)] = src[(size_t)dd * d.att_loc_filters + c];
     }
     {   // decoder LSTM: x = [h_a ; context ; h_d]
         std::vector<float> wcat;
@@ -526,7 +527,7 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
 }
 
 struct DecoderBuffers {
-    float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj, *energies, *align_tm;
+    float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj, *energies, *align_tm, *loc;
     int32_t* len_copy;
 };
 
@@ -537,6 +538,7 @@ DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
     b.c_d = ws_ptr<float>(ws, wp.c_d); b.hc = ws_ptr<float>(ws, wp.hc); b.w_cum = ws_ptr<float>(ws, wp.w_cum);
     b.q_slab = ws_ptr<float>(ws, wp.q_slab); b.proj = ws_ptr<float>(ws, wp.proj); b.energies = ws_ptr<float>(ws, wp.energies);
     b.align_tm = ws_ptr<float>(ws, wp.align_tm); b.len_copy = ws_ptr<int32_t>(ws, wp.len_copy);
+    b.loc = ws_ptr<float>(ws, wp.loc);
     return b;
 }
 
@@ -590,15 +592,25 @@ void fill_dec_job(const gvx_model* m, SkinnyJob& J, int t, int B, const DecoderB
     J.h_out = hc_n;
 }
 
+// location features for step t's attention, computed inside the LSTM launch of step t from attention(t-1)'s outputs
+void fill_loc(const gvx_model* m, LocJob& q, int t, int B, int L, const float* align_base, long align_bs, long align_ts,
+              const DecoderBuffers& db) {
+    const gvx_dims& d = m->d;
+    q.w_prev = t > 0 ? align_base + (size_t)(t - 1) * align_ts : nullptr; q.w_prev_bs = align_bs;
+    q.w_cum = db.w_cum;
+    q.loc_conv_t = m->dev_blob + m->blob.loc_conv; q.loc_dense_t = m->dev_blob + m->blob.loc_dense;
+    q.loc_out = db.loc;
+    q.B = B; q.L = L; q.a = d.att_dim; q.kl = d.att_loc_kernel; q.G = attention_groups(B, L);
+}
+
 void fill_attn(const gvx_model* m, AttnParams& p, const float* memory, const int32_t* lengths, int t, int B, int L,
                float* align_out, long align_bs, long align_ts, const DecoderBuffers& db) {
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, D = d.dec_rnn_dim;
     std::memset(&p, 0, sizeof p);
     p.q_slab = db.q_slab; p.n_slabs = d.att_rnn_dim / 8;
-    p.w_prev = t > 0 ? align_out + (size_t)(t - 1) * align_ts : nullptr; p.w_prev_bs = align_bs;
     p.w_cum = db.w_cum;
-    p.loc_conv_t = m->dev_blob + m->blob.loc_conv; p.loc_dense_t = m->dev_blob + m->blob.loc_dense; p.v = m->dev_blob + m->blob.v;
+    p.loc = db.loc; p.v = m->dev_blob + m->blob.v;
     p.pm = db.pm; p.memory = memory; p.lengths = lengths;
     p.w_out = align_out + (size_t)t * align_ts; p.w_out_bs = align_bs;
     p.ctx_out = db.hc + (size_t)(t + 1) * B * (D + E) + (size_t)D * B;
@@ -659,8 +671,10 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
             SkinnyJob jobs[2];
             fill_att_job(m, jobs[0], db.prenet + (size_t)t * B * P, t, B, db);
             if (t > 0) fill_dec_job(m, jobs[1], t - 1, B, db);
+            LocJob lq;
+            fill_loc(m, lq, t, B, L, db.align_tm, (long)L, (long)B * L, db);
             HIP_TRY(mark(st));
-            HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, SK_DECODER, st));
+            HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, SK_DECODER, st, &lq));
             HIP_TRY(mark(st));
             AttnParams ap;
             fill_attn(m, ap, memory, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
@@ -687,7 +701,9 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
             if (t >= 2) HIP_TRY(hipStreamWaitEvent(sa, ev_dec[t - 2], 0));
             SkinnyJob job;
             fill_att_job(m, job, db.prenet + (size_t)t * B * P, t, B, db);
-            HIP_TRY(launch_skinny(&job, 1, SK_DECODER, sa));
+            LocJob lq;
+            fill_loc(m, lq, t, B, L, db.align_tm, (long)L, (long)B * L, db);
+            HIP_TRY(launch_skinny(&job, 1, SK_DECODER, sa, &lq));
             AttnParams ap;
             fill_attn(m, ap, memory, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
             HIP_TRY(launch_attention(ap, sa));
@@ -933,7 +949,9 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
             HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
             SkinnyJob lj;
             fill_att_job(m, lj, db.prenet, t, B, db);
-            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, s));
+            LocJob lq;
+            fill_loc(m, lq, t, B, L, align_out, (long)T * L, L, db);
+            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, s, &lq));
             AttnParams ap;
             fill_attn(m, ap, memory, lengths, t, B, L, align_out, (long)T * L, L, db);
             HIP_TRY(launch_attention(ap, s));

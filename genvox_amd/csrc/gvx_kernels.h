@@ -85,8 +85,19 @@ struct SkinnyJob {
     int act;
     int B;
 };
+// Location features of the NEXT attention step, computed by extra workgroups of the decoder LSTM launch (which is
+// memory bound and leaves VALU/LDS idle): loc[b][l][:] = Wd * conv1d_k([w_prev ; w_cum])[l].  They depend only on the
+// previous step's attention output, not on this launch's h_a, so they come off the critical chain of the step.
+struct LocJob {
+    const float* w_prev; long w_prev_bs;    // previous alignment row b at w_prev + b*bs, or nullptr (step 0)
+    const float* w_cum;                     // [B][L]
+    const float* loc_conv_t;                // [2][kl][32]
+    const float* loc_dense_t;               // [32/4][a][4]
+    float* loc_out;                         // [B][L][a]
+    int B, L, a, kl, G;                     // G position chunks per row (0 = no location job in this launch)
+};
 enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_LINEAR = 2 };  // kernel name only; same code
-hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s);
+hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // Location-sensitive attention, one decoder step, split over G workgroups per batch row:
@@ -97,10 +108,8 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
 // ---------------------------------------------------------------------------------------------
 struct AttnParams {
     const float* q_slab; int n_slabs;       // [n_slabs][B][a]
-    const float* w_prev; long w_prev_bs;    // previous alignment row b at w_prev + b*bs, or nullptr (step 0)
     float* w_cum;                           // [B][L], updated in place by the context kernel
-    const float* loc_conv_t;                // [2][kl][32] (filters innermost, zero padded to 32)
-    const float* loc_dense_t;               // [32][a]     (filters outermost, zero padded to 32)
+    const float* loc;                       // [B][L][a] location features of this step (written by the LSTM launch)
     const float* v;                         // [a]
     const float* pm;                        // [B][L][a]
     const float* memory;                    // [B][L][E]

@@ -43,8 +43,91 @@ constexpr int SK_THREADS = SK_WAVES * 64;
 struct SkinnyJobs {
     SkinnyJob job[2];
     int njobs;
-    int tiles0;  // tiles of job 0
+    int tiles0;   // tiles of job 0
+    int tiles;    // tiles of all jobs; blocks >= tiles are location-feature workgroups
+    LocJob loc;
 };
+
+constexpr int LOC_LC = 32;   // positions per pass
+constexpr int LOC_FP = 32;   // location filters (padded)
+__host__ __device__ inline int loc_chunk_len(int L, int G) { return (L + G - 1) / G; }
+__host__ __device__ inline int loc_lds_floats(int L, int G, int kl) {
+    return 2 * (loc_chunk_len(L, G) + kl - 1) + 4 + 2 * kl * LOC_FP + LOC_LC * LOC_FP;
+}
+
+// One workgroup = one (row b, chunk of positions): conv 2 -> 32 filters (k taps) then dense 32 -> a, written to
+// loc_out[b][l][:].  512 threads; the dense weights of a lane's attention dims sit in registers.
+__device__ __forceinline__ void loc_body(const LocJob& Q, int wg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = Q.L, a = Q.a, kl = Q.kl;
+    const int g = wg % Q.G, b = wg / Q.G;
+    const int Lg = loc_chunk_len(L, Q.G);
+    const int l_begin = g * Lg, l_end = min(L, l_begin + Lg);
+    if (l_begin >= l_end) return;
+    const int pad = (kl - 1) / 2, LW = Lg + kl - 1;
+    float* wc = smem;                                   // [2][LW]
+    float* cw = smem + ((2 * LW + 3) & ~3);             // [2][kl][32]
+    float* fb = cw + 2 * kl * LOC_FP;                   // [LOC_LC][32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int idx = tid; idx < 2 * LW; idx += SK_THREADS) {
+        const int ch = idx / LW, ii = idx - ch * LW, l = l_begin + ii - pad;
+        float val = 0.f;
+        if (l >= 0 && l < L) val = ch == 0 ? (Q.w_prev ? Q.w_prev[(long)b * Q.w_prev_bs + l] : 0.f) : Q.w_cum[(long)b * L + l];
+        wc[idx] = val;
+    }
+    const int cw4 = (2 * kl * LOC_FP) >> 2;
+    for (int idx = tid; idx < cw4; idx += SK_THREADS)
+        reinterpret_cast<float4*>(cw)[idx] = reinterpret_cast<const float4*>(Q.loc_conv_t)[idx];
+    __syncthreads();
+    for (int l0 = l_begin; l0 < l_end; l0 += LOC_LC) {
+        const int lc = min(LOC_LC, l_end - l0);
+        {   // conv: thread = (position, pair of filters)
+            const int ll = tid & (LOC_LC - 1), fg = tid >> 5;
+            float acc0 = 0.f, acc1 = 0.f;
+            if (ll < lc) {
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float* xrow = wc + ch * LW + (l0 - l_begin) + ll;
+                    const float* wrow = cw + (ch * kl) * LOC_FP + fg * 2;
+#pragma unroll 8
+                    for (int k = 0; k < kl; ++k) {
+                        const float x = xrow[k];
+                        const float2 w = *reinterpret_cast<const float2*>(wrow + k * LOC_FP);
+                        acc0 = fmaf(w.x, x, acc0); acc1 = fmaf(w.y, x, acc1);
+                    }
+                }
+            }
+            *reinterpret_cast<float2*>(fb + ll * LOC_FP + fg * 2) = make_float2(acc0, acc1);
+        }
+        __syncthreads();
+        // dense: wave -> positions wave, wave+8, ...; lane -> attention dims lane, lane+64, ...
+        for (int d0 = 0; d0 < a; d0 += 64) {
+            const int d = min(d0 + lane, a - 1);
+            float wd[LOC_FP];
+#pragma unroll
+            for (int c4 = 0; c4 < LOC_FP / 4; ++c4) {
+                const float4 w4 = reinterpret_cast<const float4*>(Q.loc_dense_t)[(long)c4 * a + d];
+                wd[4 * c4 + 0] = w4.x; wd[4 * c4 + 1] = w4.y; wd[4 * c4 + 2] = w4.z; wd[4 * c4 + 3] = w4.w;
+            }
+            for (int ll = wave; ll < lc; ll += SK_WAVES) {
+                const float* frow = fb + ll * LOC_FP;
+                float s = 0.f;   // one k-ordered chain: same summation order as a plain dot product over the filters
+#pragma unroll
+                for (int c4 = 0; c4 < LOC_FP / 4; ++c4) {
+                    const float4 fv = *reinterpret_cast<const float4*>(frow + 4 * c4);
+                    s = fmaf(wd[4 * c4 + 0], fv.x, s);
+                    s = fmaf(wd[4 * c4 + 1], fv.y, s);
+                    s = fmaf(wd[4 * c4 + 2], fv.z, s);
+                    s = fmaf(wd[4 * c4 + 3], fv.w, s);
+                }
+                if (d0 + lane < a) Q.loc_out[((long)b * L + l0 + ll) * a + d0 + lane] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 
 // v_exp_f32 / v_rcp_f32 forms (abs error ~1e-7): the cell update sits on the per-step critical path after the
 // workgroup barrier, where the libm expf/tanhf sequences cost ~1 us per step.
@@ -281,7 +364,10 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 
 // Same body under three kernel names so that profiles separate the decoder step (the dominant kernel of the
 // path) from the encoder recurrence and the autoregressive GEMVs.
-template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : 6)>(jobs); }
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_kernel(SkinnyJobs jobs) {
+    if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }   // uniform per workgroup
+    skinny_body<MT, (MT == 1 ? SK_DEPTH1 : 6)>(jobs);
+}
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : 6)>(jobs); }
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void skinny_linear_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : 6)>(jobs); }
 
@@ -294,33 +380,45 @@ static hipError_t set_lds(K kern, int MT) {
 
 hipError_t skinny_init() {
     hipError_t e;
-    if ((e = set_lds(decoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
-    if ((e = set_lds(decoder_lstm_step_kernel<2>, 2)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<2>, 2)) != hipSuccess) return e;
     if ((e = set_lds(skinny_linear_kernel<1>, 1)) != hipSuccess) return e;
     return set_lds(skinny_linear_kernel<2>, 2);
 }
 
-hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s) {
+hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc) {
     if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
     SkinnyJobs js;
     js.njobs = njobs;
     js.job[0] = jobs[0];
     js.job[1] = jobs[njobs - 1];
     js.tiles0 = (jobs[0].N + 31) / 32;
-    const int tiles = js.tiles0 + (njobs > 1 ? (jobs[1].N + 31) / 32 : 0);
+    js.tiles = js.tiles0 + (njobs > 1 ? (jobs[1].N + 31) / 32 : 0);
     const int B = jobs[0].B;
     if (njobs > 1 && jobs[1].B != B) return hipErrorInvalidValue;
     if (B < 1 || B > 64) return hipErrorInvalidValue;
-    const dim3 grid(tiles), block(SK_THREADS);
-    if (B > 32) {
-        const size_t lds = skinny_lds(2);
+    int extra = 0;
+    js.loc = LocJob{};
+    if (loc && loc->G > 0) {
+        if (kind != SK_DECODER) return hipErrorInvalidValue;
+        js.loc = *loc;
+        extra = loc->B * loc->G;
+    }
+    const int MT = B > 32 ? 2 : 1;
+    size_t lds = skinny_lds(MT);
+    if (extra) {
+        const size_t need = (size_t)loc_lds_floats(loc->L, loc->G, loc->kl) * sizeof(float);
+        if (need > lds) lds = need;
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+    }
+    const dim3 grid(js.tiles + extra), block(SK_THREADS);
+    if (MT == 2) {
         if (kind == SK_DECODER) decoder_lstm_step_kernel<2><<<grid, block, lds, s>>>(js);
         else if (kind == SK_ENCODER) encoder_lstm_step_kernel<2><<<grid, block, lds, s>>>(js);
         else skinny_linear_kernel<2><<<grid, block, lds, s>>>(js);
     } else {
-        const size_t lds = skinny_lds(1);
         if (kind == SK_DECODER) decoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
         else if (kind == SK_ENCODER) encoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
         else skinny_linear_kernel<1><<<grid, block, lds, s>>>(js);

@@ -177,9 +177,10 @@ int gvx_griffin_lim(gvx_gl_plan* plan, const float* mag, const float* window, in
 int gvx_wav_finalize(const float* wav, int B, long n_samples, int trim, const double* b_coef, const double* a_coef, int order,
                      double* out, unsigned int* scratch_B, void* stream);
 
-/* ---- Per-launch timing of the decoder step (measurement only): when enabled, the teacher-forced loop brackets
- * every LSTM-step launch and every attention launch with HIP events on `stream`; gvx_kernel_times_ms synchronises
- * and returns the average duration of each over the last call's T steps. */
+/* ---- Per-kernel timing of the decoder step (measurement only): when enabled, a teacher-forced call replays the
+ * mid-sequence LSTM-step launch and the attention launches 64 times each, back to back, between HIP events on
+ * `stream` (after its loop; the call's outputs are not valid afterwards); gvx_kernel_times_ms synchronises and
+ * returns the average duration of each (ms) and the number of replays. */
 int gvx_kernel_timing_enable(gvx_model* model, int enable);
 int gvx_kernel_times_ms(gvx_model* model, float* lstm_avg_ms_out, float* attn_avg_ms_out, int* n_steps_out);
 

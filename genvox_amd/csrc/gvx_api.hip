@@ -105,6 +105,7 @@ struct gvx_model {
         }
     };
     std::vector<std::pair<LoopKey, hipGraphExec_t>> loop_graphs;
+    std::vector<std::pair<LoopKey, hipGraphExec_t>> enc_graphs;   // encoder recurrence (key.memory = output, key.T = 0)
     hipStream_t cap_stream = nullptr;  // private stream used only to record captures (the caller's may be the null stream)
     hipStream_t cap_stream2 = nullptr; // second capture stream: the decoder-LSTM branch of the step graph
     std::vector<hipEvent_t> gev;       // fork/join events used while capturing (no timing)
@@ -181,6 +182,7 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.enc_c = take((size_t)2 * B * H);
     w.flags = take(64);  // [0] token error, [1] AR rows done
     w.memory = take((size_t)B * L * E);  // encoder output of the fused forward
+    w.len_copy = take((size_t)B);        // token lengths copied next to the graphs' other operands (offset independent of T)
     w.pm = take((size_t)B * L * d.att_dim);
     w.frames = take((size_t)(T + 1) * B * M);
     w.pre1 = take((size_t)(T + 1) * B * P);
@@ -194,7 +196,6 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.proj = take((size_t)B * T * m->PSB());
     w.energies = take((size_t)B * L);
     w.align_tm = take((size_t)T * B * L);   // alignments of the step loop, time-major [T][B][L]
-    w.len_copy = take((size_t)B);           // token lengths copied next to the loop's other operands
     w.loc = take((size_t)B * L * d.att_dim);  // location features of the current step
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
@@ -316,6 +317,7 @@ void gvx_model_destroy(gvx_model* m) {
         for (auto& e : m->ev) (void)hipEventDestroy(e);
     for (auto& e : m->kev) (void)hipEventDestroy(e);
     for (auto& g : m->loop_graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto& g : m->enc_graphs) (void)hipGraphExecDestroy(g.second);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     if (m->cap_stream2) (void)hipStreamDestroy(m->cap_stream2);
     for (auto& e : m->gev) (void)hipEventDestroy(e);
@@ -504,26 +506,61 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
     HIP_TRY(zero_async(enc_h, (size_t)4 * B * H * sizeof(float), s));
     HIP_TRY(zero_async(enc_c, (size_t)2 * B * H * sizeof(float), s));
     HIP_TRY(zero_async(memory_out, (size_t)B * L * E * sizeof(float), s));
-    for (int step = 0; step < L; ++step) {
-        SkinnyJob jobs[2];
-        for (int dir = 0; dir < 2; ++dir) {
-            SkinnyJob& J = jobs[dir];
-            std::memset(&J, 0, sizeof J);
-            float* h_cur = enc_h + ((size_t)dir * 2 + (step & 1)) * B * H;
-            float* h_nxt = enc_h + ((size_t)dir * 2 + ((step + 1) & 1)) * B * H;
-            J.Wp = m->dev_blob + m->blob.enc_whh_frag[dir];
-            J.x[0] = XSeg{h_cur, H};
-            J.N = 4 * H; J.nkg = H / 8; J.mode = 0; J.B = B;
-            J.c = enc_c + (size_t)dir * B * H;
-            J.h_out = h_nxt;
-            J.addend = xg + (size_t)dir * 4 * H; J.add_bs = (long)L * 8 * H; J.add_ts = 8 * H;
-            J.lengths = lengths; J.step = step; J.reverse = dir; J.seq_len = L;
-            J.seq_out = memory_out + (size_t)dir * H; J.seq_bs = (long)L * E; J.seq_ts = E;
-            J.h_prev = h_cur;
-        }
-        HIP_TRY(launch_skinny(jobs, 2, SK_ENCODER, s));
+    // the L recurrence launches only reference workspace operands (+ the output): lengths are copied next to them and
+    // the whole sequence is captured once per (workspace, output, shape) into a hipGraph and replayed
+    const int32_t* len_ws = nullptr;
+    if (lengths) {
+        int32_t* lc = ws_ptr<int32_t>(ws, wp.len_copy);
+        HIP_TRY(hipMemcpyAsync(lc, lengths, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        len_ws = lc;
     }
-    return GVX_OK;
+    auto enqueue = [&](hipStream_t st) -> int {
+        for (int step = 0; step < L; ++step) {
+            SkinnyJob jobs[2];
+            for (int dir = 0; dir < 2; ++dir) {
+                SkinnyJob& J = jobs[dir];
+                std::memset(&J, 0, sizeof J);
+                float* h_cur = enc_h + ((size_t)dir * 2 + (step & 1)) * B * H;
+                float* h_nxt = enc_h + ((size_t)dir * 2 + ((step + 1) & 1)) * B * H;
+                J.Wp = m->dev_blob + m->blob.enc_whh_frag[dir];
+                J.x[0] = XSeg{h_cur, H};
+                J.N = 4 * H; J.nkg = H / 8; J.mode = 0; J.B = B;
+                J.c = enc_c + (size_t)dir * B * H;
+                J.h_out = h_nxt;
+                J.addend = xg + (size_t)dir * 4 * H; J.add_bs = (long)L * 8 * H; J.add_ts = 8 * H;
+                J.lengths = len_ws; J.step = step; J.reverse = dir; J.seq_len = L;
+                J.seq_out = memory_out + (size_t)dir * H; J.seq_bs = (long)L * E; J.seq_ts = E;
+                J.h_prev = h_cur;
+            }
+            HIP_TRY(launch_skinny(jobs, 2, SK_ENCODER, st));
+        }
+        return GVX_OK;
+    };
+    if (m->use_graph) {
+        const gvx_model::LoopKey key{ws, memory_out, B, L, 0, lengths != nullptr};
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : m->enc_graphs)
+            if (g.first == key) exec = g.second;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue(m->cap_stream);
+            hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
+            if (rc != GVX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            HIP_TRY(ce);
+            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            HIP_TRY(hipGraphDestroy(graph));
+            if (m->enc_graphs.size() >= 8) {
+                (void)hipGraphExecDestroy(m->enc_graphs.front().second);
+                m->enc_graphs.erase(m->enc_graphs.begin());
+            }
+            m->enc_graphs.emplace_back(key, exec);
+        }
+        HIP_TRY(hipGraphLaunch(exec, s));
+        return GVX_OK;
+    }
+    return enqueue(s);
 }
 
 struct DecoderBuffers {

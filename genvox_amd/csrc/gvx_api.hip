@@ -82,7 +82,7 @@ inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 
 
 struct WsPlan {  // byte offsets into the caller's workspace
     size_t xa, xb, xg, enc_h, enc_c, flags, memory;
-    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy, loc;
+    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy, loc, ar_masks;
     size_t ya, yb;
     size_t total;
 };
@@ -100,10 +100,13 @@ struct gvx_model {
     // hipGraph cache of the teacher-forced step loop, keyed by every pointer / size the captured launches bake in
     struct LoopKey {
         const void* ws; const void* memory; int B, L, T; bool has_len;
+        int chunk = -1; float threshold = 0.f;   // autoregressive chunk graphs only
         bool operator==(const LoopKey& o) const {
-            return ws == o.ws && memory == o.memory && B == o.B && L == o.L && T == o.T && has_len == o.has_len;
+            return ws == o.ws && memory == o.memory && B == o.B && L == o.L && T == o.T && has_len == o.has_len &&
+                   chunk == o.chunk && threshold == o.threshold;
         }
     };
+    std::vector<std::pair<LoopKey, hipGraphExec_t>> ar_graphs;    // one graph per 16-step chunk of the autoregressive loop
     std::vector<std::pair<LoopKey, hipGraphExec_t>> loop_graphs;
     std::vector<std::pair<LoopKey, hipGraphExec_t>> enc_graphs;   // encoder recurrence (key.memory = output, key.T = 0)
     hipStream_t cap_stream = nullptr;  // private stream used only to record captures (the caller's may be the null stream)
@@ -180,7 +183,7 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.xg = take((size_t)B * L * 8 * H);
     w.enc_h = take((size_t)2 * 2 * B * H);
     w.enc_c = take((size_t)2 * B * H);
-    w.flags = take(64);  // [0] token error, [1] AR rows done
+    w.flags = take(128);  // [0] token error, [1] AR rows done, [64..64+B) AR frame counts
     w.memory = take((size_t)B * L * E);  // encoder output of the fused forward
     w.len_copy = take((size_t)B);        // token lengths copied next to the graphs' other operands (offset independent of T)
     w.pm = take((size_t)B * L * d.att_dim);
@@ -197,6 +200,7 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.energies = take((size_t)B * L);
     w.align_tm = take((size_t)T * B * L);   // alignments of the step loop, time-major [T][B][L]
     w.loc = take((size_t)B * L * d.att_dim);  // location features of the current step
+    w.ar_masks = take(((size_t)2 * T * B * P + 3) / 4);  // autoregressive mode: keep masks copied next to the graphs' operands (bytes)
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
     w.yb = take((size_t)B * (T + 2 * pp) * cmax);
@@ -290,6 +294,33 @@ int pack_lstm(const WeightTable& wt, const std::string& wih_name, const std::str
 
 hipError_t zero_async(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); }
 
+// Replay the launches `enqueue(stream)` issues from a hipGraph cached under `key` (captured on the model's private
+// stream the first time; the caller's stream may be the null stream, which cannot be captured).
+template <class Cache, class Key, class F>
+int run_cached_graph(gvx_model* m, Cache& cache, const Key& key, size_t max_entries, hipStream_t s, F&& enqueue) {
+    hipGraphExec_t exec = nullptr;
+    for (auto& g : cache)
+        if (g.first == key) exec = g.second;
+    if (!exec) {
+        hipGraph_t graph = nullptr;
+        if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue(m->cap_stream);
+        const hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
+        if (rc != GVX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        HIP_TRY(ce);
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_TRY(hipGraphDestroy(graph));
+        if (cache.size() >= max_entries) {
+            (void)hipGraphExecDestroy(cache.front().second);
+            cache.erase(cache.begin());
+        }
+        cache.emplace_back(key, exec);
+    }
+    HIP_TRY(hipGraphLaunch(exec, s));
+    return GVX_OK;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -318,6 +349,7 @@ void gvx_model_destroy(gvx_model* m) {
     for (auto& e : m->kev) (void)hipEventDestroy(e);
     for (auto& g : m->loop_graphs) (void)hipGraphExecDestroy(g.second);
     for (auto& g : m->enc_graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto& g : m->ar_graphs) (void)hipGraphExecDestroy(g.second);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     if (m->cap_stream2) (void)hipStreamDestroy(m->cap_stream2);
     for (auto& e : m->gev) (void)hipEventDestroy(e);
@@ -538,27 +570,7 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
     };
     if (m->use_graph) {
         const gvx_model::LoopKey key{ws, memory_out, B, L, 0, lengths != nullptr};
-        hipGraphExec_t exec = nullptr;
-        for (auto& g : m->enc_graphs)
-            if (g.first == key) exec = g.second;
-        if (!exec) {
-            hipGraph_t graph = nullptr;
-            if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
-            HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue(m->cap_stream);
-            hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
-            if (rc != GVX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            HIP_TRY(ce);
-            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            HIP_TRY(hipGraphDestroy(graph));
-            if (m->enc_graphs.size() >= 8) {
-                (void)hipGraphExecDestroy(m->enc_graphs.front().second);
-                m->enc_graphs.erase(m->enc_graphs.begin());
-            }
-            m->enc_graphs.emplace_back(key, exec);
-        }
-        HIP_TRY(hipGraphLaunch(exec, s));
-        return GVX_OK;
+        return run_cached_graph(m, m->enc_graphs, key, 8, s, enqueue);
     }
     return enqueue(s);
 }
@@ -751,33 +763,14 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     };
     if (m->use_graph && !kt) {
         const gvx_model::LoopKey key{ws, memory, B, L, T, lengths != nullptr};
-        hipGraphExec_t exec = nullptr;
-        for (auto& g : m->loop_graphs)
-            if (g.first == key) exec = g.second;
-        if (!exec) {
-            hipGraph_t graph = nullptr;
-            if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
-            HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
-            if (m->fork_dec) {
-                if (!m->cap_stream2) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream2, hipStreamNonBlocking));
-                rc = enqueue_forked(m->cap_stream, m->cap_stream2);
-            } else {
-                rc = enqueue_loop(m->cap_stream);
-            }
-            hipError_t ce = hipStreamEndCapture(m->cap_stream, &graph);
-            if (rc != GVX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            HIP_TRY(ce);
-            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            HIP_TRY(hipGraphDestroy(graph));
-            if (m->loop_graphs.size() >= 8) {  // bounded cache
-                (void)hipGraphExecDestroy(m->loop_graphs.front().second);
-                m->loop_graphs.erase(m->loop_graphs.begin());
-            }
-            m->loop_graphs.emplace_back(key, exec);
+        if (m->fork_dec) {
+            if (!m->cap_stream2) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream2, hipStreamNonBlocking));
+            rc = run_cached_graph(m, m->loop_graphs, key, 8, s, [&](hipStream_t st) { return enqueue_forked(st, m->cap_stream2); });
         } else {
-            launches = m->fork_dec ? 4 * T : 3 * T + 1;
+            rc = run_cached_graph(m, m->loop_graphs, key, 8, s, enqueue_loop);
         }
-        HIP_TRY(hipGraphLaunch(exec, s));
+        if (rc != GVX_OK) return rc;
+        launches = m->fork_dec ? 4 * T : 3 * T + 1;
     } else {
         rc = enqueue_loop(s);
         if (rc != GVX_OK) return rc;
@@ -967,60 +960,87 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     const int PSB = m->PSB();
     int32_t* flags = ws_ptr<int32_t>(ws, wp.flags);
     int32_t* n_done = flags + 1;
-    // db.proj holds one blocked projection vector [PSB/8][B][8] per step; db.frames: one zero go-frame
-    rc = decoder_init_states(m, memory, B, L, db, s);
+    int32_t* n_frames_ws = flags + 64;
+    // Everything a step touches is moved next to the workspace so that the step launches only bake workspace addresses:
+    // encoder output, token lengths and keep masks are copied in; alignments / per-step projections stay in workspace
+    // buffers and are scattered to the caller's tensors once, after the loop.
+    float* memory_ws = ws_ptr<float>(ws, wp.memory);
+    if (memory != memory_ws)
+        HIP_TRY(hipMemcpyAsync(memory_ws, memory, (size_t)B * L * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    uint8_t* masks_ws = ws_ptr<uint8_t>(ws, wp.ar_masks);
+    HIP_TRY(hipMemcpyAsync(masks_ws, keep_masks, (size_t)2 * T * B * P, hipMemcpyDeviceToDevice, s));
+    const int32_t* len_ws = nullptr;
+    if (lengths) {
+        HIP_TRY(hipMemcpyAsync(db.len_copy, lengths, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        len_ws = db.len_copy;
+    }
+    rc = decoder_init_states(m, memory_ws, B, L, db, s);
     if (rc != GVX_OK) return rc;
-    HIP_TRY(zero_async(db.frames, (size_t)B * M * sizeof(float), s));
-    HIP_TRY(zero_async(n_done, sizeof(int32_t), s));
-    HIP_TRY(zero_async(n_frames_out, (size_t)B * sizeof(int32_t), s));
-    const int CHUNK = 16;  // steps between host checks of the all-rows-finished counter
-    int t = 0;
-    int32_t done_host = 0;
-    while (t < T) {
-        const int t_end = t + CHUNK < T ? t + CHUNK : T;
-        for (; t < t_end; ++t) {
+    HIP_TRY(zero_async(db.frames, (size_t)B * M * sizeof(float), s));   // go-frame
+    HIP_TRY(zero_async(flags + 1, (size_t)127 * sizeof(int32_t), s));   // n_done + frame counts
+
+    // one step = Prenet (2 GEMVs) -> attention LSTM (+ location features) -> attention energy / context -> decoder LSTM
+    // -> mel/gate projection -> per-row stop test; db.proj holds one blocked projection vector [PSB/8][B][8] per step
+    auto enqueue_steps = [&](hipStream_t st, int t0, int t1) -> int {
+        for (int t = t0; t < t1; ++t) {
             float* proj_t = db.proj + (size_t)t * B * PSB;
-            // Prenet on the previous mel frame (Decoder.inference, models/tts/tacotron2.py:398)
             SkinnyJob job;
             std::memset(&job, 0, sizeof job);
-            job.Wp = m->dev_blob + m->blob.pre_w0_frag;
+            job.Wp = m->dev_blob + m->blob.pre_w0_frag;   // Prenet on the previous mel frame (tacotron2.py:398)
             job.x[0] = XSeg{t == 0 ? db.frames : db.proj + (size_t)(t - 1) * B * PSB, M};
             job.N = P; job.nkg = M / 8; job.mode = 1; job.B = B; job.act = ACT_RELU;
             job.y = db.pre1;
-            job.keep = keep_masks + (size_t)t * B * P; job.keep_stride = P;
-            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
+            job.keep = masks_ws + (size_t)t * B * P; job.keep_stride = P;
+            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, st));
             job.Wp = m->dev_blob + m->blob.pre_w1_frag;
             job.x[0] = XSeg{db.pre1, P};
             job.nkg = P / 8;
             job.y = db.prenet;
-            job.keep = keep_masks + ((size_t)T + t) * B * P;
-            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
+            job.keep = masks_ws + ((size_t)T + t) * B * P;
+            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, st));
             SkinnyJob lj;
             fill_att_job(m, lj, db.prenet, t, B, db);
             LocJob lq;
-            fill_loc(m, lq, t, B, L, align_out, (long)T * L, L, db);
-            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, s, &lq));
+            fill_loc(m, lq, t, B, L, db.align_tm, (long)L, (long)B * L, db);
+            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, st, &lq));
             AttnParams ap;
-            fill_attn(m, ap, memory, lengths, t, B, L, align_out, (long)T * L, L, db);
-            HIP_TRY(launch_attention(ap, s));
+            fill_attn(m, ap, memory_ws, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
+            HIP_TRY(launch_attention(ap, st));
             fill_dec_job(m, lj, t, B, db);
-            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, s));
-            // mel + gate projection of this step
+            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, st));
             std::memset(&job, 0, sizeof job);
             job.Wp = m->dev_blob + m->blob.proj_frag; job.bias = m->dev_blob + m->blob.proj_b;
             job.x[0] = XSeg{db.hc + (size_t)(t + 1) * B * (D + E), D + E};
             job.N = M + 1; job.nkg = (D + E) / 8; job.mode = 1; job.B = B; job.act = ACT_NONE;
             job.y = proj_t;
-            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, s));
-            HIP_TRY(launch_ar_emit(proj_t, mel_out, gate_out, B, M, T, t, s));
-            HIP_TRY(launch_ar_stop(proj_t, M, gate_threshold, t, B, n_frames_out, n_done, s));
+            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, st));
+            HIP_TRY(launch_ar_stop(proj_t, M, gate_threshold, t, B, n_frames_ws, n_done, st));
         }
+        return GVX_OK;
+    };
+    const int CHUNK = 16;  // steps per graph = steps between host checks of the all-rows-finished counter
+    int t = 0;
+    int32_t done_host = 0;
+    while (t < T) {
+        const int t_end = t + CHUNK < T ? t + CHUNK : T;
+        if (m->use_graph) {
+            gvx_model::LoopKey key{ws, memory_ws, B, L, T, lengths != nullptr};
+            key.chunk = t / CHUNK; key.threshold = gate_threshold;
+            rc = run_cached_graph(m, m->ar_graphs, key, 1024, s, [&](hipStream_t st) { return enqueue_steps(st, t, t_end); });
+        } else {
+            rc = enqueue_steps(s, t, t_end);
+        }
+        if (rc != GVX_OK) return rc;
+        t = t_end;
         HIP_TRY(hipMemcpyAsync(&done_host, n_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (done_host >= B) break;
     }
     // rows that never fired ran into the cap ("Warning! Reached max decoder steps", models/tts/tacotron2.py:407-409)
-    HIP_TRY(launch_ar_stop(db.proj, M, -1.f, t - 1, B, n_frames_out, n_done, s));
+    HIP_TRY(launch_ar_stop(db.proj, M, -1.f, t - 1, B, n_frames_ws, n_done, s));
+    HIP_TRY(hipMemcpyAsync(n_frames_out, n_frames_ws, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_ar_emit_all(db.proj, mel_out, gate_out, B, M, T, t, s));
+    HIP_TRY(launch_permute01_partial(db.align_tm, align_out, t, T, B, L, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (steps_run_out) *steps_run_out = t;
     return GVX_OK;

@@ -147,8 +147,9 @@ hipError_t launch_mask_gen(uint8_t* out, size_t n, uint64_t seed, hipStream_t s)
 // AR: gate logits of step t (blocked projection vector) -> per-row finished flags / frame counts / all-finished counter
 hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, int t, int B,
                           int32_t* n_frames, int32_t* n_done, hipStream_t s);
-// AR: scatter the blocked step-t projection into mel_out [B][M][Tmax], gate_out [B][Tmax]
-hipError_t launch_ar_emit(const float* proj_t, float* mel_out, float* gate_out, int B, int M, int Tmax, int t,
-                          hipStream_t s);
+// AR: scatter the blocked per-step projections proj[t][PSB/8][B][8], t < steps, into mel_out [B][M][Tmax], gate_out [B][Tmax]
+hipError_t launch_ar_emit_all(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, hipStream_t s);
+// dst[b][t][:] = src[t][b][:] for t < steps, dst rows have Tdst time slots
+hipError_t launch_permute01_partial(const float* src, float* dst, int steps, int Tdst, int B, int n, hipStream_t s);
 
 }  // namespace gvx

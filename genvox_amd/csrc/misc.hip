@@ -214,17 +214,41 @@ hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, in
     return hipGetLastError();
 }
 
-__global__ void ar_emit_kernel(const float* proj_t, float* mel_out, float* gate_out, int B, int M, int Tmax, int t) {
-    const int b = blockIdx.x;
-    for (int m = threadIdx.x; m <= M; m += blockDim.x) {
-        const float v = proj_t[(long)(m >> 3) * B * 8 + b * 8 + (m & 7)];
-        if (m < M) mel_out[((long)b * M + m) * Tmax + t] = v;
-        else gate_out[(long)b * Tmax + t] = v;
+__global__ void ar_emit_all_kernel(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, int PSB) {
+    // thread = (b, m); loops over time so that writes along t are contiguous per thread row
+    const int b = blockIdx.y;
+    for (int m = blockIdx.x * blockDim.y + threadIdx.y; m <= M; m += gridDim.x * blockDim.y) {
+        const long src = (long)(m >> 3) * B * 8 + b * 8 + (m & 7);
+        for (int t = threadIdx.x; t < steps; t += blockDim.x) {
+            const float v = proj[(long)t * B * PSB + src];
+            if (m < M) mel_out[((long)b * M + m) * Tmax + t] = v;
+            else gate_out[(long)b * Tmax + t] = v;
+        }
     }
 }
 
-hipError_t launch_ar_emit(const float* proj_t, float* mel_out, float* gate_out, int B, int M, int Tmax, int t, hipStream_t s) {
-    hipLaunchKernelGGL(ar_emit_kernel, dim3(B), dim3(128), 0, s, proj_t, mel_out, gate_out, B, M, Tmax, t);
+hipError_t launch_ar_emit_all(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, hipStream_t s) {
+    if (steps <= 0) return hipSuccess;
+    const int PSB = (M + 1 + 7) & ~7;
+    hipLaunchKernelGGL(ar_emit_all_kernel, dim3((M + 1 + 3) / 4, B), dim3(64, 4), 0, s, proj, mel_out, gate_out, B, M, Tmax, steps, PSB);
+    return hipGetLastError();
+}
+
+__global__ void permute01_partial_kernel(const float* src, float* dst, int steps, int Tdst, int B, int n) {
+    const long rows = (long)steps * B;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int t = (int)(r / B), b = (int)(r - (long)t * B);
+        const float* sp = src + r * n;
+        float* dp = dst + ((long)b * Tdst + t) * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) dp[i] = sp[i];
+    }
+}
+
+hipError_t launch_permute01_partial(const float* src, float* dst, int steps, int Tdst, int B, int n, hipStream_t s) {
+    const long rows = (long)steps * B;
+    if (rows <= 0) return hipSuccess;
+    const int grid = (int)(rows < 4096 ? rows : 4096);
+    hipLaunchKernelGGL(permute01_partial_kernel, dim3(grid), dim3(128), 0, s, src, dst, steps, Tdst, B, n);
     return hipGetLastError();
 }
 

@@ -68,9 +68,10 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ   # launched by torch.distributed.run (any N, also N = 1)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     from genvox_amd import weights as gw
     from genvox_amd.configs import AudioConfig, Tacotron2Config, TextConfig
@@ -91,7 +92,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -105,9 +106,9 @@ def main():
         out = model.forward(batch)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the slowest rank defines the job's time
         elapsed = float(t.item())
     assert torch.isfinite(out["mel_outputs_postnet"]).all()
     log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
@@ -186,7 +187,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -22,7 +22,7 @@ def _world() -> Tuple[int, int]:
 def broadcast_packed_weights(model, src: int = 0) -> None:
     """Make every rank's model use rank ``src``'s weights: src packs, one broadcast, the others bind the blob."""
     rank, world = _world()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         model._ensure_packed()
         return
     import ctypes as C

@@ -1,0 +1,56 @@
+"""GPU: the drop-in surface end to end - config.yaml + checkpoint .pt in the reference's formats -> Synthesizer.tts -> waveform;
+the collate mirror feeding Tacotron2.forward."""
+import numpy as np
+import pytest
+import torch
+
+from genvox_amd import weights as gw
+from genvox_amd.collate import TextMelCollateFn
+from genvox_amd.configs import AudioConfig, BaseConfig, Tacotron2Config, TextConfig
+from genvox_amd.synthesizer import Synthesizer
+from genvox_amd.tacotron2 import Tacotron2
+from genvox_amd.text import TextProcessor
+
+pytestmark = pytest.mark.gpu
+
+
+def test_synthesizer_from_reference_style_checkpoint(tmp_path):
+    text = "Dr. Smith paid $3.50 on the 21st, in 1999."
+    tcfg = TextConfig(cleaners=["base_cleaners"])
+    tp = TextProcessor(tcfg)
+    tp.tokenize(text + " abcdefghijklmnopqrstuvwxyz")
+    tp.generate_token_map()
+    mc = Tacotron2Config(max_decoder_steps=40, gate_threshold=1.0)
+    ac = AudioConfig(filter_length=1024, hop_length=256, log_func="np.log")
+    cfg, ckpt = str(tmp_path / "config.yaml"), str(tmp_path / "checkpoint_1.pt")
+    BaseConfig.write_configs_to_file(cfg, {"model_config": mc, "audio_config": ac, "text_config": tcfg, "trainer_config": None})
+    sd = gw.generate_state_dict(mc, ac, tcfg, seed=4)
+    torch.save({"model_statedict": sd, "iteration": 1}, ckpt)   # the reference's checkpoint dict (tacotron2.py:574-579)
+    syn = Synthesizer(tts_model_class=Tacotron2, tts_config_path=cfg, tts_checkpoint_path=ckpt, use_cuda=True)
+    out = syn.tts(text)
+    T = 40
+    assert set(out) == {"mel_outputs", "mel_outputs_postnet", "gate_outputs", "alignments", "waveform", "sampling_rate"}
+    assert out["mel_outputs_postnet"].shape == (80, T) and out["gate_outputs"].shape == (T,)
+    assert out["alignments"].shape[0] == T and out["sampling_rate"] == 22050
+    assert out["waveform"].dtype == np.float64 and out["waveform"].shape == (1024 + (T - 1) * 256 - 1000,)
+    assert np.isfinite(out["waveform"]).all() and np.abs(out["waveform"]).max() > 0
+    # same seed -> same Prenet masks -> identical mels (the masks are drawn from a seed taken from torch's RNG)
+    torch.manual_seed(7)
+    a = syn.tts(text)["mel_outputs_postnet"]
+    torch.manual_seed(7)
+    b = syn.tts(text)["mel_outputs_postnet"]
+    assert np.array_equal(a, b)
+
+
+def test_collate_feeds_forward():
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=30)
+    m = Tacotron2(mc, ac, tc).to("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    items = [{"tokens": torch.randint(0, 30, (n,), generator=g, dtype=torch.int32), "features": torch.randn(80, t, generator=g)}
+             for n, t in ((9, 14), (21, 30), (15, 22))]
+    batch = TextMelCollateFn()(items)
+    assert batch["token_lengths"].tolist() == [21, 15, 9] and batch["mel_lengths"].tolist() == [30, 22, 14]
+    assert batch["gate_padded"][2, 13] == 1 and batch["gate_padded"][2, 12] == 0
+    out = m.forward(m.prepare_batch(batch, "cuda:0"))
+    assert out["mel_outputs_postnet"].shape == (3, 80, 30) and torch.isfinite(out["mel_outputs_postnet"]).all()
+    assert torch.all(out["gate_outputs"][2, 14:] == 1e3)

@@ -174,6 +174,33 @@ class AudioProcessor:
         _lib.check(lib.gvx_wav_finalize(y.data_ptr(), B, n, self.TRIM, b, a, nb - 1, out.data_ptr(), scratch.data_ptr(), self._stream()))
         return out
 
+    def wav_to_mel(self, signal: torch.Tensor) -> torch.Tensor:
+        """[B, n] normalised float32 signals -> mel (dB) [B, n_mels, T] (reference convert_wav2mel chain, per row)."""
+        lib = self._ensure()
+        x = signal.to(self.device, torch.float32).contiguous()
+        B, n = x.shape
+        c = self.config
+        T = (n - c.filter_length) // c.hop_length + 1
+        if len(self._dev_consts) < 3:
+            self._dev_consts = self._dev_consts + (torch.from_numpy(np.ascontiguousarray(self.mel_basis)).to(self.device),)
+        out = torch.empty(B, c.n_mels, T, device=self.device)
+        ws = self._workspace(B, T)
+        _lib.check(lib.gvx_wav_to_mel(self._plan, x.data_ptr(), self._dev_consts[0].data_ptr(), self._dev_consts[2].data_ptr(), B, n,
+                                      c.n_mels, 0 if c.log_func == "np.log" else 1, float(c.ref_level_db), out.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), self._stream()))
+        return out
+
+    def convert_wav2mel(self, input_path: str, output_path: str) -> None:
+        """Reference signature (core/processors.py:70-79): read a wav file, write the mel (dB) as .npy."""
+        import scipy.io.wavfile
+
+        fs, sig = scipy.io.wavfile.read(input_path)
+        assert fs == self.config.sampling_rate, f"wav file ({input_path}) sampling rate ({fs}) does not match with config ({self.config.sampling_rate})"
+        if self.config.normalize:
+            sig = (sig / max(np.abs(np.min(sig)), np.abs(np.max(sig)))).astype(np.float32)   # utils/audio/base.py:20-22
+        mel = self.wav_to_mel(torch.from_numpy(np.ascontiguousarray(sig, dtype=np.float32))[None])
+        np.save(output_path, mel[0].cpu().numpy())
+
     # ------------------------------------------------------------------ reference surface
     def convert_mel2wav_batch(self, mels: torch.Tensor, n_iter: int = 32) -> torch.Tensor:
         """[B, n_mels, T] mel (dB) -> float64 waveforms [B, n_fft + (T-1)*hop - 1000] on the device."""

@@ -246,6 +246,48 @@ __global__ void gl_final_kernel(const float2* ang, const float* mag, float2* spe
     }
 }
 
+// |spec| of a frame-major complex spectrum into rows padded to kp floats (kp % 4 == 0, pad = 0) for the GEMM
+__global__ void magnitude_kernel(const float2* spec_t, float* mag, int bins, int kp, long frames) {
+    const long total = frames * kp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long fr = i / kp;
+        const int k = (int)(i - fr * kp);
+        float v = 0.f;
+        if (k < bins) { const float2 z = spec_t[fr * bins + k]; v = hypotf(z.x, z.y); }
+        mag[i] = v;
+    }
+}
+
+// basis [n_mels][bins] -> padded [n_mels][kp]
+__global__ void pad_rows_kernel(const float* src, float* dst, int rows, int cols, int kp) {
+    const int total = rows * kp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / kp, c = i - r * kp;
+        dst[i] = c < cols ? src[r * cols + c] : 0.f;
+    }
+}
+
+// mel_db[b][m][t] = log(max(amin, mel_t[(b,t)][m])) - log(max(amin, ref))      (utils/audio/base.py:24-36, power=False, scale=1)
+__global__ void amp_to_db_transpose_kernel(const float* mel_t, float* mel_db, int M, int T, int log10_kind, float log_ref) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.y * 32, m0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, m = m0 + tx;
+        float v = 0.f;
+        if (t < T && m < M) {
+            const float a = fmaxf(1e-5f, mel_t[((long)b * T + t) * M + m]);
+            v = (log10_kind ? log10f(a) : logf(a)) - log_ref;
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, t = t0 + tx;
+        if (t < T && m < M) mel_db[((long)b * M + m) * T + t] = tile[tx][r];
+    }
+}
+
 // clip spurious samples, trim, peak, normalise to float32, IIR low-pass in float64 (core/processors.py:91-95,
 // utils/audio/base.py:20-22, :164-169; scipy.signal.lfilter = direct form II transposed)
 __global__ void wav_peak_kernel(const float* y, long n, int trim, unsigned int* peak_bits) {
@@ -495,6 +537,48 @@ int gvx_wav_finalize(const float* wav, int B, long n_samples, int trim, const do
     wav_peak_kernel<<<dim3(64, B), 256, 0, s>>>(wav, n_samples, trim, scratch_B);
     GL_HIP(hipGetLastError());
     wav_filter_kernel<<<(B + 63) / 64, 64, 0, s>>>(wav, n_samples, trim, scratch_B, c, out, B);
+    GL_HIP(hipGetLastError());
+    return GVX_OK;
+}
+
+int gvx_wav_to_mel(gvx_gl_plan* p, const float* signal, const float* window, const float* mel_basis, int B, long n_samples, int n_mels,
+                   int log10_kind, float ref, float* mel_db_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !signal || !window || !mel_basis || !mel_db_out) return gl_fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (n_samples < p->n_fft) return gl_fail(GVX_ERR_INVALID_ARG, "signal shorter than one frame");
+    const int T = (int)((n_samples - p->n_fft) / p->hop + 1);
+    FftPair* fp = nullptr;
+    int rc = get_plans(p, (long)B * T, &fp);
+    if (rc != GVX_OK) return rc;
+    const GlWs w = gl_plan_ws(p, B, T, n_mels, fp->work_bytes);
+    rc = check_gl(p, B, T, ws, ws_bytes, w.total);
+    if (rc != GVX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long frames = (long)B * T;
+    const int kp = (p->bins + 3) & ~3;                     // GEMM K must be a multiple of 4: 513 -> 516, zero padded
+    // workspace reuse: fr = framed signal, reb0 = spectrum, ang = padded magnitudes, reb1 = padded basis, amp = mel amplitudes
+    if ((size_t)frames * kp * sizeof(float) > (size_t)frames * p->bins * sizeof(float2) || (size_t)n_mels * kp > (size_t)frames * p->bins * 2)
+        return gl_fail(GVX_ERR_WORKSPACE, "workspace regions too small for the padded operands");
+    gl_frame_kernel<<<dim3((unsigned)frames), 256, 0, s>>>(signal, window, wsp<float>(ws, w.fr), p->n_fft, p->hop, T, n_samples);
+    GL_HIP(hipGetLastError());
+    rc = run_fft(p, fp->r2c, wsp<float>(ws, w.fr), wsp<float2>(ws, w.reb0), wsp<char>(ws, w.fft_work), fp->work_bytes, s);
+    if (rc != GVX_OK) return rc;
+    float* mag_p = wsp<float>(ws, w.ang);
+    float* basis_p = wsp<float>(ws, w.reb1);
+    magnitude_kernel<<<blocks_for(frames * kp), 256, 0, s>>>(wsp<float2>(ws, w.reb0), mag_p, p->bins, kp, frames);
+    GL_HIP(hipGetLastError());
+    pad_rows_kernel<<<blocks_for((long)n_mels * kp), 256, 0, s>>>(mel_basis, basis_p, n_mels, p->bins, kp);
+    GL_HIP(hipGetLastError());
+    // fft2mel (utils/audio/base.py:139-141): mel_t[(b,t)][m] = sum_k basis[m][k] * |S|[(b,t)][k]
+    gvx::GemmParams g{};
+    g.A = mag_p; g.amap = gvx::RowMap{(int)frames, 0, (long)kp};
+    g.W = basis_p; g.ldw = kp;
+    g.C = wsp<float>(ws, w.amp); g.cmap = gvx::RowMap{(int)frames, 0, (long)n_mels};
+    g.M = (int)frames; g.N = n_mels; g.K = kp; g.act = gvx::ACT_NONE;
+    GL_HIP(gvx::launch_gemm(g, s));
+    const float refc = ref > 1e-5f ? ref : 1e-5f;
+    const float log_ref = log10_kind ? log10f(refc) : logf(refc);
+    amp_to_db_transpose_kernel<<<dim3((n_mels + 31) / 32, (T + 31) / 32, B), dim3(32, 8), 0, s>>>(wsp<float>(ws, w.amp), mel_db_out, n_mels, T,
+                                                                                                 log10_kind, log_ref);
     GL_HIP(hipGetLastError());
     return GVX_OK;
 }

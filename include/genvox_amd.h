@@ -171,6 +171,11 @@ int gvx_mel_to_magnitude(gvx_gl_plan* plan, const float* mel_db, const float* in
  * mag [B][bins][T]; phase_out [B][bins][T] or NULL; wav_out [B][n_fft + (T-1)*hop] or NULL. */
 int gvx_griffin_lim(gvx_gl_plan* plan, const float* mag, const float* window, int B, int T, int n_iter, float momentum,
                     float* phase_out, float* wav_out, void* workspace, size_t workspace_bytes, void* stream);
+/* wav -> mel features (AudioProcessor.convert_wav2mel, core/processors.py:70-79: stft, |.|, fft2mel, amplitude_to_db with
+ * power=False/scale=1; utils/audio/base.py:24-36, :58-69, :139-141).  signal [B][n_samples] (already normalised),
+ * mel_basis [n_mels][bins] -> mel_db_out [B][n_mels][T], T = (n_samples - n_fft)/hop + 1. */
+int gvx_wav_to_mel(gvx_gl_plan* plan, const float* signal, const float* window, const float* mel_basis, int B, long n_samples,
+                   int n_mels, int log10_kind, float ref, float* mel_db_out, void* workspace, size_t workspace_bytes, void* stream);
 /* tail of convert_mel2wav (core/processors.py:91-95): samples with |y| > 1 -> 0, drop `trim` samples at both ends,
  * divide by the peak (float32), IIR filter b/a (HOST doubles, order+1 each; scipy.signal.lfilter semantics, float64).
  * out: float64 [B][n_samples - 2*trim]; scratch_B: B uint32 of device scratch. */

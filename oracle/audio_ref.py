@@ -101,6 +101,20 @@ def db_to_amplitude(db: np.ndarray, log_func: str = "np.log10", ref: float = 1.0
     return np.power(10, x)
 
 
+def amplitude_to_db(mag: np.ndarray, log_func: str = "np.log10", ref: float = 1.0, amin: float = 1e-5) -> np.ndarray:
+    """base.py:24-36 with power=False, scale=1 (how core/processors.py:77 calls it)."""
+    lf = np.log if log_func == "np.log" else np.log10
+    db = lf(np.maximum(amin, np.abs(mag)))
+    db -= lf(np.maximum(amin, ref))
+    return db * 1.0
+
+
+def wav_to_mel(signal: np.ndarray, mel_basis: np.ndarray, n_fft: int, hop: int, log_func: str, ref: float) -> np.ndarray:
+    """AudioProcessor.convert_wav2mel without the file I/O (core/processors.py:70-79): stft -> |.| -> fft2mel (base.py:139-141) -> dB."""
+    spec = stft(signal, n_fft, hop)
+    return amplitude_to_db(np.matmul(mel_basis, np.abs(spec)), log_func=log_func, ref=ref)
+
+
 def griffin_lim(mag: np.ndarray, n_fft: int, hop: int, momentum: float = 0.99, n_iter: int = 32,
                 return_complex: bool = False) -> np.ndarray:
     """Fast Griffin-Lim (base.py:147-162): magnitude [bins, frames] -> phase [bins, frames].

@@ -123,3 +123,14 @@ def test_batched_rows_equal_single_rows(ap):
     for i in range(3):
         alone = ap.convert_mel2wav_batch(batch[i:i + 1], n_iter=8)
         assert torch.equal(together[i], alone[0])
+
+
+def test_wav_to_mel_matches_reference(ap):
+    """feature extraction on the device (stft -> |.| -> mel filterbank -> dB)."""
+    fx = load_fixture("audio")
+    sig = torch.from_numpy(fx["signal"])
+    mel = ap.wav_to_mel(torch.stack([sig, 0.25 * sig])).cpu().numpy()
+    assert mel.shape == (2,) + fx["mel_db"].shape
+    assert np.abs(mel[0] - fx["mel_db"]).max() <= 1e-4          # dB values are O(1..10); fp32 log of an fp32 GEMM
+    want = audio_ref.wav_to_mel(0.25 * fx["signal"], fx["mel_basis"], AUDIO_CASE["n_fft"], AUDIO_CASE["hop"], AUDIO_CASE["log_func"], AUDIO_CASE["ref"])
+    assert np.abs(mel[1] - want).max() <= 1e-4

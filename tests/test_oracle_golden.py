@@ -60,6 +60,8 @@ def test_audio_oracle_matches_reference():
     assert spec.dtype == np.complex64
     assert np.array_equal(spec.real, fx["stft_real"]) and np.array_equal(spec.imag, fx["stft_imag"])
     assert np.array_equal(audio_ref.istft(spec, n_fft, hop), fx["istft"])
+    mel_db = audio_ref.wav_to_mel(fx["signal"], fx["mel_basis"], n_fft, hop, c["log_func"], c["ref"])
+    assert mel_db.dtype == np.float32 and max_abs_diff(mel_db, fx["mel_db"]) <= 1e-6
     mag = np.matmul(fx["inverse_mel_basis"], audio_ref.db_to_amplitude(fx["mel_db"], c["log_func"], c["ref"]))
     assert max_abs_diff(mag, fx["mag"]) <= 1e-6
     for k in (1, 2, 32):

@@ -28,8 +28,14 @@ namespace gvx {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// Prefetch depth (k-groups in flight per wave): swept on the MI355X in interleaved A/B runs - 4 (one batch tile) and
+// 3 (two batch tiles) beat 8 / 6 by 6-8 %: the per-wave K slices (28 / 40 k-groups) then stay in the branch-free
+// steady-state loop almost to the end, and 8 waves x 3 KiB per CU already cover the loaded-memory latency.
 #ifndef SK_DEPTH1
-#define SK_DEPTH1 8
+#define SK_DEPTH1 4
+#endif
+#ifndef SK_DEPTH2
+#define SK_DEPTH2 3
 #endif
 #ifndef SK_SPLIT_OLD
 #define SK_SPLIT_OLD 32   // 32/64 = even split
@@ -250,13 +256,23 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // drain: at most two passes
-        for (; base < kg_end; base += DEPTH) {
+        // drain.  The slots hold the next min(remaining, DEPTH) groups and remaining < 2*DEPTH.  Only when more than
+        // DEPTH groups are left is there anything to refill: that pass is branch free (every slot valid, refills are
+        // clamped loads; the few surplus ones re-read the last group and are never consumed).  The final pass issues
+        // no loads and only guards the MFMAs (wave-uniform).
+        int rem = kg_end - base;
+        if (rem > DEPTH) {
 #pragma unroll
             for (int u = 0; u < DEPTH; ++u) {
-                if (base + u < kg_end) SK_MFMA(u)
-                if (base + DEPTH < kg_end) SK_LOAD(u, base + u + DEPTH)
+                SK_MFMA(u)
+                SK_LOAD(u, base + u + DEPTH)
+                __builtin_amdgcn_sched_barrier(0);
             }
+            rem -= DEPTH;
+        }
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            if (u < rem) SK_MFMA(u)
         }
 #undef SK_MFMA
 #undef SK_LOAD
@@ -366,10 +382,10 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 // path) from the encoder recurrence and the autoregressive GEMVs.
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_kernel(SkinnyJobs jobs) {
     if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }   // uniform per workgroup
-    skinny_body<MT, (MT == 1 ? SK_DEPTH1 : 6)>(jobs);
+    skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
 }
-template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : 6)>(jobs); }
-template <int MT> __global__ __launch_bounds__(SK_THREADS) void skinny_linear_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : 6)>(jobs); }
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs); }
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void skinny_linear_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs); }
 
 static size_t skinny_lds(int MT) { return (size_t)(SK_WAVES * MT * 16 * 64 + MT * 32 * 8) * sizeof(float); }
 

@@ -30,14 +30,16 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def algorithmic_bytes_lstm_launch(mc, B):
-    """Bytes one decoder LSTM-step launch must move (DESIGN.md section 'Roofline'): both recurrent matrices and
-    biases once, the x rows, cell state read+write, new hidden states, attention-query partial slabs."""
+def algorithmic_bytes_lstm_launch(mc, B, L):
+    """Bytes one decoder LSTM-step launch must move: both recurrent matrices and biases once, the
+    x rows, cell state read+write, new hidden states, attention-query partial slabs, and - since the launch also
+    produces the next attention step's location features - the two weight rows read and L*a features written per row."""
     P, E, A, D, a = mc.prenet_dim, mc.encoder_embedding_dim, mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.attention_dim
     weights = 4 * A * (P + E + A) + 4 * D * (A + E + D) + 4 * A + 4 * D
     per_row = (P + E + A) + (A + E + D) + 2 * (A + D) + (A + D)
     slabs = (A // 8) * a
-    return 4 * (weights + B * (per_row + slabs))
+    loc = 2 * L + L * a
+    return 4 * (weights + B * (per_row + slabs + loc))
 
 
 def algorithmic_bytes_decoder_step(mc, B, L):
@@ -126,7 +128,7 @@ def main():
         torch.cuda.synchronize()
         kt = model.kernel_times_ms()
         model.enable_kernel_timing(False)
-        alg = algorithmic_bytes_lstm_launch(mc, B)
+        alg = algorithmic_bytes_lstm_launch(mc, B, L)
         achieved = alg / (kt["decoder_lstm_step"] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic_latest.json")

@@ -54,3 +54,44 @@ def test_collate_feeds_forward():
     out = m.forward(m.prepare_batch(batch, "cuda:0"))
     assert out["mel_outputs_postnet"].shape == (3, 80, 30) and torch.isfinite(out["mel_outputs_postnet"]).all()
     assert torch.all(out["gate_outputs"][2, 14:] == 1e3)
+
+
+def test_c_abi_rejects_bad_arguments_loudly():
+    """Error behaviour of the boundary: status code + message, no crash, no silent fallback."""
+    import ctypes as C
+
+    from genvox_amd import _lib
+
+    lib = _lib.load()
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=12)
+    m = Tacotron2(mc, ac, tc).to("cuda:0")
+    # token id outside the embedding table: flagged, not an out-of-bounds read (row is embedded as zeros)
+    bad = {"token_padded": torch.full((2, 8), 99, dtype=torch.long), "token_lengths": torch.tensor([8, 8]),
+           "mel_padded": torch.zeros(2, 80, 4), "gate_padded": torch.zeros(2, 4), "mel_lengths": torch.tensor([4, 4])}
+    out = m.forward(bad)
+    assert torch.isfinite(out["mel_outputs"]).all()
+    h = m._handle
+    ws = m._get_workspace(2, 8, 4)
+    s = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(16, device="cuda")
+    # batch over the per-call limit, workspace too small, misaligned workspace, null outputs
+    assert lib.gvx_encoder_forward(h, x.data_ptr(), None, 65, 8, x.data_ptr(), ws.data_ptr(), ws.numel(), s) == -2
+    assert b"batch" in lib.gvx_last_error()
+    assert lib.gvx_encoder_forward(h, x.data_ptr(), None, 2, 8, x.data_ptr(), ws.data_ptr(), 1024, s) == -5
+    assert b"workspace too small" in lib.gvx_last_error()
+    assert lib.gvx_encoder_forward(h, x.data_ptr(), None, 2, 8, x.data_ptr(), ws.data_ptr() + 4, ws.numel() - 4, s) == -5
+    assert lib.gvx_postnet_forward(h, None, 2, 4, None, ws.data_ptr(), ws.numel(), s) == -1
+    assert lib.gvx_mask_padding(None, None, None, None, 2, 80, 4, s) == -1
+    # inference past the per-call batch limit is refused by the host mirror with a clear message
+    with pytest.raises(AssertionError, match="shard"):
+        m.inference({"tokens": torch.zeros(65, 4, dtype=torch.long)})
+    # a teacher-forced batch over the limit is split transparently and matches per-chunk calls
+    B, L, T = 70, 6, 3
+    g = torch.Generator().manual_seed(1)
+    big = {"token_padded": torch.randint(0, 12, (B, L), generator=g), "token_lengths": torch.full((B,), L),
+           "mel_padded": torch.randn(B, 80, T, generator=g), "gate_padded": torch.zeros(B, T), "mel_lengths": torch.full((B,), T)}
+    masks = torch.from_numpy(gw.prenet_keep_masks((T + 1) * B, mc.prenet_dim)).reshape(2, T + 1, B, mc.prenet_dim)
+    whole = m.forward({**big, "prenet_keep_masks": masks})
+    part = m.forward({**{k: v[64:] for k, v in big.items()}, "prenet_keep_masks": masks[:, :, 64:].contiguous()})
+    assert whole["mel_outputs"].shape == (B, 80, T)
+    assert torch.equal(whole["mel_outputs_postnet"][64:], part["mel_outputs_postnet"])

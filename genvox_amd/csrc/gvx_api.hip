@@ -178,12 +178,13 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     WsPlan w{};
     size_t off = 0;
     auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
+    // status words first, at a shape-independent offset (gvx_workspace_status)
+    w.flags = take(128);  // [0] token error, [1] AR rows done, [64..64+B) AR frame counts
     w.xa = take((size_t)B * (L + 2 * pe) * E);
     w.xb = take((size_t)B * (L + 2 * pe) * E);
     w.xg = take((size_t)B * L * 8 * H);
     w.enc_h = take((size_t)2 * 2 * B * H);
     w.enc_c = take((size_t)2 * B * H);
-    w.flags = take(128);  // [0] token error, [1] AR rows done, [64..64+B) AR frame counts
     w.memory = take((size_t)B * L * E);  // encoder output of the fused forward
     w.len_copy = take((size_t)B);        // token lengths copied next to the graphs' other operands (offset independent of T)
     w.pm = take((size_t)B * L * d.att_dim);
@@ -843,6 +844,18 @@ int postnet_impl(gvx_model* m, const float* mel_in, int B, int T, float* mel_pos
 
 // =====================================================================================================
 extern "C" {
+
+int gvx_workspace_status(const gvx_model* m, const void* ws, size_t ws_bytes, void* stream, int32_t* host_out) {
+    if (!m || !ws || !host_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    const WsPlan wp = make_ws_plan(m, 1, 1, 1);   // the status words sit in front of every shape-dependent region
+    if (ws_bytes < wp.flags + sizeof(int32_t)) return fail(GVX_ERR_WORKSPACE, "workspace too small");
+    int32_t h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, reinterpret_cast<const char*>(ws) + wp.flags, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    host_out[0] = h;
+    host_out[1] = 0;
+    return GVX_OK;
+}
 
 int gvx_encoder_forward(gvx_model* m, const int64_t* tokens, const int32_t* lengths, int B, int L, float* memory_out,
                         void* ws, size_t ws_bytes, void* stream) {

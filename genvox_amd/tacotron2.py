@@ -169,6 +169,18 @@ class Tacotron2(nn.Module):
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
+    def check_status(self) -> None:
+        """Read the device-side status word of the last calls (synchronises the stream): raises IndexError for a token
+        id outside the embedding table, which is what nn.Embedding does in the reference (models/tts/tacotron2.py:459).
+        Not called by forward(): one check after a batch of calls is enough."""
+        if self._workspace is None:
+            return
+        out = (C.c_int32 * 2)()
+        _lib.check(_lib.load().gvx_workspace_status(self._handle, self._workspace.data_ptr(), self._workspace.numel(),
+                                                    self._stream(), out))
+        if out[0]:
+            raise IndexError("genvox_amd: token id outside [0, n_tokens)")
+
     def enable_stage_timing(self, enable: bool = True) -> None:
         self._timing = enable
         if self._handle is not None:

@@ -88,6 +88,14 @@ int gvx_model_bind_blob(gvx_model* model, const void* device_blob);
 /* Bytes of scratch the calls below need for batch B, L tokens and up to T frames. */
 size_t gvx_workspace_bytes(const gvx_model* model, int B, int L, int T);
 
+/* Device-side status words the kernels raise in the workspace, copied to host_out[2] after synchronising `stream`:
+ *   [0] != 0: a token id was outside [0, n_tokens) (the reference's nn.Embedding raises IndexError there,
+ *             models/tts/tacotron2.py:459; the row is embedded as zeros here) - set by the last
+ *             gvx_encoder_forward / gvx_tacotron2_forward on this workspace;
+ *   [1]: reserved (0).
+ * Costs a stream synchronisation: meant for tests and for one check after a batch of calls, not for every call. */
+int gvx_workspace_status(const gvx_model* model, const void* workspace, size_t workspace_bytes, void* stream, int32_t* host_out);
+
 /* ---- Encoder: embedding + conv/BN/relu stack + BiLSTM with packed-sequence semantics.
  * Replaces nn.Embedding + Encoder.forward / Encoder.inference (models/tts/tacotron2.py:459,
  * :231-246, :248-256).  tokens: int64 [B, L]; lengths: int32 [B] or NULL (= all L);

@@ -70,6 +70,10 @@ def test_c_abi_rejects_bad_arguments_loudly():
            "mel_padded": torch.zeros(2, 80, 4), "gate_padded": torch.zeros(2, 4), "mel_lengths": torch.tensor([4, 4])}
     out = m.forward(bad)
     assert torch.isfinite(out["mel_outputs"]).all()
+    with pytest.raises(IndexError):
+        m.check_status()
+    m.forward({**bad, "token_padded": torch.zeros(2, 8, dtype=torch.long)})
+    m.check_status()   # the flag is per call
     h = m._handle
     ws = m._get_workspace(2, 8, 4)
     s = torch.cuda.current_stream().cuda_stream

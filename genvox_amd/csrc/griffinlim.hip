@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <string>
 
@@ -341,6 +342,75 @@ __global__ void wav_filter_kernel(const float* y, long n, int trim, const unsign
     }
 }
 
+// The same filter, parallel over chunks of every utterance.  The recurrence is linear and stable: a chunk started W samples
+// early from a zero state differs from the sequential filter by |M^W| (M = state transition matrix), and the host picks W
+// so that this is below 1e-18 - far under a float64 ulp of the output - so the warm-up samples are simply filtered and
+// discarded (overlap-discard).  One thread = one chunk; no cross-chunk exchange, no extra buffers; a row's result does
+// not depend on the batch it is in.  Reference: scipy.signal.lfilter in butter_lowpass_filter (utils/audio/base.py:164-166).
+__global__ void wav_filter_chunked_kernel(const float* y, long n, int trim, const unsigned int* peak_bits, IirCoef c, double* out,
+                                          int chunk, int warm, int nch) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (k >= nch) return;
+    const long n_out = n - 2L * trim;
+    const float peak = __uint_as_float(peak_bits[b]);
+    const long i_begin = (long)k * chunk, i_end = min(n_out, i_begin + chunk);
+    const long i_start = max(0L, i_begin - warm);
+    double z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* yb = y + (long)b * n + trim;
+    double* ob = out + (long)b * n_out;
+    constexpr int CH = 16;
+    float cur[CH], nxt[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) cur[q] = (i_start + q) < i_end ? yb[i_start + q] : 0.f;
+    for (long i0 = i_start; i0 < i_end; i0 += CH) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) nxt[q] = (i0 + CH + q) < i_end ? yb[i0 + CH + q] : 0.f;
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            if (i0 + q < i_end) {
+                float v = cur[q];
+                if (v > 1.f || v < -1.f) v = 0.f;
+                const double x = (double)(v / peak);
+                const double yo = c.b[0] * x + z[0];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) {
+                    if (r <= c.order) z[r - 1] = c.b[r] * x + (r < c.order ? z[r] : 0.0) - c.a[r] * yo;
+                }
+                if (i0 + q >= i_begin) ob[i0 + q] = yo;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) cur[q] = nxt[q];
+    }
+}
+
+// smallest W with max|M^W| < 1e-18 for the filter's state transition matrix (direct form II transposed), or -1 if the
+// filter decays too slowly (or not at all) for the overlap-discard scheme
+int iir_warmup_length(const IirCoef& c, int cap) {
+    const int n = c.order;
+    double P[8][8] = {}, M[8][8] = {}, R[8][8];
+    for (int q = 1; q <= n; ++q) {
+        M[q - 1][0] = -c.a[q];
+        if (q < n) M[q - 1][q] = 1.0;
+    }
+    for (int i = 0; i < n; ++i) P[i][i] = 1.0;
+    for (int w = 1; w <= cap; ++w) {
+        double mx = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < n; ++k) acc += P[i][k] * M[k][j];
+                R[i][j] = acc;
+                mx = std::fmax(mx, std::fabs(acc));
+            }
+        std::memcpy(P, R, sizeof P);
+        if (!(mx < 1e300)) return -1;
+        if (mx < 1e-18) return w;
+    }
+    return -1;
+}
+
 int run_fft(gvx_gl_plan* p, rocfft_plan plan, void* in, void* out, void* work, size_t work_bytes, hipStream_t s) {
     if (!p->info) GL_FFT(rocfft_execution_info_create(&p->info));
     if (work_bytes) GL_FFT(rocfft_execution_info_set_work_buffer(p->info, work, work_bytes));
@@ -536,7 +606,16 @@ int gvx_wav_finalize(const float* wav, int B, long n_samples, int trim, const do
     GL_HIP(hipMemsetAsync(scratch_B, 0, (size_t)B * sizeof(unsigned int), s));
     wav_peak_kernel<<<dim3(64, B), 256, 0, s>>>(wav, n_samples, trim, scratch_B);
     GL_HIP(hipGetLastError());
-    wav_filter_kernel<<<(B + 63) / 64, 64, 0, s>>>(wav, n_samples, trim, scratch_B, c, out, B);
+    const int warm = iir_warmup_length(c, 4096);
+    if (warm > 0) {
+        int chunk = 1024;
+        while (chunk < 8 * warm) chunk *= 2;   // warm-up work <= 1/8 of the total
+        const long n_out = n_samples - 2L * trim;
+        const int nch = (int)((n_out + chunk - 1) / chunk);
+        wav_filter_chunked_kernel<<<dim3((nch + 63) / 64, B), 64, 0, s>>>(wav, n_samples, trim, scratch_B, c, out, chunk, warm, nch);
+    } else {
+        wav_filter_kernel<<<(B + 63) / 64, 64, 0, s>>>(wav, n_samples, trim, scratch_B, c, out, B);   // slowly decaying filter: sequential
+    }
     GL_HIP(hipGetLastError());
     return GVX_OK;
 }

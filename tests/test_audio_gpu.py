@@ -134,3 +134,50 @@ def test_wav_to_mel_matches_reference(ap):
     assert np.abs(mel[0] - fx["mel_db"]).max() <= 1e-4          # dB values are O(1..10); fp32 log of an fp32 GEMM
     want = audio_ref.wav_to_mel(0.25 * fx["signal"], fx["mel_basis"], AUDIO_CASE["n_fft"], AUDIO_CASE["hop"], AUDIO_CASE["log_func"], AUDIO_CASE["ref"])
     assert np.abs(mel[1] - want).max() <= 1e-4
+
+
+def test_finalize_chunked_filter_matches_lfilter(ap):
+    """clip / trim / peak-normalise / Butterworth low-pass (core/processors.py:91-95, utils/audio/base.py:164-169) on
+    signals long enough for many filter chunks: the overlap-discard kernel equals scipy's sequential lfilter to float64
+    rounding, for ragged batch sizes, and a row's result does not depend on its batch."""
+    import scipy.signal
+
+    rng = np.random.default_rng(5)
+    B, n = 5, 30000 + 2 * ap.TRIM + 37            # ~30 chunks of 1024, ragged tail
+    wav = (rng.standard_normal((B, n)) * 0.4).astype(np.float32)
+    wav[1, 1000:1010] = 3.0                        # spurious samples > 1 are zeroed (core/processors.py:92)
+    got = ap.finalize(torch.from_numpy(wav)).cpu().numpy()
+    for b in range(B):
+        y = wav[b].copy()
+        y[np.abs(y) > 1] = 0
+        y = y[ap.TRIM:-ap.TRIM]
+        y = y / np.abs(y).max()
+        want = scipy.signal.lfilter(ap._b, ap._a, y.astype(np.float64))
+        assert np.abs(got[b] - want).max() <= 1e-13
+    alone = ap.finalize(torch.from_numpy(wav[3:4])).cpu().numpy()
+    assert np.array_equal(alone[0], got[3])
+
+
+def test_finalize_slow_filter_falls_back_to_sequential(ap):
+    """A filter whose impulse response does not die out within the warm-up cap runs on the sequential kernel."""
+    import ctypes as C
+
+    import scipy.signal
+
+    from genvox_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(6)
+    B, n, trim = 3, 5000, 10
+    wav = (rng.standard_normal((B, n)) * 0.3).astype(np.float32)
+    b = np.array([1.0, 0.0]); a = np.array([1.0, -0.9999])     # pole at 0.9999: |M^W| < 1e-18 needs W ~ 4e5
+    y = torch.from_numpy(wav).cuda()
+    out = torch.empty(B, n - 2 * trim, dtype=torch.float64, device="cuda")
+    scratch = torch.empty(B, dtype=torch.int32, device="cuda")
+    _lib.check(lib.gvx_wav_finalize(y.data_ptr(), B, n, trim, (C.c_double * 2)(*b), (C.c_double * 2)(*a), 1, out.data_ptr(),
+                                    scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy()
+    for r in range(B):
+        x = wav[r].copy(); x[np.abs(x) > 1] = 0; x = x[trim:-trim]; x = x / np.abs(x).max()
+        want = scipy.signal.lfilter(b, a, x.astype(np.float64))
+        assert np.abs(got[r] - want).max() <= 1e-9 * np.abs(want).max()

@@ -18,9 +18,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -54,6 +56,7 @@ struct FftPair {
 
 struct gvx_gl_plan {
     int n_fft, hop, bins;
+    float2* tw = nullptr;   // fused 1024-point path: [0,512) e^{-2 pi i m/512}, [512, 512+513) e^{-2 pi i k/1024}
     std::map<long, FftPair> plans;  // keyed by batch count (B*T)
     rocfft_execution_info info = nullptr;
 };
@@ -411,6 +414,214 @@ int iir_warmup_length(const IirCoef& c, int cap) {
     return -1;
 }
 
+// =====================================================================================================
+// Fused Griffin-Lim iteration for n_fft = 1024, hop = 256 (the reference's vocoder setting).
+// The rocFFT pipeline moves each frame through HBM seven times per iteration (c2r pre/post kernels, raw frames, overlap-add,
+// re-framing, r2c, update: 8.6 GB per iteration at 256 x 800 frames).  Here an iteration is two kernels:
+//   gl_inverse_ola_kernel   spectrum -> 512-point complex inverse FFT per frame in LDS (one wave per frame, 16 frames per
+//                           workgroup) -> window -> overlap-add of the workgroup's 13 hop blocks -> y        (reads S, writes y)
+//   gl_forward_update_kernel  y -> window -> FFT -> rebuilt spectrum -> momentum update -> new S and tprev in place
+//                                                                     (reads y, tprev, mag; writes S, tprev)
+// = 3.9 GB per iteration, the minimum for an iteration that keeps S and tprev in HBM.
+// FFT: a 1024-point real transform as a 512-point complex Stockham radix-8 (3 passes, 8 points per lane, exchange through
+// LDS) plus the even/odd split; unnormalised inverse like rocFFT's c2r, so the 1/n_fft of istft stays where it was.
+// Summation order of the overlap-add (ascending frame index) and every elementwise formula are those of the unfused
+// kernels above; only the FFT's internal rounding differs (fp32, table twiddles computed in double).
+// =====================================================================================================
+constexpr int FN = 512;              // complex points
+constexpr int FPAD = FN + FN / 8;    // LDS words (float2) per frame: index i lives at i + (i >> 3)
+__device__ __forceinline__ int fpad(int i) { return i + (i >> 3); }
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+template <bool INV> __device__ __forceinline__ float2 rot90(float2 a) {   // a * (-i) forward, a * (+i) inverse
+    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d) {
+    const float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = rot90<INV>(csub(b, d));
+    a = cadd(t0, t2); b = cadd(t1, t3); c = csub(t0, t2); d = csub(t1, t3);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft8(float2 v[8]) {
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4<INV>(e0, e1, e2, e3);
+    dft4<INV>(o0, o1, o2, o3);
+    const float h = 0.70710678118654752f;
+    // o_k *= w8^k, w8 = e^{-+ i pi/4}
+    const float2 w1 = INV ? make_float2(h * (o1.x - o1.y), h * (o1.x + o1.y)) : make_float2(h * (o1.x + o1.y), h * (o1.y - o1.x));
+    const float2 w2 = rot90<INV>(o2);
+    const float2 w3 = INV ? make_float2(-h * (o3.x + o3.y), h * (o3.x - o3.y)) : make_float2(h * (o3.y - o3.x), -h * (o3.x + o3.y));
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, w1); v[5] = csub(e1, w1);
+    v[2] = cadd(e2, w2); v[6] = csub(e2, w2);
+    v[3] = cadd(e3, w3); v[7] = csub(e3, w3);
+}
+
+// 512-point complex FFT of one frame by one wave.  In: lane j holds x[j + 64 r] in v[r].  Out: lane j holds X[j + 64 r]
+// in v[r] (natural order); if to_lds, the result is also left in `buf` (padded indexing) for the caller.
+template <bool INV>
+__device__ __forceinline__ void fft512_wave(float2 v[8], float2* buf, const float2* __restrict__ tw, int j, bool to_lds) {
+#pragma unroll
+    for (int stage = 0; stage < 3; ++stage) {
+        const int Ns = stage == 0 ? 1 : (stage == 1 ? 8 : 64);
+        const int k = j & (Ns - 1);
+        if (stage > 0) {
+            const int mult = 64 / Ns;   // twiddle w_{Ns*8}^{r k} = w_512^{r k mult}
+#pragma unroll
+            for (int r = 1; r < 8; ++r) {
+                float2 w = tw[(r * k * mult) & (FN - 1)];
+                if (INV) w.y = -w.y;
+                v[r] = cmul(v[r], w);
+            }
+        }
+        dft8<INV>(v);
+        if (stage < 2 || to_lds) {
+            const int j0 = (j / Ns) * Ns * 8 + k;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) buf[fpad(j0 + r * Ns)] = v[r];
+        }
+        if (stage < 2) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = buf[fpad(j + 64 * r)];
+            __syncthreads();
+        }
+    }
+}
+
+constexpr int GLI_FRAMES = 16;                 // frames (waves) per workgroup of the inverse kernel
+constexpr int GLI_BLOCKS = GLI_FRAMES - 3;     // hop blocks it completes (n_fft / hop - 1 = 3 halo frames)
+
+// S [B*T][513] (frame-major) -> y [B][(T+3)*256]: y[i] = (sum_t win[k] * (irfft(S_t)[k] / 1024)) / wss[i], k = i - 256 t
+__global__ __launch_bounds__(GLI_FRAMES * 64) void gl_inverse_ola_kernel(const float2* __restrict__ spec, const float* __restrict__ win,
+                                                                         const float* __restrict__ wss, const float2* __restrict__ tw,
+                                                                         float* __restrict__ y, int T) {
+    extern __shared__ __attribute__((aligned(16))) float2 fsm[];   // [GLI_FRAMES][FPAD] float2; reused as [GLI_FRAMES][1024] float
+    const int b = blockIdx.y, h0 = blockIdx.x * GLI_BLOCKS;
+    const int tid = threadIdx.x, j = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = h0 - 3 + wave;
+    const bool valid = t >= 0 && t < T;       // wave-uniform; every wave still joins the barriers
+    float2* buf = fsm + wave * FPAD;
+    float2 v[8];
+    if (valid) {
+        const float2* S = spec + ((long)b * T + t) * 513;
+        const float2* tw2 = tw + FN;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = j + 64 * r;
+            float2 a = S[k], c = S[512 - k];
+            if (k == 0) { a.y = 0.f; c.y = 0.f; }          // c2r ignores the imaginary parts of the DC and Nyquist bins
+            c.y = -c.y;                                     // conj(S[512 - k])
+            const float2 w = tw2[k];                        // e^{-2 pi i k/1024}; need e^{+...}
+            const float2 d = csub(a, c);
+            const float2 id = make_float2(-d.y, d.x);       // i * d
+            v[r] = cadd(cadd(a, c), cmul(id, make_float2(w.x, -w.y)));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
+    }
+    fft512_wave<true>(v, buf, tw, j, false);
+    // windowed frame (same operation order as gl_ola_kernel: win[k] * (fr[k] * (1/n_fft))) into this wave's LDS row
+    float* frow = reinterpret_cast<float*>(buf);   // 1024 floats inside the wave's FPAD*2 floats; all exchanges above are done
+    __syncthreads();
+    if (valid) {
+        const float inv_n = 1.f / 1024.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n2 = 2 * (j + 64 * r);
+            const float2 w = *reinterpret_cast<const float2*>(win + n2);
+            *reinterpret_cast<float2*>(frow + n2) = make_float2(w.x * (v[r].x * inv_n), w.y * (v[r].y * inv_n));
+        }
+    }
+    __syncthreads();
+    // overlap-add of hop blocks h0 .. h0+12 (ascending frame order), divide by the window sum of squares
+    const long n = (long)(T + 3) * 256;
+    const float* fall = reinterpret_cast<const float*>(fsm);
+    for (int idx = tid; idx < GLI_BLOCKS * 256; idx += GLI_FRAMES * 64) {
+        const int hb = idx >> 8, q = idx & 255;
+        const int h = h0 + hb;
+        const long i = (long)h * 256 + q;
+        if (i >= n) break;
+        float sacc = 0.f;
+#pragma unroll
+        for (int d = 3; d >= 0; --d) {           // frames t = h-3 .. h  ->  waves hb .. hb+3
+            const int tt = h - d;
+            if (tt >= 0 && tt < T) sacc += fall[(long)(hb + 3 - d) * (FPAD * 2) + d * 256 + q];
+        }
+        const float w = wss[i];
+        y[(long)b * n + i] = w > 1.17549435e-38f ? sacc / w : sacc;
+    }
+}
+
+constexpr int GLF_FRAMES = 4;   // frames (waves) per workgroup of the forward kernel
+
+// y -> rebuilt = rfft(win * frame); ang' = rebuilt - c*tprev; S = mag * ang' / (|ang'| + tiny); tprev = rebuilt  (in place)
+__global__ __launch_bounds__(GLF_FRAMES * 64) void gl_forward_update_kernel(const float* __restrict__ y, const float* __restrict__ win,
+                                                                            const float2* __restrict__ tw, const float* __restrict__ mag,
+                                                                            float2* __restrict__ tprev, float2* __restrict__ spec,
+                                                                            float c, int first, int T, long frames) {
+    __shared__ __attribute__((aligned(16))) float2 fsm[GLF_FRAMES * FPAD];
+    const int tid = threadIdx.x, j = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long f = (long)blockIdx.x * GLF_FRAMES + wave;
+    const bool valid = f < frames;
+    float2* buf = fsm + wave * FPAD;
+    float2 v[8];
+    if (valid) {
+        const int b = (int)(f / T), t = (int)(f - (long)b * T);
+        const float* yb = y + (long)b * (long)(T + 3) * 256 + (long)t * 256;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n2 = 2 * (j + 64 * r);
+            const float2 x = *reinterpret_cast<const float2*>(yb + n2);
+            const float2 w = *reinterpret_cast<const float2*>(win + n2);
+            v[r] = make_float2(w.x * x.x, w.y * x.y);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
+    }
+    fft512_wave<false>(v, buf, tw, j, true);
+    __syncthreads();
+    if (!valid) return;
+    const float2* tw2 = tw + FN;
+    const long base = f * 513;
+    // bins k = j + 64 r (r = 0..7) and, on lane 0, k = 512
+    for (int r = 0; r < 9; ++r) {
+        const int k = r < 8 ? j + 64 * r : 512;
+        if (r == 8 && j != 0) break;
+        const float2 zk = buf[fpad(k & (FN - 1))];
+        float2 zc = buf[fpad((512 - k) & (FN - 1))];
+        zc.y = -zc.y;
+        const float2 w = tw2[k];
+        const float2 sm = cadd(zk, zc), df = csub(zk, zc);
+        const float2 wd = cmul(w, df);                       // W^k (Z[k] - conj Z[512-k])
+        float2 reb = make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));   // 0.5*sm - 0.5i*wd
+        if (k == 0 || k == 512) reb.y = 0.f;                 // exactly real for a real signal
+        float2 a = reb;
+        if (!first) {
+            const float2 pv = tprev[base + k];
+            a.x = reb.x - c * pv.x;
+            a.y = reb.y - c * pv.y;
+        }
+        const float d = hypotf(a.x, a.y) + 1.17549435e-38f;
+        const float m = mag[base + k];
+        spec[base + k] = make_float2(a.x / d * m, a.y / d * m);
+        tprev[base + k] = reb;
+    }
+}
+
+bool getenv_flag(const char* name) {
+    const char* e = std::getenv(name);
+    return e && e[0] == '1';
+}
+
 int run_fft(gvx_gl_plan* p, rocfft_plan plan, void* in, void* out, void* work, size_t work_bytes, hipStream_t s) {
     if (!p->info) GL_FFT(rocfft_execution_info_create(&p->info));
     if (work_bytes) GL_FFT(rocfft_execution_info_set_work_buffer(p->info, work, work_bytes));
@@ -460,6 +671,22 @@ int gvx_gl_plan_create(int n_fft, int hop, gvx_gl_plan** out) {
     }
     gvx_gl_plan* p = new gvx_gl_plan();
     p->n_fft = n_fft; p->hop = hop; p->bins = n_fft / 2 + 1;
+    if (n_fft == 1024 && hop == 256) {   // tables of the fused Griffin-Lim path
+        std::vector<float2> h(FN + 513);
+        const double two_pi = 6.283185307179586476925286766559;
+        for (int m = 0; m < FN; ++m) h[m] = make_float2((float)std::cos(two_pi * m / 512.0), (float)-std::sin(two_pi * m / 512.0));
+        for (int k = 0; k <= 512; ++k) h[FN + k] = make_float2((float)std::cos(two_pi * k / 1024.0), (float)-std::sin(two_pi * k / 1024.0));
+        if (hipMalloc(&p->tw, h.size() * sizeof(float2)) != hipSuccess ||
+            hipMemcpy(p->tw, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+            delete p;
+            return gl_fail(GVX_ERR_HIP, "twiddle table allocation failed");
+        }
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gl_inverse_ola_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GLI_FRAMES * FPAD * (int)sizeof(float2)) != hipSuccess) {
+            delete p;
+            return gl_fail(GVX_ERR_HIP, "hipFuncSetAttribute failed");
+        }
+    }
     *out = p;
     return GVX_OK;
 }
@@ -471,6 +698,7 @@ void gvx_gl_plan_destroy(gvx_gl_plan* p) {
         if (kv.second.c2r) rocfft_plan_destroy(kv.second.c2r);
     }
     if (p->info) rocfft_execution_info_destroy(p->info);
+    if (p->tw) (void)hipFree(p->tw);
     delete p;
 }
 
@@ -569,7 +797,22 @@ int gvx_griffin_lim(gvx_gl_plan* p, const float* mag, const float* window, int B
     gl_init_kernel<<<blocks_for(nbin), 256, 0, s>>>(mag_t, ang, nbin);
     GL_HIP(hipGetLastError());
     const float c = momentum / (1.f + momentum);
-    for (int it = 0; it < n_iter; ++it) {
+    const bool fused = p->tw != nullptr && !getenv_flag("GVX_GL_ROCFFT");
+    auto inverse_ola = [&](const float2* spec) -> int {   // y = istft(spec), fused path
+        gl_inverse_ola_kernel<<<dim3((unsigned)((T + 3 + GLI_BLOCKS - 1) / GLI_BLOCKS), B), GLI_FRAMES * 64,
+                                GLI_FRAMES * FPAD * sizeof(float2), s>>>(spec, window, wsp<float>(ws, w.wss), p->tw, wsp<float>(ws, w.y), T);
+        GL_HIP(hipGetLastError());
+        return GVX_OK;
+    };
+    for (int it = 0; fused && it < n_iter; ++it) {
+        rc = inverse_ola(ang);                                  // inverse = istft(angles)
+        if (rc != GVX_OK) return rc;
+        const long frames = (long)B * T;                        // rebuilt = stft(inverse); momentum update; tprev = rebuilt
+        gl_forward_update_kernel<<<dim3((unsigned)((frames + GLF_FRAMES - 1) / GLF_FRAMES)), GLF_FRAMES * 64, 0, s>>>(
+            wsp<float>(ws, w.y), window, p->tw, mag_t, reb[0], ang, c, it == 0, T, frames);
+        GL_HIP(hipGetLastError());
+    }
+    for (int it = 0; !fused && it < n_iter; ++it) {
         rc = istft_frames(p, fp, ang, window, B, T, ws, w, s);  // inverse = istft(angles)
         if (rc != GVX_OK) return rc;
         gl_frame_kernel<<<dim3((unsigned)((long)B * T)), 256, 0, s>>>(wsp<float>(ws, w.y), window, wsp<float>(ws, w.fr), p->n_fft, p->hop, T, n);
@@ -581,13 +824,13 @@ int gvx_griffin_lim(gvx_gl_plan* p, const float* mag, const float* window, int B
         GL_HIP(hipGetLastError());
     }
     // phase = angle(angles); final spectrum = mag * exp(i phase) (not `angles` itself: they differ where mag < 0)
-    float2* spec_t = reb[0];
-    float* phase_t = reinterpret_cast<float*>(reb[1]);
+    float2* spec_t = reb[1];
+    float* phase_t = wsp<float>(ws, w.fr);   // frames * n_fft floats >= frames * bins
     gl_final_kernel<<<blocks_for(nbin), 256, 0, s>>>(ang, mag_t, wav_out ? spec_t : nullptr, phase_out ? phase_t : nullptr, nbin);
     GL_HIP(hipGetLastError());
     if (phase_out) GL_HIP(launch_transpose<float>(phase_t, phase_out, B, T, p->bins, s));
     if (wav_out) {
-        rc = istft_frames(p, fp, spec_t, window, B, T, ws, w, s);
+        rc = fused ? inverse_ola(spec_t) : istft_frames(p, fp, spec_t, window, B, T, ws, w, s);
         if (rc != GVX_OK) return rc;
         GL_HIP(hipMemcpyAsync(wav_out, wsp<float>(ws, w.y), (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, s));
     }

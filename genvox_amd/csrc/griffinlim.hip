@@ -463,6 +463,12 @@ __device__ __forceinline__ void dft8(float2 v[8]) {
 
 // 512-point complex FFT of one frame by one wave.  In: lane j holds x[j + 64 r] in v[r].  Out: lane j holds X[j + 64 r]
 // in v[r] (natural order); if to_lds, the result is also left in `buf` (padded indexing) for the caller.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool INV>
 __device__ __forceinline__ void fft512_wave(float2 v[8], float2* buf, const float2* __restrict__ tw, int j, bool to_lds) {
 #pragma unroll
@@ -485,10 +491,12 @@ __device__ __forceinline__ void fft512_wave(float2 v[8], float2* buf, const floa
             for (int r = 0; r < 8; ++r) buf[fpad(j0 + r * Ns)] = v[r];
         }
         if (stage < 2) {
-            __syncthreads();
+            // the exchange stays inside this wave's LDS row and a wave's LDS instructions execute in order: a wave-level
+            // fence (no instruction, only ordering for the compiler) is all the synchronisation the pass needs
+            wave_lds_fence();
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = buf[fpad(j + 64 * r)];
-            __syncthreads();
+            wave_lds_fence();
         }
     }
 }
@@ -587,32 +595,43 @@ __global__ __launch_bounds__(GLF_FRAMES * 64) void gl_forward_update_kernel(cons
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
     }
-    fft512_wave<false>(v, buf, tw, j, true);
-    __syncthreads();
-    if (!valid) return;
+    // the update's operands do not depend on the FFT: fetch them now so their latency hides under it
     const float2* tw2 = tw + FN;
     const long base = f * 513;
+    float2 pv[9], wk[9];
+    float mg[9];
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int k = r < 8 ? j + 64 * r : 512;
+            const bool mine = r < 8 || j == 0;
+            pv[r] = (mine && !first) ? tprev[base + k] : make_float2(0.f, 0.f);
+            mg[r] = mine ? mag[base + k] : 0.f;
+            wk[r] = tw2[k];
+        }
+    }
+    fft512_wave<false>(v, buf, tw, j, true);
+    wave_lds_fence();
+    if (!valid) return;
     // bins k = j + 64 r (r = 0..7) and, on lane 0, k = 512
+#pragma unroll
     for (int r = 0; r < 9; ++r) {
         const int k = r < 8 ? j + 64 * r : 512;
         if (r == 8 && j != 0) break;
         const float2 zk = buf[fpad(k & (FN - 1))];
         float2 zc = buf[fpad((512 - k) & (FN - 1))];
         zc.y = -zc.y;
-        const float2 w = tw2[k];
         const float2 sm = cadd(zk, zc), df = csub(zk, zc);
-        const float2 wd = cmul(w, df);                       // W^k (Z[k] - conj Z[512-k])
+        const float2 wd = cmul(wk[r], df);                   // W^k (Z[k] - conj Z[512-k])
         float2 reb = make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));   // 0.5*sm - 0.5i*wd
         if (k == 0 || k == 512) reb.y = 0.f;                 // exactly real for a real signal
         float2 a = reb;
         if (!first) {
-            const float2 pv = tprev[base + k];
-            a.x = reb.x - c * pv.x;
-            a.y = reb.y - c * pv.y;
+            a.x = reb.x - c * pv[r].x;
+            a.y = reb.y - c * pv[r].y;
         }
         const float d = hypotf(a.x, a.y) + 1.17549435e-38f;
-        const float m = mag[base + k];
-        spec[base + k] = make_float2(a.x / d * m, a.y / d * m);
+        spec[base + k] = make_float2(a.x / d * mg[r], a.y / d * mg[r]);
         tprev[base + k] = reb;
     }
 }

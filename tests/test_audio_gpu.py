@@ -181,3 +181,22 @@ def test_finalize_slow_filter_falls_back_to_sequential(ap):
         x = wav[r].copy(); x[np.abs(x) > 1] = 0; x = x[trim:-trim]; x = x / np.abs(x).max()
         want = scipy.signal.lfilter(b, a, x.astype(np.float64))
         assert np.abs(got[r] - want).max() <= 1e-9 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 13), (2, 29), (5, 100)])
+def test_fused_griffin_lim_matches_rocfft_pipeline(ap, B, T, monkeypatch):
+    """The fused in-LDS FFT iteration (n_fft 1024 / hop 256) against the rocFFT pipeline it replaces, on the same
+    magnitudes: frame counts around the 13-block / 16-frame workgroup shape, first-iteration and momentum paths.
+    Both are fp32; they differ only in the FFTs' internal rounding, which Griffin-Lim amplifies slowly."""
+    rng = np.random.default_rng(B * 100 + T)
+    mag = np.abs(rng.standard_normal((B, 513, T))).astype(np.float32) * 3.0
+    mag[:, :, T // 2] *= 1e-3                      # a quiet frame
+    for n_iter, tol in ((0, 1e-5), (1, 2e-5), (4, 2e-4)):
+        monkeypatch.delenv("GVX_GL_ROCFFT", raising=False)
+        ph_f, wav_f = ap.griffin_lim(torch.from_numpy(mag), n_iter=n_iter)
+        monkeypatch.setenv("GVX_GL_ROCFFT", "1")
+        ph_r, wav_r = ap.griffin_lim(torch.from_numpy(mag), n_iter=n_iter)
+        wf, wr = wav_f.cpu().numpy(), wav_r.cpu().numpy()
+        for b in range(B):   # edge samples are divided by a ~1e-10 window sum: compare weighted (see istft_error)
+            assert istft_error(wf[b], wr[b], 1024, 256) <= tol * max(float(np.abs(wr[b]).max()), 1.0) * 10, (n_iter, "wav", b)
+        assert weighted_phase_diff(ph_f.cpu().numpy(), ph_r.cpu().numpy(), mag) <= tol * 50, (n_iter, "phase")

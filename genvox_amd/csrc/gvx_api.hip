@@ -993,7 +993,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     HIP_TRY(zero_async(flags + 1, (size_t)127 * sizeof(int32_t), s));   // n_done + frame counts
 
     // one step = Prenet (2 GEMVs) -> attention LSTM (+ location features) -> attention energy / context -> decoder LSTM
-    // -> mel/gate projection -> per-row stop test; db.proj holds one blocked projection vector [PSB/8][B][8] per step
+    // -> mel/gate projection (+ per-row stop test in its epilogue); db.proj holds one blocked projection vector [PSB/8][B][8] per step
     auto enqueue_steps = [&](hipStream_t st, int t0, int t1) -> int {
         for (int t = t0; t < t1; ++t) {
             float* proj_t = db.proj + (size_t)t * B * PSB;
@@ -1026,8 +1026,9 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
             job.x[0] = XSeg{db.hc + (size_t)(t + 1) * B * (D + E), D + E};
             job.N = M + 1; job.nkg = (D + E) / 8; job.mode = 1; job.B = B; job.act = ACT_NONE;
             job.y = proj_t;
+            job.stop_n_frames = n_frames_ws; job.stop_n_done = n_done;   // per-row stop test in the projection's epilogue
+            job.stop_col = M; job.stop_step = t; job.stop_threshold = gate_threshold;
             HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, st));
-            HIP_TRY(launch_ar_stop(proj_t, M, gate_threshold, t, B, n_frames_ws, n_done, st));
         }
         return GVX_OK;
     };

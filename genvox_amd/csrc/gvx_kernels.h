@@ -84,6 +84,9 @@ struct SkinnyJob {
     const uint8_t* keep; long keep_stride;  // keep[b*stride + n]
     int act;
     int B;
+    // autoregressive stop test fused into the projection job (models/tts/tacotron2.py:405-409): the lane that produces output
+    // row stop_col (the gate logit) of batch row b marks the row finished at step stop_step when sigmoid(gate) > threshold
+    int32_t* stop_n_frames; int32_t* stop_n_done; int stop_col; int stop_step; float stop_threshold;   // stop_n_frames = nullptr: off
 };
 // Location features of the NEXT attention step, computed by extra workgroups of the decoder LSTM launch (which is
 // memory bound and leaves VALU/LDS idle): loc[b][l][:] = Wd * conv1d_k([w_prev ; w_cum])[l].  They depend only on the

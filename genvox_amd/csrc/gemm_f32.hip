@@ -176,6 +176,8 @@ static hipError_t init_cfg() {
 hipError_t gemm_init() {
     hipError_t e = init_cfg<2, 2, 2, 2>();
     if (e != hipSuccess) return e;
+    e = init_cfg<2, 2, 1, 2>();
+    if (e != hipSuccess) return e;
     e = init_cfg<4, 1, 1, 3>();
     if (e != hipSuccess) return e;
     return init_cfg<4, 1, 1, 1>();
@@ -194,6 +196,10 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.K & 3) return hipErrorInvalidValue;
     if (p.N <= 32) return launch_cfg<4, 1, 1, 1>(p, s);
     if (p.N <= 96) return launch_cfg<4, 1, 1, 3>(p, s);
+    // fewer than ~1.5 workgroups per CU with 128 x 128 tiles (encoder convolutions: 4096 x 512): halve the tile height so
+    // that all 256 CUs get work
+    const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (tiles128 < 384) return launch_cfg<2, 2, 1, 2>(p, s);
     return launch_cfg<2, 2, 2, 2>(p, s);
 }
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "gvx_postnet_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "gvx_mask_padding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gvx_tacotron2_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_tacotron2_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "gvx_prenet_masks_generate": (_i, [_vp, _sz, C.c_uint64, _vp]),
     "gvx_stage_timing_enable": (_i, [_vp, _i]),
     "gvx_stage_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),

@@ -913,6 +913,19 @@ int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* to
     return GVX_OK;
 }
 
+int gvx_tacotron2_loss(const float* mel_out, const float* mel_post_out, const float* gate_out, const float* mel_target,
+                       const float* gate_target, int B, int n_mels, int T, float* loss_out, void* scratch, size_t scratch_bytes,
+                       void* stream) {
+    if (!mel_out || !mel_post_out || !gate_out || !mel_target || !gate_target || !loss_out || !scratch)
+        return fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (B < 1 || n_mels < 1 || T < 1) return fail(GVX_ERR_INVALID_ARG, "B, n_mels and T must be >= 1");
+    if (scratch_bytes < loss_scratch_bytes() || (reinterpret_cast<uintptr_t>(scratch) & 7))
+        return fail(GVX_ERR_WORKSPACE, "scratch too small (%zu bytes needed) or not 8-byte aligned", loss_scratch_bytes());
+    HIP_TRY(launch_tacotron2_loss(mel_out, mel_post_out, gate_out, mel_target, gate_target, (long)B * n_mels * T, (long)B * T,
+                                  reinterpret_cast<double*>(scratch), loss_out, (hipStream_t)stream));
+    return GVX_OK;
+}
+
 int gvx_prenet_masks_generate(uint8_t* masks_out, size_t n, uint64_t seed, void* stream) {
     if (!masks_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
     HIP_TRY(launch_mask_gen(masks_out, n, seed, (hipStream_t)stream));

@@ -146,6 +146,10 @@ hipError_t launch_mask_padding(float* mel, float* mel_post, float* gate, const i
                                hipStream_t s);
 // dst[b][t][:] = src[t][b][:]  (rows of n floats, n % 4 == 0 not required)
 hipError_t launch_permute01(const float* src, float* dst, int T, int B, int n, hipStream_t s);
+// Tacotron2Loss: out3 = {loss, mel_loss, gate_loss}; scratch = loss_scratch_bytes() of device memory (8-byte aligned)
+size_t loss_scratch_bytes();
+hipError_t launch_tacotron2_loss(const float* mel, const float* mel_post, const float* gate, const float* mel_t, const float* gate_t,
+                                 long n_mel, long n_gate, double* scratch, float* out3, hipStream_t s);
 hipError_t launch_mask_gen(uint8_t* out, size_t n, uint64_t seed, hipStream_t s);
 // AR: gate logits of step t (blocked projection vector) -> per-row finished flags / frame counts / all-finished counter
 hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, int t, int B,

@@ -252,4 +252,58 @@ hipError_t launch_permute01_partial(const float* src, float* dst, int steps, int
     return hipGetLastError();
 }
 
+// ---- criterion of the evaluation step (Tacotron2Loss, models/tts/tacotron2.py:598-615) ------------------------------
+// partial[block] = {sum (mel - target)^2, sum (mel_post - target)^2, sum BCE-with-logits(gate, gate target)} in float64;
+// LOSS_BLOCKS fixed blocks with a fixed element assignment, then one thread adds the partials in block order: bitwise
+// reproducible, and accurate enough that the means match a float64 evaluation to float32 rounding.
+constexpr int LOSS_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ mel, const float* __restrict__ mel_post,
+                                                           const float* __restrict__ gate, const float* __restrict__ mel_t,
+                                                           const float* __restrict__ gate_t, long n_mel, long n_gate, double* partial) {
+    __shared__ double red[3][256];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    const long stride = (long)LOSS_BLOCKS * 256, first = (long)blockIdx.x * 256 + threadIdx.x;
+    for (long i = first; i < n_mel; i += stride) {
+        const float t = mel_t[i], a = mel[i] - t, b = mel_post[i] - t;
+        s0 += (double)(a * a);
+        s1 += (double)(b * b);
+    }
+    for (long i = first; i < n_gate; i += stride) {
+        const float x = gate[i], y = gate_t[i];
+        s2 += (double)(fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));   // numerically stable BCE with logits
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int q = 0; q < 3; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) partial[(long)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void loss_final_kernel(const double* partial, long n_mel, long n_gate, float* out3) {
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = 0; b < LOSS_BLOCKS; ++b)
+        for (int q = 0; q < 3; ++q) s[q] += partial[b * 3 + q];
+    const float mse0 = (float)(s[0] / (double)n_mel), mse1 = (float)(s[1] / (double)n_mel);
+    const float mel_loss = mse0 + mse1;                      // float32 sums, like the reference's tensor arithmetic
+    const float gate_loss = (float)(s[2] / (double)n_gate);
+    out3[0] = mel_loss + gate_loss;
+    out3[1] = mel_loss;
+    out3[2] = gate_loss;
+}
+
+size_t loss_scratch_bytes() { return (size_t)LOSS_BLOCKS * 3 * sizeof(double); }
+
+hipError_t launch_tacotron2_loss(const float* mel, const float* mel_post, const float* gate, const float* mel_t, const float* gate_t,
+                                 long n_mel, long n_gate, double* scratch, float* out3, hipStream_t s) {
+    loss_partial_kernel<<<dim3(LOSS_BLOCKS), dim3(256), 0, s>>>(mel, mel_post, gate, mel_t, gate_t, n_mel, n_gate, scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    loss_final_kernel<<<dim3(1), dim3(1), 0, s>>>(scratch, n_mel, n_gate, out3);
+    return hipGetLastError();
+}
+
 }  // namespace gvx

@@ -356,7 +356,43 @@ class Tacotron2(nn.Module):
         raise NotImplementedError("genvox_amd.Tacotron2 is an inference-only forward path (no backward kernels); "
                                   "train with the reference and load the checkpoint here.")
 
+    def get_criterion(self) -> Dict:
+        """Reference: tacotron2.py:501-504."""
+        return {"loss": Tacotron2Loss}
+
     def eval_step(self, batch: Dict, criterion: Optional[Dict] = None, eval_outdir: Optional[str] = None) -> Dict[str, torch.Tensor]:
-        """Forward under no_grad (reference: tacotron2.py:524-528); plotting/loss logging is out of scope."""
+        """Forward + criterion under no_grad (reference: tacotron2.py:524-529): fills `loss_items_eval` with
+        loss_eval / mel_loss_eval / gate_loss_eval like the reference and returns the forward outputs.  The plots the
+        reference writes to `eval_outdir` are out of scope."""
         with torch.no_grad():
-            return self.forward(batch)
+            outputs = self.forward(batch)
+            loss = (criterion or self.get_criterion())["loss"](batch, outputs)
+        self.loss_items_eval = {(key + "_eval"): val.item() for key, val in loss.items()}
+        return outputs
+
+    def get_eval_priority(self) -> float:
+        """Reference: tacotron2.py:550-551."""
+        return self.loss_items_eval["loss_eval"]
+
+
+def Tacotron2Loss(batch: Dict[str, torch.Tensor], outputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Criterion of the evaluation step, same name / arguments / result keys as the reference's Tacotron2Loss
+    (models/tts/tacotron2.py:598-615): {"loss", "mel_loss", "gate_loss"} as 0-dim float32 tensors on the outputs'
+    device.  One HIP reduction (gvx_tacotron2_loss); forward only - there is no backward on this path."""
+    lib = _lib.load()
+    mel = outputs["mel_outputs"]
+    dev = mel.device
+    if dev.type != "cuda":
+        raise RuntimeError("genvox_amd.Tacotron2Loss needs the outputs of the GPU forward path (cuda tensors)")
+    B, M, T = mel.shape
+    f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+    mel, post, gate = f32(mel), f32(outputs["mel_outputs_postnet"]), f32(outputs["gate_outputs"])
+    mel_t, gate_t = f32(batch["mel_padded"]), f32(batch["gate_padded"])
+    if mel_t.shape != mel.shape or gate_t.shape != gate.shape:
+        raise ValueError(f"target shapes {tuple(mel_t.shape)}, {tuple(gate_t.shape)} do not match the outputs {tuple(mel.shape)}, {tuple(gate.shape)}")
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    scratch = torch.empty(6144, dtype=torch.uint8, device=dev)   # float64 partial sums of the reduction
+    _lib.check(lib.gvx_tacotron2_loss(mel.data_ptr(), post.data_ptr(), gate.data_ptr(), mel_t.data_ptr(), gate_t.data_ptr(),
+                                      B, M, T, out.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                      torch.cuda.current_stream(dev).cuda_stream))
+    return {"loss": out[0], "mel_loss": out[1], "gate_loss": out[2]}

@@ -143,6 +143,17 @@ int gvx_tacotron2_forward(gvx_model* model, const int64_t* tokens, const int32_t
                           float* mel_out, float* mel_post_out, float* gate_out, float* align_out,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Criterion of the evaluation step.  Replaces Tacotron2Loss (models/tts/tacotron2.py:598-615) as called by
+ * Tacotron2.eval_step (:524-529): loss_out[3] (device) = {loss, mel_loss, gate_loss} with
+ *   mel_loss = mean((mel_out - mel_target)^2) + mean((mel_post_out - mel_target)^2)   over all B*n_mels*T elements,
+ *   gate_loss = mean(BCE-with-logits(gate_out, gate_target))                          over all B*T elements,
+ *   loss = mel_loss + gate_loss.
+ * All tensors are the [B, n_mels, T] / [B, T] device arrays of the forward call; forward only (no gradients).
+ * scratch: >= 6144 bytes of device memory, 8-byte aligned (float64 partial sums of the two-stage reduction). */
+int gvx_tacotron2_loss(const float* mel_out, const float* mel_post_out, const float* gate_out, const float* mel_target,
+                       const float* gate_target, int B, int n_mels, int T, float* loss_out, void* scratch, size_t scratch_bytes,
+                       void* stream);
+
 /* ---- Prenet keep-mask generator for callers that do not supply masks (the reference draws them from
  * torch's RNG inside F.dropout, models/tts/tacotron2.py:143).  Writes n bytes of Bernoulli(0.5) {0,1}. */
 int gvx_prenet_masks_generate(uint8_t* masks_out, size_t n, uint64_t seed, void* stream);

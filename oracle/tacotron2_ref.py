@@ -232,3 +232,15 @@ def tacotron2_inference(sd, tokens: torch.Tensor, keep_masks: torch.Tensor, gate
     mel_post = mel_out + postnet(sd, mel_out)
     return {"mel_outputs": mel_out, "mel_outputs_postnet": mel_post,
             "gate_outputs": torch.stack(gates, dim=1), "alignments": torch.stack(aligns, dim=1)}
+
+
+def tacotron2_loss(batch, outputs):
+    """Restates Tacotron2Loss (models/tts/tacotron2.py:598-615): MSE(mel_outputs, target) + MSE(mel_outputs_postnet,
+    target) (means over all B*n_mels*T elements, padding included) + BCE-with-logits(gate_outputs, gate target) (mean
+    over B*T).  float32 tensors in, dict of 0-dim float32 tensors out."""
+    mel_t = batch["mel_padded"].to(torch.float32)
+    gate_t = batch["gate_padded"].to(torch.float32).reshape(-1)
+    mel_loss = ((outputs["mel_outputs"] - mel_t) ** 2).mean() + ((outputs["mel_outputs_postnet"] - mel_t) ** 2).mean()
+    x = outputs["gate_outputs"].reshape(-1)
+    gate_loss = (torch.clamp(x, min=0) - x * gate_t + torch.log1p(torch.exp(-x.abs()))).mean()
+    return {"loss": mel_loss + gate_loss, "mel_loss": mel_loss, "gate_loss": gate_loss}

@@ -40,7 +40,7 @@ import torch.nn.functional as F  # noqa: E402
 
 import configs as ref_configs  # noqa: E402  (reference)
 from configs.models import Tacotron2Config as RefTacotron2Config  # noqa: E402  (reference)
-from models.tts.tacotron2 import Tacotron2 as RefTacotron2  # noqa: E402  (reference)
+from models.tts.tacotron2 import Tacotron2 as RefTacotron2, Tacotron2Loss as RefTacotron2Loss  # noqa: E402  (reference)
 from core.processors import AudioProcessor as RefAudioProcessor  # noqa: E402  (reference)
 from utils.audio import base as ref_audio  # noqa: E402  (reference)
 
@@ -101,9 +101,13 @@ def make_tf_case(name, case):
     chk = torch.relu(torch.relu(x @ w0.t()) * masks[0] * 2 @ w1.t()) * masks[1] * 2
     assert torch.equal(chk, taps["prenet_outputs"]), "mask extraction does not reproduce the reference's Prenet"
 
+    # the reference's criterion on its own outputs (eval_step, models/tts/tacotron2.py:524-529, :598-615)
+    with torch.no_grad():
+        loss = RefTacotron2Loss({k: v.clone() for k, v in batch.items()}, out)
     np.savez_compressed(
         os.path.join(HERE, f"{name}.npz"),
         **{k: v for k, v in inp.items()},
+        loss=np.float32(loss["loss"].item()), mel_loss=np.float32(loss["mel_loss"].item()), gate_loss=np.float32(loss["gate_loss"].item()),
         keep_masks_packed=np.packbits(masks.numpy().reshape(2, -1), axis=1),
         mel_outputs=out["mel_outputs"].numpy(), mel_outputs_postnet=out["mel_outputs_postnet"].numpy(),
         gate_outputs=out["gate_outputs"].numpy(), alignments=out["alignments"].numpy(),

@@ -73,3 +73,14 @@ def test_audio_oracle_matches_reference():
                                         c["log_func"], c["ref"])
     assert fs == int(fx["fs"]) and wav.shape == fx["wav"].shape and wav.dtype == np.float64
     assert max_abs_diff(wav, fx["wav"]) <= 1e-4
+
+
+@pytest.mark.parametrize("name", sorted(TF_CASES))
+def test_oracle_loss_matches_reference_criterion(name):
+    """Tacotron2Loss on the reference's own outputs (fixture values from the reference's criterion)."""
+    fx = load_fixture(name)
+    batch = {"mel_padded": torch.from_numpy(fx["mel_padded"]), "gate_padded": torch.from_numpy(fx["gate_padded"])}
+    outputs = {k: torch.from_numpy(fx[k]) for k in ("mel_outputs", "mel_outputs_postnet", "gate_outputs")}
+    got = tacotron2_ref.tacotron2_loss(batch, outputs)
+    for k in ("loss", "mel_loss", "gate_loss"):
+        assert abs(float(got[k]) - float(fx[k])) <= 2e-6 * max(1.0, abs(float(fx[k]))), k

@@ -99,3 +99,39 @@ def test_c_abi_rejects_bad_arguments_loudly():
     part = m.forward({**{k: v[64:] for k, v in big.items()}, "prenet_keep_masks": masks[:, :, 64:].contiguous()})
     assert whole["mel_outputs"].shape == (B, 80, T)
     assert torch.equal(whole["mel_outputs_postnet"][64:], part["mel_outputs_postnet"])
+
+
+@pytest.mark.parametrize("name", ["tf_small", "tf_full"])
+def test_eval_step_criterion_matches_reference(name):
+    """Tacotron2.eval_step + Tacotron2Loss (models/tts/tacotron2.py:524-529, :598-615): the HIP reduction on the
+    reference's own outputs reproduces the reference criterion's values (fixtures), and eval_step fills
+    loss_items_eval from the GPU forward like the reference does."""
+    from genvox_amd.tacotron2 import Tacotron2Loss
+    from oracle import tacotron2_ref
+    from tests.golden.cases import TF_CASES, case_configs
+    from tests.helpers import case_state_dict, load_fixture, tf_batch, unpack_masks
+
+    case, fx = TF_CASES[name], load_fixture(name)
+    batch = {"mel_padded": torch.from_numpy(fx["mel_padded"]), "gate_padded": torch.from_numpy(fx["gate_padded"])}
+    ref_out = {k: torch.from_numpy(fx[k]).cuda() for k in ("mel_outputs", "mel_outputs_postnet", "gate_outputs")}
+    got = Tacotron2Loss(batch, ref_out)
+    for k in ("loss", "mel_loss", "gate_loss"):
+        assert got[k].shape == () and got[k].dtype == torch.float32
+        assert abs(float(got[k]) - float(fx[k])) <= 2e-6 * max(1.0, abs(float(fx[k]))), k
+    again = Tacotron2Loss(batch, ref_out)
+    assert all(torch.equal(got[k], again[k]) for k in got)   # fixed reduction order
+
+    mc, ac, tc = case_configs(case)
+    m = Tacotron2(mc, ac, tc)
+    m.load_state_dict(case_state_dict(name))
+    m = m.to("cuda:0")
+    masks = unpack_masks(fx["keep_masks_packed"], (2, (case["T"] + 1) * case["B"], mc.prenet_dim))
+    full = {**tf_batch(fx), "prenet_keep_masks": masks}
+    out = m.eval_step(full, m.get_criterion(), None)
+    want = tacotron2_ref.tacotron2_loss({k: v for k, v in full.items()}, {k: v.cpu() for k, v in out.items()})
+    for k in ("loss", "mel_loss", "gate_loss"):
+        assert abs(m.loss_items_eval[k + "_eval"] - float(want[k])) <= 2e-6 * max(1.0, abs(float(want[k])))
+        assert abs(m.loss_items_eval[k + "_eval"] - float(fx[k])) <= 1e-4 * max(1.0, abs(float(fx[k])))   # forward parity carried through
+    assert m.get_eval_priority() == m.loss_items_eval["loss_eval"]
+    with pytest.raises(ValueError):
+        Tacotron2Loss({"mel_padded": batch["mel_padded"][:, :, :-1], "gate_padded": batch["gate_padded"]}, ref_out)

@@ -73,7 +73,7 @@ struct Blob {  // offsets in floats into the packed weight blob
     size_t pre_w0, pre_w1, pre_w0_frag, pre_w1_frag;
     size_t att_frag, att_bias, wq_t, wmem, v, loc_conv, loc_dense;
     size_t dec_frag, dec_bias;
-    size_t proj_w, proj_b, proj_frag;
+    size_t proj_w, proj_b, proj_frag, proj_hd_t, proj_ctx_frag;   // last two: autoregressive split of the projection (see gvx_decoder_autoregressive)
     size_t post_w[MAX_CONV], post_b[MAX_CONV];
     size_t total;
 };
@@ -82,7 +82,7 @@ inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 
 
 struct WsPlan {  // byte offsets into the caller's workspace
     size_t xa, xb, xg, enc_h, enc_c, flags, memory;
-    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy, loc, ar_masks;
+    size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy, loc, ar_masks, p_slab, p_ctx;
     size_t ya, yb;
     size_t total;
 };
@@ -162,6 +162,8 @@ Blob make_blob_layout(const gvx_dims& d) {
     b.dec_frag = take(frag_floats(4 * D, A + E + D)); b.dec_bias = take((size_t)4 * D);
     b.proj_w = take((size_t)(M + 1) * (D + E)); b.proj_b = take(M + 1);
     b.proj_frag = take(frag_floats(M + 1, D + E));
+    b.proj_hd_t = take((size_t)D * ((M + 1 + 7) & ~7));
+    b.proj_ctx_frag = take(frag_floats(M + 1, E));
     for (int i = 0; i < d.postnet_n_conv; ++i) {
         const int cin = i == 0 ? M : d.postnet_dim, cout = i == d.postnet_n_conv - 1 ? M : d.postnet_dim;
         b.post_w[i] = take((size_t)cout * d.postnet_kernel * cin);
@@ -201,6 +203,8 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.energies = take((size_t)B * L);
     w.align_tm = take((size_t)T * B * L);   // alignments of the step loop, time-major [T][B][L]
     w.loc = take((size_t)B * L * d.att_dim);  // location features of the current step
+    w.p_slab = take((size_t)(D / 8) * B * m->PSB());   // autoregressive mode: projection partials of the decoder-LSTM tiles
+    w.p_ctx = take((size_t)B * m->PSB());            //   and of the context columns (blocked vector)
     w.ar_masks = take(((size_t)2 * T * B * P + 3) / 4);  // autoregressive mode: keep masks copied next to the graphs' operands (bytes)
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
@@ -444,6 +448,16 @@ int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, vo
         std::memcpy(w.data() + (size_t)M * K, src, sizeof(float) * K);
         std::memcpy(out + bl.proj_w, w.data(), sizeof(float) * w.size());
         pack_frag(w, M + 1, K, out + bl.proj_frag);
+        // autoregressive mode: the h_d columns tile-major [D/8][PSB][8] (rows past M are zero) for the partial products the
+        // decoder-LSTM tiles emit, the context columns as their own fragment matrix
+        const int PSBp = (M + 1 + 7) & ~7;
+        for (int t = 0; t < D / 8; ++t)
+            for (int n = 0; n < PSBp; ++n)
+                for (int jj = 0; jj < 8; ++jj)
+                    out[bl.proj_hd_t + ((size_t)t * PSBp + n) * 8 + jj] = n <= M ? w[(size_t)n * K + t * 8 + jj] : 0.f;
+        std::vector<float> wc((size_t)(M + 1) * E);
+        for (int n = 0; n <= M; ++n) std::memcpy(&wc[(size_t)n * E], &w[(size_t)n * K + D], sizeof(float) * E);
+        pack_frag(wc, M + 1, E, out + bl.proj_ctx_frag);
         if (!(src = wt.get("decoder.linear_projection.linear_layer.bias", M, &rc))) return rc;
         std::memcpy(out + bl.proj_b, src, sizeof(float) * M);
         if (!(src = wt.get("decoder.gate_layer.linear_layer.bias", 1, &rc))) return rc;
@@ -577,7 +591,7 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
 }
 
 struct DecoderBuffers {
-    float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj, *energies, *align_tm, *loc;
+    float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj, *energies, *align_tm, *loc, *p_slab, *p_ctx;
     int32_t* len_copy;
 };
 
@@ -589,6 +603,7 @@ DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
     b.q_slab = ws_ptr<float>(ws, wp.q_slab); b.proj = ws_ptr<float>(ws, wp.proj); b.energies = ws_ptr<float>(ws, wp.energies);
     b.align_tm = ws_ptr<float>(ws, wp.align_tm); b.len_copy = ws_ptr<int32_t>(ws, wp.len_copy);
     b.loc = ws_ptr<float>(ws, wp.loc);
+    b.p_slab = ws_ptr<float>(ws, wp.p_slab); b.p_ctx = ws_ptr<float>(ws, wp.p_ctx);
     return b;
 }
 
@@ -1006,7 +1021,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     HIP_TRY(zero_async(flags + 1, (size_t)127 * sizeof(int32_t), s));   // n_done + frame counts
 
     // one step = Prenet (2 GEMVs) -> attention LSTM (+ location features) -> attention energy / context -> decoder LSTM
-    // -> mel/gate projection (+ per-row stop test in its epilogue); db.proj holds one blocked projection vector [PSB/8][B][8] per step
+    // (+ projection partials) -> projection reduction + per-row stop test; db.proj holds one blocked projection vector [PSB/8][B][8] per step
     auto enqueue_steps = [&](hipStream_t st, int t0, int t1) -> int {
         for (int t = t0; t < t1; ++t) {
             float* proj_t = db.proj + (size_t)t * B * PSB;
@@ -1032,16 +1047,20 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
             AttnParams ap;
             fill_attn(m, ap, memory_ws, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
             HIP_TRY(launch_attention(ap, st));
-            fill_dec_job(m, lj, t, B, db);
-            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, st));
-            std::memset(&job, 0, sizeof job);
-            job.Wp = m->dev_blob + m->blob.proj_frag; job.bias = m->dev_blob + m->blob.proj_b;
-            job.x[0] = XSeg{db.hc + (size_t)(t + 1) * B * (D + E), D + E};
-            job.N = M + 1; job.nkg = (D + E) / 8; job.mode = 1; job.B = B; job.act = ACT_NONE;
-            job.y = proj_t;
-            job.stop_n_frames = n_frames_ws; job.stop_n_done = n_done;   // per-row stop test in the projection's epilogue
-            job.stop_col = M; job.stop_step = t; job.stop_threshold = gate_threshold;
-            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, st));
+            // decoder LSTM.  The mel/gate projection of [h_d ; ctx] rides along instead of being a 3-workgroup launch of its
+            // own (17.8 us at batch 64): every LSTM tile emits the partial products of its 8 hidden units (the attention-query
+            // slab mechanism with the projection's h_d columns), three extra workgroups of the same launch project the
+            // context, which is known before the launch; a small reduction adds the 128 + 1 partials in a fixed order.
+            SkinnyJob dj[2];
+            fill_dec_job(m, dj[0], t, B, db);
+            dj[0].Wq_t = m->dev_blob + m->blob.proj_hd_t; dj[0].q_slab = db.p_slab; dj[0].att_dim = PSB;
+            std::memset(&dj[1], 0, sizeof dj[1]);
+            dj[1].Wp = m->dev_blob + m->blob.proj_ctx_frag; dj[1].bias = m->dev_blob + m->blob.proj_b;
+            dj[1].x[0] = XSeg{db.hc + (size_t)(t + 1) * B * (D + E) + (size_t)D * B, E};
+            dj[1].N = M + 1; dj[1].nkg = E / 8; dj[1].mode = 1; dj[1].B = B; dj[1].act = ACT_NONE;
+            dj[1].y = db.p_ctx;
+            HIP_TRY(launch_skinny(dj, 2, SK_DECODER, st));
+            HIP_TRY(launch_ar_project(db.p_slab, D / 8, db.p_ctx, proj_t, M, gate_threshold, t, B, n_frames_ws, n_done, st));
         }
         return GVX_OK;
     };

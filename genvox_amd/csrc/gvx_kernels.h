@@ -84,9 +84,6 @@ struct SkinnyJob {
     const uint8_t* keep; long keep_stride;  // keep[b*stride + n]
     int act;
     int B;
-    // autoregressive stop test fused into the projection job (models/tts/tacotron2.py:405-409): the lane that produces output
-    // row stop_col (the gate logit) of batch row b marks the row finished at step stop_step when sigmoid(gate) > threshold
-    int32_t* stop_n_frames; int32_t* stop_n_done; int stop_col; int stop_step; float stop_threshold;   // stop_n_frames = nullptr: off
 };
 // Location features of the NEXT attention step, computed by extra workgroups of the decoder LSTM launch (which is
 // memory bound and leaves VALU/LDS idle): loc[b][l][:] = Wd * conv1d_k([w_prev ; w_cum])[l].  They depend only on the
@@ -154,6 +151,10 @@ hipError_t launch_mask_gen(uint8_t* out, size_t n, uint64_t seed, hipStream_t s)
 // AR: gate logits of step t (blocked projection vector) -> per-row finished flags / frame counts / all-finished counter
 hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, int t, int B,
                           int32_t* n_frames, int32_t* n_done, hipStream_t s);
+// AR: proj_t (blocked [PSB/8][B][8]) = sum over the n_slabs partial slabs [slab][B][PSB] (ascending) + p_ctx (blocked, bias
+// included), rows n <= M; the gate row also runs the per-row stop test of launch_ar_stop
+hipError_t launch_ar_project(const float* p_slab, int n_slabs, const float* p_ctx, float* proj_t, int M, float threshold, int t, int B,
+                             int32_t* n_frames, int32_t* n_done, hipStream_t s);
 // AR: scatter the blocked per-step projections proj[t][PSB/8][B][8], t < steps, into mel_out [B][M][Tmax], gate_out [B][Tmax]
 hipError_t launch_ar_emit_all(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, hipStream_t s);
 // dst[b][t][:] = src[t][b][:] for t < steps, dst rows have Tdst time slots

@@ -214,6 +214,46 @@ hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, in
     return hipGetLastError();
 }
 
+// thread = (b, n): consecutive threads read consecutive floats of a slab row
+__global__ __launch_bounds__(256) void ar_project_kernel(const float* __restrict__ p_slab, int n_slabs, const float* __restrict__ p_ctx,
+                                                         float* __restrict__ proj_t, int M, int PSB, float threshold, int t, int B,
+                                                         int32_t* n_frames, int32_t* n_done) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * PSB) return;
+    const int b = idx / PSB, n = idx - b * PSB;
+    if (n > M) return;
+    const long blocked = (long)(n >> 3) * B * 8 + b * 8 + (n & 7);
+    const float* sp = p_slab + (long)b * PSB + n;
+    const long sstride = (long)B * PSB;
+    float acc = 0.f;
+    int sl = 0;
+    for (; sl + 8 <= n_slabs; sl += 8) {   // 8 loads in flight, added in ascending slab order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = sp[(long)(sl + q) * sstride];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    for (; sl < n_slabs; ++sl) acc += sp[(long)sl * sstride];
+    const float v = acc + p_ctx[blocked];
+    proj_t[blocked] = v;
+    if (n == M && n_frames[b] == 0) {      // gate logit: models/tts/tacotron2.py:405-409
+        const float sg = 1.f / (1.f + expf(-v));
+        if (sg > threshold) {
+            n_frames[b] = t + 1;
+            atomicAdd(n_done, 1);
+        }
+    }
+}
+
+hipError_t launch_ar_project(const float* p_slab, int n_slabs, const float* p_ctx, float* proj_t, int M, float threshold, int t, int B,
+                             int32_t* n_frames, int32_t* n_done, hipStream_t s) {
+    const int PSB = (M + 1 + 7) & ~7;
+    hipLaunchKernelGGL(ar_project_kernel, dim3((B * PSB + 255) / 256), dim3(256), 0, s, p_slab, n_slabs, p_ctx, proj_t, M, PSB, threshold, t, B,
+                       n_frames, n_done);
+    return hipGetLastError();
+}
+
 __global__ void ar_emit_all_kernel(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, int PSB) {
     // thread = (b, m); loops over time so that writes along t are contiguous per thread row
     const int b = blockIdx.y;

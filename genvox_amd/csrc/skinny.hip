@@ -351,13 +351,6 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                         else if (J.act == ACT_TANH) v = tanhf(v);
                         if (J.keep) v = J.keep[(long)b * J.keep_stride + nn] ? 2.f * v : 0.f;
                         J.y[(long)(nn >> 3) * blk + b * 8 + (nn & 7)] = v;  // blocked output
-                        if (J.stop_n_frames && nn == J.stop_col && J.stop_n_frames[b] == 0) {
-                            const float sg = 1.f / (1.f + expf(-v));   // same expression as ar_stop_kernel (misc.hip)
-                            if (sg > J.stop_threshold) {
-                                J.stop_n_frames[b] = J.stop_step + 1;
-                                atomicAdd(J.stop_n_done, 1);
-                            }
-                        }
                     }
                 }
             }

@@ -110,17 +110,6 @@ struct gvx_model {
     std::vector<std::pair<LoopKey, hipGraphExec_t>> loop_graphs;
     std::vector<std::pair<LoopKey, hipGraphExec_t>> enc_graphs;   // encoder recurrence (key.memory = output, key.T = 0)
     hipStream_t cap_stream = nullptr;  // private stream used only to record captures (the caller's may be the null stream)
-    hipStream_t cap_stream2 = nullptr; // second capture stream: the decoder-LSTM branch of the step graph
-    std::vector<hipEvent_t> gev;       // fork/join events used while capturing (no timing)
-    bool fork_dec = false;             // GVX_FORK=1: experimental two-branch graph (measured 45 ms vs 30 ms: cross-stream edges are expensive)
-    int reserve_graph_events(size_t n) {
-        while (gev.size() < n) {
-            hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return GVX_ERR_HIP;
-            gev.push_back(e);
-        }
-        return GVX_OK;
-    }
     bool use_graph = true;
     // per-launch timing of the decoder step kernels (measurement only)
     bool ktiming = false;
@@ -342,7 +331,6 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     m->d = *dims;
     m->blob = make_blob_layout(*dims);
     if (const char* e = std::getenv("GVX_NO_GRAPH")) m->use_graph = !(e[0] == '1');
-    if (const char* e = std::getenv("GVX_FORK")) m->fork_dec = (e[0] == '1');
     *out = m;
     return GVX_OK;
 }
@@ -356,8 +344,6 @@ void gvx_model_destroy(gvx_model* m) {
     for (auto& g : m->enc_graphs) (void)hipGraphExecDestroy(g.second);
     for (auto& g : m->ar_graphs) (void)hipGraphExecDestroy(g.second);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-    if (m->cap_stream2) (void)hipStreamDestroy(m->cap_stream2);
-    for (auto& e : m->gev) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -748,45 +734,11 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         ++launches;
         return GVX_OK;
     };
-    // Forked schedule (graph only): decoder-LSTM(t) does not feed the next step's attention-LSTM, so it runs on a second
-    // captured stream and overlaps attention-LSTM(t+1) / attention(t+1); only attention-LSTM -> energies -> context is
-    // on the critical chain.  Edges: dec(t) after context(t) [ctx, h_a(t)] and dec(t-1) [stream order]; att(t) after
-    // dec(t-2), whose input buffer h_a[(t+1)&1] att(t) overwrites; final join before the projection.
-    auto enqueue_forked = [&](hipStream_t sa, hipStream_t sb) -> int {
-        int rcf = m->reserve_graph_events(2 * (size_t)T + 2);
-        if (rcf != GVX_OK) return rcf;
-        hipEvent_t* ev_ctx = m->gev.data();
-        hipEvent_t* ev_dec = m->gev.data() + T + 1;
-        for (int t = 0; t < T; ++t) {
-            if (t >= 2) HIP_TRY(hipStreamWaitEvent(sa, ev_dec[t - 2], 0));
-            SkinnyJob job;
-            fill_att_job(m, job, db.prenet + (size_t)t * B * P, t, B, db);
-            LocJob lq;
-            fill_loc(m, lq, t, B, L, db.align_tm, (long)L, (long)B * L, db);
-            HIP_TRY(launch_skinny(&job, 1, SK_DECODER, sa, &lq));
-            AttnParams ap;
-            fill_attn(m, ap, memory, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
-            HIP_TRY(launch_attention(ap, sa));
-            HIP_TRY(hipEventRecord(ev_ctx[t], sa));
-            HIP_TRY(hipStreamWaitEvent(sb, ev_ctx[t], 0));
-            fill_dec_job(m, job, t, B, db);
-            HIP_TRY(launch_skinny(&job, 1, SK_DECODER, sb));
-            HIP_TRY(hipEventRecord(ev_dec[t], sb));
-        }
-        HIP_TRY(hipStreamWaitEvent(sa, ev_dec[T - 1], 0));
-        launches = 4 * T;
-        return GVX_OK;
-    };
     if (m->use_graph && !kt) {
         const gvx_model::LoopKey key{ws, memory, B, L, T, lengths != nullptr};
-        if (m->fork_dec) {
-            if (!m->cap_stream2) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream2, hipStreamNonBlocking));
-            rc = run_cached_graph(m, m->loop_graphs, key, 8, s, [&](hipStream_t st) { return enqueue_forked(st, m->cap_stream2); });
-        } else {
-            rc = run_cached_graph(m, m->loop_graphs, key, 8, s, enqueue_loop);
-        }
+        rc = run_cached_graph(m, m->loop_graphs, key, 8, s, enqueue_loop);
         if (rc != GVX_OK) return rc;
-        launches = m->fork_dec ? 4 * T : 3 * T + 1;
+        launches = 3 * T + 1;
     } else {
         rc = enqueue_loop(s);
         if (rc != GVX_OK) return rc;

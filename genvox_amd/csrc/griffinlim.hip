@@ -636,6 +636,52 @@ __global__ __launch_bounds__(GLF_FRAMES * 64) void gl_forward_update_kernel(cons
     }
 }
 
+// frames of a signal -> |rfft(win * frame)| into rows padded to kp floats (kp >= 513, pad = 0): the magnitude input of the
+// mel GEMM (convert_wav2mel: stft + abs, core/processors.py:70-79) without the framed-signal and complex-spectrum round trips
+__global__ __launch_bounds__(GLF_FRAMES * 64) void stft_magnitude_kernel(const float* __restrict__ x, long n_samples, const float* __restrict__ win,
+                                                                         const float2* __restrict__ tw, float* __restrict__ mag, int kp,
+                                                                         int T, long frames) {
+    __shared__ __attribute__((aligned(16))) float2 fsm[GLF_FRAMES * FPAD];
+    const int tid = threadIdx.x, j = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long f = (long)blockIdx.x * GLF_FRAMES + wave;
+    const bool valid = f < frames;
+    float2* buf = fsm + wave * FPAD;
+    float2 v[8];
+    if (valid) {
+        const int b = (int)(f / T), t = (int)(f - (long)b * T);
+        const float* xb = x + (long)b * n_samples + (long)t * 256;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n2 = 2 * (j + 64 * r);
+            const float2 w = *reinterpret_cast<const float2*>(win + n2);
+            v[r] = make_float2(w.x * xb[n2], w.y * xb[n2 + 1]);   // rows need not be 8-byte aligned (n_samples is arbitrary)
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
+    }
+    fft512_wave<false>(v, buf, tw, j, true);
+    wave_lds_fence();
+    if (!valid) return;
+    const float2* tw2 = tw + FN;
+    float* row = mag + f * kp;
+    for (int k = j; k < kp; k += 64) {
+        float out = 0.f;
+        if (k <= 512) {
+            const float2 zk = buf[fpad(k & (FN - 1))];
+            float2 zc = buf[fpad((512 - k) & (FN - 1))];
+            zc.y = -zc.y;
+            const float2 sm = cadd(zk, zc), df = csub(zk, zc);
+            const float2 wd = cmul(tw2[k], df);
+            float2 X = make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
+            if (k == 0 || k == 512) X.y = 0.f;
+            out = hypotf(X.x, X.y);
+        }
+        row[k] = out;
+    }
+}
+
 bool getenv_flag(const char* name) {
     const char* e = std::getenv(name);
     return e && e[0] == '1';
@@ -899,14 +945,20 @@ int gvx_wav_to_mel(gvx_gl_plan* p, const float* signal, const float* window, con
     // workspace reuse: fr = framed signal, reb0 = spectrum, ang = padded magnitudes, reb1 = padded basis, amp = mel amplitudes
     if ((size_t)frames * kp * sizeof(float) > (size_t)frames * p->bins * sizeof(float2) || (size_t)n_mels * kp > (size_t)frames * p->bins * 2)
         return gl_fail(GVX_ERR_WORKSPACE, "workspace regions too small for the padded operands");
-    gl_frame_kernel<<<dim3((unsigned)frames), 256, 0, s>>>(signal, window, wsp<float>(ws, w.fr), p->n_fft, p->hop, T, n_samples);
-    GL_HIP(hipGetLastError());
-    rc = run_fft(p, fp->r2c, wsp<float>(ws, w.fr), wsp<float2>(ws, w.reb0), wsp<char>(ws, w.fft_work), fp->work_bytes, s);
-    if (rc != GVX_OK) return rc;
     float* mag_p = wsp<float>(ws, w.ang);
     float* basis_p = wsp<float>(ws, w.reb1);
-    magnitude_kernel<<<blocks_for(frames * kp), 256, 0, s>>>(wsp<float2>(ws, w.reb0), mag_p, p->bins, kp, frames);
-    GL_HIP(hipGetLastError());
+    if (p->tw && !getenv_flag("GVX_GL_ROCFFT")) {   // n_fft 1024 / hop 256: framing + window + FFT + magnitude in one kernel
+        stft_magnitude_kernel<<<dim3((unsigned)((frames + GLF_FRAMES - 1) / GLF_FRAMES)), GLF_FRAMES * 64, 0, s>>>(
+            signal, n_samples, window, p->tw, mag_p, kp, T, frames);
+        GL_HIP(hipGetLastError());
+    } else {
+        gl_frame_kernel<<<dim3((unsigned)frames), 256, 0, s>>>(signal, window, wsp<float>(ws, w.fr), p->n_fft, p->hop, T, n_samples);
+        GL_HIP(hipGetLastError());
+        rc = run_fft(p, fp->r2c, wsp<float>(ws, w.fr), wsp<float2>(ws, w.reb0), wsp<char>(ws, w.fft_work), fp->work_bytes, s);
+        if (rc != GVX_OK) return rc;
+        magnitude_kernel<<<blocks_for(frames * kp), 256, 0, s>>>(wsp<float2>(ws, w.reb0), mag_p, p->bins, kp, frames);
+        GL_HIP(hipGetLastError());
+    }
     pad_rows_kernel<<<blocks_for((long)n_mels * kp), 256, 0, s>>>(mel_basis, basis_p, n_mels, p->bins, kp);
     GL_HIP(hipGetLastError());
     // fft2mel (utils/audio/base.py:139-141): mel_t[(b,t)][m] = sum_k basis[m][k] * |S|[(b,t)][k]

@@ -68,6 +68,12 @@ def main():
                                             "utterances_per_s": round(B / dt, 1)}
         dt2 = timed(lambda: ap.convert_mel2wav_batch(mel, n_iter=32), warm=1, reps=2)
         res["convert_mel2wav_b256x800_32it"] = {"ms": round(dt2 * 1e3, 1), "utterances_per_s": round(B / dt2, 1)}
+        sig = torch.rand(B, 1024 + (T - 1) * 256, device="cuda") * 2 - 1
+        dt3 = timed(lambda: ap.wav_to_mel(sig), warm=1, reps=3)
+        os.environ["GVX_GL_ROCFFT"] = "1"
+        dt4 = timed(lambda: ap.wav_to_mel(sig), warm=1, reps=3)
+        del os.environ["GVX_GL_ROCFFT"]
+        res["wav_to_mel_b256x800"] = {"ms": round(dt3 * 1e3, 2), "frames_per_s": round(B * T / dt3), "ms_rocfft_pipeline": round(dt4 * 1e3, 2)}
     print(json.dumps(res, indent=1))
 
 

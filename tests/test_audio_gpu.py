@@ -200,3 +200,19 @@ def test_fused_griffin_lim_matches_rocfft_pipeline(ap, B, T, monkeypatch):
         for b in range(B):   # edge samples are divided by a ~1e-10 window sum: compare weighted (see istft_error)
             assert istft_error(wf[b], wr[b], 1024, 256) <= tol * max(float(np.abs(wr[b]).max()), 1.0) * 10, (n_iter, "wav", b)
         assert weighted_phase_diff(ph_f.cpu().numpy(), ph_r.cpu().numpy(), mag) <= tol * 50, (n_iter, "phase")
+
+
+def test_other_fft_size_uses_rocfft_pipeline_and_matches_oracle():
+    """n_fft 512 / hop 128 has no fused kernels: the rocFFT pipeline serves it; two Griffin-Lim iterations and the
+    final iSTFT against the oracle (utils/audio/base.py:147-162, :71-88)."""
+    n_fft, hop, T = 512, 128, 37
+    ap2 = AudioProcessor(AudioConfig(sampling_rate=22050, filter_length=n_fft, hop_length=hop, n_mels=80, mel_fmin=0.0,
+                                     mel_fmax=8000.0, log_func="np.log", ref_level_db=1.0))
+    rng = np.random.default_rng(9)
+    mag = np.abs(rng.standard_normal((n_fft // 2 + 1, T))).astype(np.float32)
+    phase, wav = ap2.griffin_lim(torch.from_numpy(mag)[None], n_iter=2)
+    phase = phase.cpu().numpy()[0]
+    want = audio_ref.griffin_lim(mag, n_fft, hop, n_iter=2)
+    assert weighted_phase_diff(phase, want, mag) <= 1e-3
+    spec = (mag * (np.cos(phase) + 1j * np.sin(phase))).astype(np.complex64)
+    assert istft_error(wav.cpu().numpy()[0], audio_ref.istft(spec, n_fft, hop), n_fft, hop) <= 1e-4

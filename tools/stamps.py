@@ -26,7 +26,7 @@ lib = C.CDLL(_lib.LIB_PATH)
 buf = (C.c_ulonglong * 96)()
 assert lib.gvx_debug_read_stamps(buf) == 0
 names = {0: ["start", "mainloop done", "red synced", "cell done", "qslab done"],
-         1: ["start", "q issued+summed", "staged wc/cw", "wd loaded+sync", "pm issued", "conv done", "energies done", "reduced"],
+         1: ["start", "loads issued", "q summed + synced", "tanh partials done", "reduced + stored"],
          2: ["start", "softmax done", "ctx partial", "ctx written"]}
 for k, title in enumerate(["decoder_lstm_step (wg 0)", "attn_energy (wg 0,0)", "attn_context (wg 0,0)"]):
     v = [buf[k * 32 + i] for i in range(len(names[k]))]
@@ -40,7 +40,9 @@ lib2 = C.CDLL(_lib.LIB_PATH)
 raw = (C.c_ulonglong * 96)()
 lib2.gvx_debug_read_stamps_skinny.argtypes = [C.c_void_p]
 if lib2.gvx_debug_read_stamps_skinny(raw) == 0:
-    t0 = raw[0]
     for row, nm in ((1, "attention-LSTM tile 0"), (2, "decoder-LSTM tile 0")):
+        # row 2 carries its own reference: block 0's start stamp of the launch the decoder tile ran in (slot 7); the last
+        # launch of a sequence has decoder tiles only, so row 0 may belong to a different launch
+        t0 = raw[2 * 32 + 7] if row == 2 else raw[0]
         ends = [(raw[row * 32 + 8 + w] - t0) * 10 for w in range(8)]
         print(f"{nm}: per-wave main-loop end (ns after block 0 start): {ends}  spread {max(ends) - min(ends)} ns")

@@ -74,6 +74,32 @@ def main():
         dt4 = timed(lambda: ap.wav_to_mel(sig), warm=1, reps=3)
         del os.environ["GVX_GL_ROCFFT"]
         res["wav_to_mel_b256x800"] = {"ms": round(dt3 * 1e3, 2), "frames_per_s": round(B * T / dt3), "ms_rocfft_pipeline": round(dt4 * 1e3, 2)}
+    if "cpu" in which:
+        # CPU baselines for configs 3 and 4 (the oracle = CPU restatement of the reference, on this box's host cores):
+        # bounded samples, reported beside the GPU figures above; bench.py carries the one for config 2.
+        import numpy as np
+
+        from oracle import audio_ref, tacotron2_ref
+
+        n_thr = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+        torch.set_num_threads(n_thr)
+        sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+        steps, L = 40, 128
+        tok = torch.from_numpy(gw.synthetic_inputs(1, L, 8, 40, 80, seed=3)["token_padded"])
+        masks = torch.from_numpy(gw.prenet_keep_masks(steps, mc.prenet_dim, seed=11)).reshape(2, steps, mc.prenet_dim)
+        t0 = time.perf_counter()
+        tacotron2_ref.tacotron2_inference(sd, tok, masks, gate_threshold=1.0, max_decoder_steps=steps)
+        dt = time.perf_counter() - t0
+        res["cpu_autoregressive_b1"] = {"us_per_step": round(dt / steps * 1e6, 1), "rtf_per_utterance_stream": round(dt / steps / (ac.hop_length / ac.sampling_rate), 4),
+                                        "cores": n_thr, "sample": f"oracle Tacotron2.inference, batch 1 (the reference's only autoregressive mode), {steps} steps incl. encoder"}
+        T, it = 200, 8
+        mag = np.abs(np.random.default_rng(0).standard_normal((513, T))).astype(np.float32)
+        t0 = time.perf_counter()
+        audio_ref.griffin_lim(mag, 1024, 256, n_iter=it)
+        dt = time.perf_counter() - t0
+        per_frame_it = dt / (T * it)
+        res["cpu_griffin_lim"] = {"frames_per_s_at_60it": round(1.0 / (per_frame_it * 60)), "cores": 1,
+                                  "sample": f"oracle griffin_lim (numpy, per-frame loops like the reference), {T} frames x {it} iterations, scaled to 60"}
     print(json.dumps(res, indent=1))
 
 

@@ -30,7 +30,7 @@ def main():
     which = set(sys.argv[1:]) or {"tf64", "ar", "postnet", "gl"}
     mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, hop_length=256, log_func="np.log"), TextConfig(n_tokens=40)
     res = {}
-    if which & {"tf64", "ar", "postnet"}:
+    if which & {"tf64", "ar", "ar1", "postnet"}:
         model = Tacotron2(mc, ac, tc)
         model.load_state_dict(gw.generate_state_dict(mc, ac, tc, seed=0))
         model = model.to("cuda:0")
@@ -50,6 +50,13 @@ def main():
                                                "rtf_aggregate": round(dt / (audio_s * B), 6),
                                                "mel_frames_per_s": round(B * mc.max_decoder_steps / dt)}
         mc.gate_threshold = 0.5
+    if "ar1" in which:   # the reference's own autoregressive shape: one utterance
+        mc.gate_threshold = 1.0
+        tok = torch.from_numpy(gw.synthetic_inputs(1, 128, 8, 40, 80, seed=3)["token_padded"]).cuda()
+        dt = timed(lambda: model.inference({"tokens": tok}), warm=1, reps=2)
+        audio_s = mc.max_decoder_steps * ac.hop_length / ac.sampling_rate
+        res["autoregressive_b1_1000steps"] = {"ms": round(dt * 1e3, 1), "us_per_step": round(dt / mc.max_decoder_steps * 1e6, 1),
+                                              "rtf": round(dt / audio_s, 5)}
     if "postnet" in which:
         B, T = 256, 800
         mel = torch.randn(64, 80, T, device="cuda")

@@ -70,7 +70,7 @@ struct Blob {  // offsets in floats into the packed weight blob
     size_t emb;
     size_t enc_w[MAX_CONV], enc_b[MAX_CONV];
     size_t enc_wih, enc_bih, enc_whh_frag[2];
-    size_t pre_w0, pre_w1, pre_w0_frag, pre_w1_frag;
+    size_t pre_w0, pre_w1, pre_w0_frag, pre_w1_frag, pre_w0_t;
     size_t att_frag, att_bias, wq_t, wmem, v, loc_conv, loc_dense;
     size_t dec_frag, dec_bias;
     size_t proj_w, proj_b, proj_frag, proj_hd_t, proj_ctx_frag;   // last two: autoregressive split of the projection (see gvx_decoder_autoregressive)
@@ -143,6 +143,7 @@ Blob make_blob_layout(const gvx_dims& d) {
     for (int dir = 0; dir < 2; ++dir) b.enc_whh_frag[dir] = take(frag_floats(4 * H, H));
     b.pre_w0 = take((size_t)P * M); b.pre_w1 = take((size_t)P * P);
     b.pre_w0_frag = take(frag_floats(P, M)); b.pre_w1_frag = take(frag_floats(P, P));
+    b.pre_w0_t = take((size_t)M * P);   // transposed, for the autoregressive Prenet layer 1 inside ar_project_kernel
     b.att_frag = take(frag_floats(4 * A, P + E + A)); b.att_bias = take((size_t)4 * A);
     b.wq_t = take((size_t)A * d.att_dim);
     b.wmem = take((size_t)d.att_dim * E); b.v = take(d.att_dim);
@@ -389,6 +390,8 @@ int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, vo
         if (!(src = wt.get("decoder.prenet.layers.0.linear_layer.weight", (int64_t)P * M, &rc))) return rc;
         std::memcpy(out + bl.pre_w0, src, sizeof(float) * P * M);
         pack_frag(std::vector<float>(src, src + (size_t)P * M), P, M, out + bl.pre_w0_frag);
+        for (int j = 0; j < P; ++j)
+            for (int k = 0; k < M; ++k) out[bl.pre_w0_t + (size_t)k * P + j] = src[(size_t)j * M + k];
         if (!(src = wt.get("decoder.prenet.layers.1.linear_layer.weight", (int64_t)P * P, &rc))) return rc;
         std::memcpy(out + bl.pre_w1, src, sizeof(float) * P * P);
         pack_frag(std::vector<float>(src, src + (size_t)P * P), P, P, out + bl.pre_w1_frag);
@@ -969,22 +972,18 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     }
     rc = decoder_init_states(m, memory_ws, B, L, db, s);
     if (rc != GVX_OK) return rc;
-    HIP_TRY(zero_async(db.frames, (size_t)B * M * sizeof(float), s));   // go-frame
+    HIP_TRY(zero_async(db.pre1, (size_t)B * P * sizeof(float), s));    // Prenet layer 1 of the go-frame: relu(W0 * 0) = 0
     HIP_TRY(zero_async(flags + 1, (size_t)127 * sizeof(int32_t), s));   // n_done + frame counts
 
-    // one step = Prenet (2 GEMVs) -> attention LSTM (+ location features) -> attention energy / context -> decoder LSTM
+    // one step = Prenet layer 2 (layer 1 rides in the previous step's projection kernel) -> attention LSTM (+ location features) -> attention energy / context -> decoder LSTM
     // (+ projection partials) -> projection reduction + per-row stop test; db.proj holds one blocked projection vector [PSB/8][B][8] per step
     auto enqueue_steps = [&](hipStream_t st, int t0, int t1) -> int {
         for (int t = t0; t < t1; ++t) {
             float* proj_t = db.proj + (size_t)t * B * PSB;
             SkinnyJob job;
             std::memset(&job, 0, sizeof job);
-            job.Wp = m->dev_blob + m->blob.pre_w0_frag;   // Prenet on the previous mel frame (tacotron2.py:398)
-            job.x[0] = XSeg{t == 0 ? db.frames : db.proj + (size_t)(t - 1) * B * PSB, M};
-            job.N = P; job.nkg = M / 8; job.mode = 1; job.B = B; job.act = ACT_RELU;
-            job.y = db.pre1;
-            job.keep = masks_ws + (size_t)t * B * P; job.keep_stride = P;
-            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, st));
+            // Prenet layer 1 of this step was computed by the previous step's projection kernel (zeros for the go-frame)
+            job.N = P; job.mode = 1; job.B = B; job.act = ACT_RELU; job.keep_stride = P;
             job.Wp = m->dev_blob + m->blob.pre_w1_frag;
             job.x[0] = XSeg{db.pre1, P};
             job.nkg = P / 8;
@@ -1012,7 +1011,9 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
             dj[1].N = M + 1; dj[1].nkg = E / 8; dj[1].mode = 1; dj[1].B = B; dj[1].act = ACT_NONE;
             dj[1].y = db.p_ctx;
             HIP_TRY(launch_skinny(dj, 2, SK_DECODER, st));
-            HIP_TRY(launch_ar_project(db.p_slab, D / 8, db.p_ctx, proj_t, M, gate_threshold, t, B, n_frames_ws, n_done, st));
+            const uint8_t* keep_next = t + 1 < T ? masks_ws + (size_t)(t + 1) * B * P : nullptr;   // layer-1 masks of step t+1
+            HIP_TRY(launch_ar_project(db.p_slab, D / 8, db.p_ctx, proj_t, M, gate_threshold, t, B, n_frames_ws, n_done,
+                                      m->dev_blob + m->blob.pre_w0_t, P, keep_next, db.pre1, st));
         }
         return GVX_OK;
     };

@@ -151,10 +151,11 @@ hipError_t launch_mask_gen(uint8_t* out, size_t n, uint64_t seed, hipStream_t s)
 // AR: gate logits of step t (blocked projection vector) -> per-row finished flags / frame counts / all-finished counter
 hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, int t, int B,
                           int32_t* n_frames, int32_t* n_done, hipStream_t s);
-// AR: proj_t (blocked [PSB/8][B][8]) = sum over the n_slabs partial slabs [slab][B][PSB] (ascending) + p_ctx (blocked, bias
-// included), rows n <= M; the gate row also runs the per-row stop test of launch_ar_stop
+// AR: proj_t (blocked [PSB/8][B][8]) = sum over the n_slabs partial slabs [slab][B][PSB] (fixed order) + p_ctx (blocked, bias
+// included), rows n <= M; the gate row also runs the per-row stop test of launch_ar_stop; then, unless keep == nullptr,
+// Prenet layer 1 of the next step: pre1 (blocked [P/8][B][8]) = 2 * keep[b][j] * relu(W0 mel), w0t = W0 transposed [M][P]
 hipError_t launch_ar_project(const float* p_slab, int n_slabs, const float* p_ctx, float* proj_t, int M, float threshold, int t, int B,
-                             int32_t* n_frames, int32_t* n_done, hipStream_t s);
+                             int32_t* n_frames, int32_t* n_done, const float* w0t, int P, const uint8_t* keep, float* pre1, hipStream_t s);
 // AR: scatter the blocked per-step projections proj[t][PSB/8][B][8], t < steps, into mel_out [B][M][Tmax], gate_out [B][Tmax]
 hipError_t launch_ar_emit_all(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, hipStream_t s);
 // dst[b][t][:] = src[t][b][:] for t < steps, dst rows have Tdst time slots

@@ -214,43 +214,66 @@ hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, in
     return hipGetLastError();
 }
 
-// thread = (b, n): consecutive threads read consecutive floats of a slab row
+// One workgroup per batch row b (256 threads).
+//   phase 1: proj[b][n] = sum of the partial slabs (two halves of the slab range summed by two thread groups, then added
+//            lower half first) + p_ctx; gate row -> per-row stop test (models/tts/tacotron2.py:405-409)
+//   phase 2: Prenet layer 1 of the NEXT step on the fresh mel frame (tacotron2.py:398, :140-144): pre1[b][j] =
+//            2 * keep * relu(sum_n W0[j][n] * mel[n]) - the 80 -> 256 GEMV that used to be a launch of its own
 __global__ __launch_bounds__(256) void ar_project_kernel(const float* __restrict__ p_slab, int n_slabs, const float* __restrict__ p_ctx,
                                                          float* __restrict__ proj_t, int M, int PSB, float threshold, int t, int B,
-                                                         int32_t* n_frames, int32_t* n_done) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * PSB) return;
-    const int b = idx / PSB, n = idx - b * PSB;
-    if (n > M) return;
-    const long blocked = (long)(n >> 3) * B * 8 + b * 8 + (n & 7);
-    const float* sp = p_slab + (long)b * PSB + n;
-    const long sstride = (long)B * PSB;
-    float acc = 0.f;
-    int sl = 0;
-    for (; sl + 8 <= n_slabs; sl += 8) {   // 8 loads in flight, added in ascending slab order
-        float v[8];
+                                                         int32_t* n_frames, int32_t* n_done, const float* __restrict__ w0t, int P,
+                                                         const uint8_t* __restrict__ keep, float* __restrict__ pre1) {
+    __shared__ float part[2][128];
+    __shared__ float mel[128];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int half = tid / PSB, n = tid - half * PSB;   // PSB <= 128
+    if (half < 2 && n <= M) {
+        const int s_begin = half == 0 ? 0 : n_slabs / 2, s_end = half == 0 ? n_slabs / 2 : n_slabs;
+        const float* sp = p_slab + (long)b * PSB + n;
+        const long sstride = (long)B * PSB;
+        float acc = 0.f;
+        int sl = s_begin;
+        for (; sl + 16 <= s_end; sl += 16) {   // 16 loads in flight, added in ascending slab order
+            float v[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = sp[(long)(sl + q) * sstride];
+            for (int q = 0; q < 16; ++q) v[q] = sp[(long)(sl + q) * sstride];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc += v[q];
-    }
-    for (; sl < n_slabs; ++sl) acc += sp[(long)sl * sstride];
-    const float v = acc + p_ctx[blocked];
-    proj_t[blocked] = v;
-    if (n == M && n_frames[b] == 0) {      // gate logit: models/tts/tacotron2.py:405-409
-        const float sg = 1.f / (1.f + expf(-v));
-        if (sg > threshold) {
-            n_frames[b] = t + 1;
-            atomicAdd(n_done, 1);
+            for (int q = 0; q < 16; ++q) acc += v[q];
         }
+        for (; sl < s_end; ++sl) acc += sp[(long)sl * sstride];
+        part[half][n] = acc;
+    }
+    __syncthreads();
+    if (half == 0 && n <= M) {
+        const long blocked = (long)(n >> 3) * B * 8 + b * 8 + (n & 7);
+        const float v = (part[0][n] + part[1][n]) + p_ctx[blocked];
+        proj_t[blocked] = v;
+        if (n < M) mel[n] = v;
+        if (n == M && n_frames[b] == 0) {
+            const float sg = 1.f / (1.f + expf(-v));
+            if (sg > threshold) {
+                n_frames[b] = t + 1;
+                atomicAdd(n_done, 1);
+            }
+        }
+    }
+    if (!keep) return;   // last step: nobody consumes a next Prenet input
+    __syncthreads();
+    for (int j = tid; j < P; j += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < M; ++k) acc = fmaf(w0t[(long)k * P + j], mel[k], acc);
+        acc = fmaxf(acc, 0.f);
+        acc = keep[(long)b * P + j] ? 2.f * acc : 0.f;
+        pre1[(long)(j >> 3) * B * 8 + b * 8 + (j & 7)] = acc;
     }
 }
 
 hipError_t launch_ar_project(const float* p_slab, int n_slabs, const float* p_ctx, float* proj_t, int M, float threshold, int t, int B,
-                             int32_t* n_frames, int32_t* n_done, hipStream_t s) {
+                             int32_t* n_frames, int32_t* n_done, const float* w0t, int P, const uint8_t* keep, float* pre1, hipStream_t s) {
     const int PSB = (M + 1 + 7) & ~7;
-    hipLaunchKernelGGL(ar_project_kernel, dim3((B * PSB + 255) / 256), dim3(256), 0, s, p_slab, n_slabs, p_ctx, proj_t, M, PSB, threshold, t, B,
-                       n_frames, n_done);
+    if (PSB > 128 || M > 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ar_project_kernel, dim3(B), dim3(256), 0, s, p_slab, n_slabs, p_ctx, proj_t, M, PSB, threshold, t, B, n_frames, n_done,
+                       w0t, P, keep, pre1);
     return hipGetLastError();
 }
 

@@ -41,7 +41,8 @@ SIGNATURES = {
     "gvx_encoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "gvx_decoder_teacher_forced": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_decoder_autoregressive": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp, _sz, _vp]),
-    "gvx_postnet_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "gvx_postnet_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "gvx_postnet_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "gvx_mask_padding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gvx_tacotron2_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_tacotron2_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),

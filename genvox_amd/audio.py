@@ -103,9 +103,8 @@ class AudioProcessor:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    @staticmethod
-    def _stream() -> int:
-        return torch.cuda.current_stream().cuda_stream
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     # ------------------------------------------------------------------ device stages (batched, reference layouts)
     def stft(self, signal: torch.Tensor) -> torch.Tensor:

@@ -149,6 +149,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const int m = m0 + (wr * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
             if (m >= p.M) continue;
             const long c_off = row_off(p.cmap, m);
+            const int grp = m / p.cmap.R, idx = m - grp * p.cmap.R;
+            const bool live = !p.row_len || idx < p.row_len[grp];
+            // conv output with halo rows: the first / last c_halo interior rows of a sequence also zero one halo row each
+            const bool halo_front = p.c_halo > 0 && idx < p.c_halo;
+            const bool halo_back = p.c_halo > 0 && idx >= p.cmap.R - p.c_halo;
+            const long halo_step = (long)p.c_halo * p.cmap.s0;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + (wc * TN + j) * 32 + r;
@@ -158,7 +164,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == ACT_TANH) v = tanhf(v);
                 if (p.keep) v = p.keep[(long)m * p.keep_ld + n] ? 2.f * v : 0.f;
-                p.C[c_off + (long)(n >> 3) * p.c_nblk + (n & 7)] = v;
+                const long col = (long)(n >> 3) * p.c_nblk + (n & 7);
+                p.C[c_off + col] = live ? v : 0.f;
+                if (halo_front) p.C[c_off - halo_step + col] = 0.f;
+                if (halo_back) p.C[c_off + halo_step + col] = 0.f;
             }
         }
     }

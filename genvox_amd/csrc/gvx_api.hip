@@ -97,18 +97,38 @@ struct gvx_model {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     int last_decoder_launches = 0;
-    // hipGraph cache of the teacher-forced step loop, keyed by every pointer / size the captured launches bake in
+    // hipGraph caches of the step loops.  A key holds every pointer / size the captured launches bake in - including the
+    // weight blob: re-binding weights (load_state_dict -> new blob) must never replay launches that read the old one.
     struct LoopKey {
-        const void* ws; const void* memory; int B, L, T; bool has_len;
-        int chunk = -1; float threshold = 0.f;   // autoregressive chunk graphs only
+        const void* ws; const void* memory; const void* blob; int B, L, T; bool has_len;
+        float threshold = 0.f;   // autoregressive graphs only
         bool operator==(const LoopKey& o) const {
-            return ws == o.ws && memory == o.memory && B == o.B && L == o.L && T == o.T && has_len == o.has_len &&
-                   chunk == o.chunk && threshold == o.threshold;
+            return ws == o.ws && memory == o.memory && blob == o.blob && B == o.B && L == o.L && T == o.T &&
+                   has_len == o.has_len && threshold == o.threshold;
         }
     };
-    std::vector<std::pair<LoopKey, hipGraphExec_t>> ar_graphs;    // one graph per 16-step chunk of the autoregressive loop
-    std::vector<std::pair<LoopKey, hipGraphExec_t>> loop_graphs;
-    std::vector<std::pair<LoopKey, hipGraphExec_t>> enc_graphs;   // encoder recurrence (key.memory = output, key.T = 0)
+    // One entry per key: the graphs of its chunks (one for the encoder / teacher-forced loop, one per 16-step chunk of the
+    // autoregressive loop).  Policy: the first call with a key launches eagerly and only remembers the key; capture starts at
+    // the second sighting (a serving process sees a new (B, L) per request - instantiating ~60 graphs of ~100 nodes for a
+    // shape that never comes back costs more than the launches it saves); at most GRAPH_SETS keys per cache, LRU eviction.
+    struct GraphSet {
+        LoopKey key;
+        int sightings = 0;
+        uint64_t last_use = 0;
+        std::vector<hipGraphExec_t> execs;
+    };
+    static constexpr size_t GRAPH_SETS = 4;
+    std::vector<GraphSet> ar_graphs, loop_graphs, enc_graphs;
+    uint64_t use_clock = 0;
+    bool capture_first = false;   // GVX_GRAPH_FIRST=1: capture at the first sighting (tests of the replay path)
+    void drop_graphs() {
+        for (auto* c : {&ar_graphs, &loop_graphs, &enc_graphs}) {
+            for (auto& gs : *c)
+                for (auto e : gs.execs)
+                    if (e) (void)hipGraphExecDestroy(e);
+            c->clear();
+        }
+    }
     hipStream_t cap_stream = nullptr;  // private stream used only to record captures (the caller's may be the null stream)
     bool use_graph = true;
     // per-launch timing of the decoder step kernels (measurement only)
@@ -289,13 +309,37 @@ int pack_lstm(const WeightTable& wt, const std::string& wih_name, const std::str
 
 hipError_t zero_async(void* p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); }
 
-// Replay the launches `enqueue(stream)` issues from a hipGraph cached under `key` (captured on the model's private
-// stream the first time; the caller's stream may be the null stream, which cannot be captured).
-template <class Cache, class Key, class F>
-int run_cached_graph(gvx_model* m, Cache& cache, const Key& key, size_t max_entries, hipStream_t s, F&& enqueue) {
-    hipGraphExec_t exec = nullptr;
-    for (auto& g : cache)
-        if (g.first == key) exec = g.second;
+// Find (or create, evicting the least recently used) the graph set of `key` and count the sighting.
+gvx_model::GraphSet* touch_graph_set(gvx_model* m, std::vector<gvx_model::GraphSet>& cache, const gvx_model::LoopKey& key) {
+    gvx_model::GraphSet* hit = nullptr;
+    for (auto& gs : cache)
+        if (gs.key == key) hit = &gs;
+    if (!hit) {
+        if (cache.size() >= gvx_model::GRAPH_SETS) {
+            size_t lru = 0;
+            for (size_t i = 1; i < cache.size(); ++i)
+                if (cache[i].last_use < cache[lru].last_use) lru = i;
+            for (auto e : cache[lru].execs)
+                if (e) (void)hipGraphExecDestroy(e);
+            cache.erase(cache.begin() + lru);
+        }
+        cache.emplace_back();
+        hit = &cache.back();
+        hit->key = key;
+    }
+    ++hit->sightings;
+    hit->last_use = ++m->use_clock;
+    return hit;
+}
+
+// Run the launches `enqueue(stream)` issues as chunk `chunk` of graph set `gs`: eagerly at the key's first sighting,
+// afterwards from a hipGraph (captured on the model's private stream: the caller's may be the null stream, which
+// cannot be captured).
+template <class F>
+int run_chunk(gvx_model* m, gvx_model::GraphSet* gs, size_t chunk, hipStream_t s, F&& enqueue) {
+    if (!m->use_graph || !gs || (gs->sightings < 2 && !m->capture_first)) return enqueue(s);
+    if (gs->execs.size() <= chunk) gs->execs.resize(chunk + 1, nullptr);
+    hipGraphExec_t exec = gs->execs[chunk];
     if (!exec) {
         hipGraph_t graph = nullptr;
         if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
@@ -306,11 +350,7 @@ int run_cached_graph(gvx_model* m, Cache& cache, const Key& key, size_t max_entr
         HIP_TRY(ce);
         HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         HIP_TRY(hipGraphDestroy(graph));
-        if (cache.size() >= max_entries) {
-            (void)hipGraphExecDestroy(cache.front().second);
-            cache.erase(cache.begin());
-        }
-        cache.emplace_back(key, exec);
+        gs->execs[chunk] = exec;
     }
     HIP_TRY(hipGraphLaunch(exec, s));
     return GVX_OK;
@@ -332,6 +372,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     m->d = *dims;
     m->blob = make_blob_layout(*dims);
     if (const char* e = std::getenv("GVX_NO_GRAPH")) m->use_graph = !(e[0] == '1');
+    if (const char* e = std::getenv("GVX_GRAPH_FIRST")) m->capture_first = e[0] == '1';
     *out = m;
     return GVX_OK;
 }
@@ -341,9 +382,7 @@ void gvx_model_destroy(gvx_model* m) {
     if (m->ev_valid)
         for (auto& e : m->ev) (void)hipEventDestroy(e);
     for (auto& e : m->kev) (void)hipEventDestroy(e);
-    for (auto& g : m->loop_graphs) (void)hipGraphExecDestroy(g.second);
-    for (auto& g : m->enc_graphs) (void)hipGraphExecDestroy(g.second);
-    for (auto& g : m->ar_graphs) (void)hipGraphExecDestroy(g.second);
+    m->drop_graphs();
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
 }
@@ -463,6 +502,9 @@ int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, vo
 int gvx_model_bind_blob(gvx_model* m, const void* device_blob) {
     if (!m || !device_blob) return fail(GVX_ERR_INVALID_ARG, "null argument");
     if (reinterpret_cast<uintptr_t>(device_blob) & 255) return fail(GVX_ERR_INVALID_ARG, "blob must be 256-byte aligned");
+    // captured step loops bake blob addresses into their kernel nodes: a new blob invalidates every cached graph (the
+    // key carries the blob pointer as well, so a stale graph could not be selected even if one survived)
+    if (m->dev_blob != device_blob) m->drop_graphs();
     m->dev_blob = reinterpret_cast<const float*>(device_blob);
     HIP_TRY(gemm_init());
     HIP_TRY(skinny_init());
@@ -541,9 +583,11 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
     }
     HIP_TRY(zero_async(enc_h, (size_t)4 * B * H * sizeof(float), s));
     HIP_TRY(zero_async(enc_c, (size_t)2 * B * H * sizeof(float), s));
-    HIP_TRY(zero_async(memory_out, (size_t)B * L * E * sizeof(float), s));
-    // the L recurrence launches only reference workspace operands (+ the output): lengths are copied next to them and
-    // the whole sequence is captured once per (workspace, output, shape) into a hipGraph and replayed
+    // The L recurrence launches only reference workspace operands: lengths are copied next to them and the sequence output
+    // goes to the workspace-resident memory buffer (copied to the caller's tensor afterwards when that is a different
+    // one), so the key of the cached hipGraph does not depend on a freshly allocated output tensor.
+    float* mem_ws = ws_ptr<float>(ws, wp.memory);
+    HIP_TRY(zero_async(mem_ws, (size_t)B * L * E * sizeof(float), s));
     const int32_t* len_ws = nullptr;
     if (lengths) {
         int32_t* lc = ws_ptr<int32_t>(ws, wp.len_copy);
@@ -565,18 +609,19 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
                 J.h_out = h_nxt;
                 J.addend = xg + (size_t)dir * 4 * H; J.add_bs = (long)L * 8 * H; J.add_ts = 8 * H;
                 J.lengths = len_ws; J.step = step; J.reverse = dir; J.seq_len = L;
-                J.seq_out = memory_out + (size_t)dir * H; J.seq_bs = (long)L * E; J.seq_ts = E;
+                J.seq_out = mem_ws + (size_t)dir * H; J.seq_bs = (long)L * E; J.seq_ts = E;
                 J.h_prev = h_cur;
             }
             HIP_TRY(launch_skinny(jobs, 2, SK_ENCODER, st));
         }
         return GVX_OK;
     };
-    if (m->use_graph) {
-        const gvx_model::LoopKey key{ws, memory_out, B, L, 0, lengths != nullptr};
-        return run_cached_graph(m, m->enc_graphs, key, 8, s, enqueue);
-    }
-    return enqueue(s);
+    const gvx_model::LoopKey key{ws, mem_ws, m->dev_blob, B, L, 0, lengths != nullptr};
+    const int rc = run_chunk(m, m->use_graph ? touch_graph_set(m, m->enc_graphs, key) : nullptr, 0, s, enqueue);
+    if (rc != GVX_OK) return rc;
+    if (memory_out != mem_ws)
+        HIP_TRY(hipMemcpyAsync(memory_out, mem_ws, (size_t)B * L * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return GVX_OK;
 }
 
 struct DecoderBuffers {
@@ -738,8 +783,8 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         return GVX_OK;
     };
     if (m->use_graph && !kt) {
-        const gvx_model::LoopKey key{ws, memory, B, L, T, lengths != nullptr};
-        rc = run_cached_graph(m, m->loop_graphs, key, 8, s, enqueue_loop);
+        const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr};
+        rc = run_chunk(m, touch_graph_set(m, m->loop_graphs, key), 0, s, enqueue_loop);
         if (rc != GVX_OK) return rc;
         launches = 3 * T + 1;
     } else {
@@ -787,27 +832,49 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     return GVX_OK;
 }
 
-int postnet_impl(gvx_model* m, const float* mel_in, int B, int T, float* mel_post_out, void* ws, const WsPlan& wp, hipStream_t s) {
+// Postnet + residual on channels-last halo buffers ya / yb (each B * (T + 2p) * max(postnet_dim, n_mels) floats).
+// mel_lengths (optional): row b is treated as a sequence of mel_lengths[b] frames - the input and every layer's output
+// are zero from that frame on, exactly what the convolutions of a batch-1 run see as padding at the sequence end.
+int postnet_impl(gvx_model* m, const float* mel_in, const int32_t* mel_lengths, int B, int T, float* mel_post_out, float* ya,
+                 float* yb, hipStream_t s) {
     const gvx_dims& d = m->d;
     const int M = d.n_mels, pp = (d.postnet_kernel - 1) / 2, n = d.postnet_n_conv;
-    float* ya = ws_ptr<float>(ws, wp.ya);
-    float* yb = ws_ptr<float>(ws, wp.yb);
-    // every conv input needs zero halo rows in ITS channel layout; the GEMM only writes interior rows
-    HIP_TRY(launch_zero_halo(ya, B, T, pp, M, s));
-    HIP_TRY(launch_to_channels_last(mel_in, ya, B, M, T, pp, s));
+    // every conv input needs zero halo rows in ITS channel layout: the producer of a buffer writes them (the transpose for
+    // the first one, the GEMM epilogue of layer i for layer i + 1; a separate launch only when T < halo)
+    HIP_TRY(launch_to_channels_last(mel_in, ya, B, M, T, pp, mel_lengths, s));
     float* cur = ya;
     float* nxt = yb;
     for (int i = 0; i < n; ++i) {
         const int cin = i == 0 ? M : d.postnet_dim, cout = i == n - 1 ? M : d.postnet_dim;
         const bool last = i == n - 1;
-        if (!last) HIP_TRY(launch_zero_halo(nxt, B, T, pp, cout, s));
-        int rc = conv_layer(m, cur, nxt, B, T, cin, cout, d.postnet_kernel, m->blob.post_w[i], m->blob.post_b[i],
-                            last ? ACT_NONE : ACT_TANH, last ? 0 : pp, s);
-        if (rc != GVX_OK) return rc;
+        const int out_halo = last ? 0 : pp;
+        const bool fused_halo = out_halo > 0 && T >= out_halo;
+        if (out_halo > 0 && !fused_halo) HIP_TRY(launch_zero_halo(nxt, B, T, pp, cout, s));
+        GemmParams g{};
+        g.A = cur; g.amap = RowMap{T, (long)(T + 2 * pp) * cin, (long)cin};
+        g.W = m->dev_blob + m->blob.post_w[i]; g.ldw = (long)d.postnet_kernel * cin;
+        g.C = nxt + (long)out_halo * cout; g.cmap = RowMap{T, (long)(T + 2 * out_halo) * cout, (long)cout};
+        g.bias = m->dev_blob + m->blob.post_b[i];
+        g.M = B * T; g.N = cout; g.K = d.postnet_kernel * cin; g.act = last ? ACT_NONE : ACT_TANH;
+        g.row_len = last ? nullptr : mel_lengths;   // the last layer's padding is zeroed by the residual kernel
+        g.c_halo = fused_halo ? out_halo : 0;
+        HIP_TRY(launch_gemm(g, s));
         float* t = cur; cur = nxt; nxt = t;
     }
-    HIP_TRY(launch_residual_to_channels_first(mel_in, cur, mel_post_out, B, M, T, s));
+    HIP_TRY(launch_residual_to_channels_first(mel_in, cur, mel_post_out, B, M, T, mel_lengths, s));
     return GVX_OK;
+}
+
+struct PostnetPlan { size_t ya, yb, total; };
+PostnetPlan make_postnet_plan(const gvx_model* m, int B, int T) {
+    const gvx_dims& d = m->d;
+    const int pp = (d.postnet_kernel - 1) / 2, cmax = d.postnet_dim > d.n_mels ? d.postnet_dim : d.n_mels;
+    const size_t buf = align_up((size_t)B * (T + 2 * pp) * cmax * sizeof(float), 256);
+    PostnetPlan p;
+    p.ya = align_up(128 * sizeof(float), 256);   // behind the status words of the full plan
+    p.yb = p.ya + buf;
+    p.total = p.yb + buf;
+    return p;
 }
 
 }  // namespace
@@ -845,11 +912,23 @@ int gvx_decoder_teacher_forced(gvx_model* m, const float* memory, const int32_t*
                            make_ws_plan(m, B, L, T), (hipStream_t)stream);
 }
 
-int gvx_postnet_forward(gvx_model* m, const float* mel_in, int B, int T, float* mel_post_out, void* ws, size_t ws_bytes, void* stream) {
-    int rc = check_common(m, B, 1, T, ws, ws_bytes);
-    if (rc != GVX_OK) return rc;
+size_t gvx_postnet_workspace_bytes(const gvx_model* m, int B, int T) {
+    if (!m || B < 1 || T < 1) return 0;
+    return make_postnet_plan(m, B, T).total;
+}
+
+int gvx_postnet_forward(gvx_model* m, const float* mel_in, const int32_t* mel_lengths, int B, int T, float* mel_post_out, void* ws,
+                        size_t ws_bytes, void* stream) {
+    if (!m) return fail(GVX_ERR_INVALID_ARG, "null model");
+    if (!m->dev_blob) return fail(GVX_ERR_STATE, "weights not bound (call gvx_model_bind_blob)");
+    if (B < 1 || T < 1) return fail(GVX_ERR_INVALID_ARG, "B and T must be >= 1");
+    if ((long)B * T > (1L << 30)) return fail(GVX_ERR_UNSUPPORTED, "B * T = %ld frames exceed the GEMM row index range", (long)B * T);
+    if (!ws) return fail(GVX_ERR_WORKSPACE, "null workspace");
+    if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(GVX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    const PostnetPlan pp = make_postnet_plan(m, B, T);
+    if (ws_bytes < pp.total) return fail(GVX_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, pp.total);
     if (!mel_in || !mel_post_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
-    return postnet_impl(m, mel_in, B, T, mel_post_out, ws, make_ws_plan(m, B, 1, T), (hipStream_t)stream);
+    return postnet_impl(m, mel_in, mel_lengths, B, T, mel_post_out, ws_ptr<float>(ws, pp.ya), ws_ptr<float>(ws, pp.yb), (hipStream_t)stream);
 }
 
 int gvx_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths, int B, int n_mels, int T, void* stream) {
@@ -876,7 +955,7 @@ int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* to
     rc = decoder_tf_impl(m, memory, token_lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws, wp, s);
     if (rc != GVX_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(m->ev[4], s));
-    rc = postnet_impl(m, mel_out, B, T, mel_post_out, ws, wp, s);
+    rc = postnet_impl(m, mel_out, nullptr, B, T, mel_post_out, ws_ptr<float>(ws, wp.ya), ws_ptr<float>(ws, wp.yb), s);
     if (rc != GVX_OK) return rc;
     if (mel_lengths) HIP_TRY(launch_mask_padding(mel_out, mel_post_out, gate_out, mel_lengths, B, m->d.n_mels, T, s));
     if (timed) HIP_TRY(hipEventRecord(m->ev[5], s));
@@ -1020,15 +1099,15 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     const int CHUNK = 16;  // steps per graph = steps between host checks of the all-rows-finished counter
     int t = 0;
     int32_t done_host = 0;
+    gvx_model::GraphSet* gset = nullptr;
+    if (m->use_graph) {
+        gvx_model::LoopKey key{ws, memory_ws, m->dev_blob, B, L, T, lengths != nullptr};
+        key.threshold = gate_threshold;
+        gset = touch_graph_set(m, m->ar_graphs, key);
+    }
     while (t < T) {
         const int t_end = t + CHUNK < T ? t + CHUNK : T;
-        if (m->use_graph) {
-            gvx_model::LoopKey key{ws, memory_ws, B, L, T, lengths != nullptr};
-            key.chunk = t / CHUNK; key.threshold = gate_threshold;
-            rc = run_cached_graph(m, m->ar_graphs, key, 1024, s, [&](hipStream_t st) { return enqueue_steps(st, t, t_end); });
-        } else {
-            rc = enqueue_steps(s, t, t_end);
-        }
+        rc = run_chunk(m, gset, (size_t)(t / CHUNK), s, [&](hipStream_t st) { return enqueue_steps(st, t, t_end); });
         if (rc != GVX_OK) return rc;
         t = t_end;
         HIP_TRY(hipMemcpyAsync(&done_host, n_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1038,8 +1117,10 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     // rows that never fired ran into the cap ("Warning! Reached max decoder steps", models/tts/tacotron2.py:407-409)
     HIP_TRY(launch_ar_stop(db.proj, M, -1.f, t - 1, B, n_frames_ws, n_done, s));
     HIP_TRY(hipMemcpyAsync(n_frames_out, n_frames_ws, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(launch_ar_emit_all(db.proj, mel_out, gate_out, B, M, T, t, s));
-    HIP_TRY(launch_permute01_partial(db.align_tm, align_out, t, T, B, L, s));
+    // rows that stopped early kept decoding until the last row finished: their frames past n_frames get the reference's
+    // padding values (mel 0, gate 1e3, alignment 0 - mask_padding, models/tts/tacotron2.py:466-473)
+    HIP_TRY(launch_ar_emit_all(db.proj, mel_out, gate_out, B, M, T, t, n_frames_ws, s));
+    HIP_TRY(launch_permute01_partial(db.align_tm, align_out, t, T, B, L, n_frames_ws, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (steps_run_out) *steps_run_out = t;
     return GVX_OK;

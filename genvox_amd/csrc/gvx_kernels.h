@@ -50,6 +50,11 @@ struct GemmParams {
     const uint8_t* keep; long keep_ld; // Prenet keep mask [M][N] {0,1} or nullptr; kept values are doubled
     int M, N, K;                       // K % 4 == 0
     int act;
+    // conv-output extras (rows grouped by cmap.R = frames per sequence):
+    const int32_t* row_len = nullptr;  // [M / cmap.R] valid rows per group: rows at or past it are written as zeros
+    int c_halo = 0;                    // > 0: C has c_halo halo rows before and after each group's cmap.R rows (C points at
+                                       // the first interior row); the tile that owns an edge row also zeroes "its" halo row
+                                       // (requires cmap.R >= c_halo)
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 
@@ -133,10 +138,11 @@ hipError_t launch_embed(const int64_t* tokens, const float* emb, int n_tokens, f
 hipError_t launch_frames_from_mel(const float* mel_in, float* frames, int B, int M, int T, hipStream_t s);
 // proj [B][T][M+1] (batch-major)  ->  mel_out [B][M][T], gate_out [B][T]
 hipError_t launch_split_projection(const float* proj, float* mel_out, float* gate_out, int B, int M, int T, hipStream_t s);
-// [B][M][T] -> halo-padded channels-last [B][T+2p][M]
-hipError_t launch_to_channels_last(const float* src, float* dst, int B, int M, int T, int halo, hipStream_t s);
-// mel_post[b][m][t] = mel[b][m][t] + y[b][t][m]
-hipError_t launch_residual_to_channels_first(const float* mel, const float* y, float* mel_post, int B, int M, int T, hipStream_t s);
+// [B][M][T] -> halo-padded channels-last [B][T+2p][M]; halo rows and frames t >= lens[b] (lens may be nullptr) are zeroed
+hipError_t launch_to_channels_last(const float* src, float* dst, int B, int M, int T, int halo, const int32_t* lens, hipStream_t s);
+// mel_post[b][m][t] = mel[b][m][t] + y[b][t][m]   (0 for t >= lens[b] when lens != nullptr)
+hipError_t launch_residual_to_channels_first(const float* mel, const float* y, float* mel_post, int B, int M, int T,
+                                             const int32_t* lens, hipStream_t s);
 // zero the 2*halo halo rows of every sequence of a channels-last buffer [B][T+2*halo][C]
 hipError_t launch_zero_halo(float* buf, int B, int T, int halo, int C, hipStream_t s);
 hipError_t launch_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths, int B, int M, int T,
@@ -157,8 +163,11 @@ hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, in
 hipError_t launch_ar_project(const float* p_slab, int n_slabs, const float* p_ctx, float* proj_t, int M, float threshold, int t, int B,
                              int32_t* n_frames, int32_t* n_done, const float* w0t, int P, const uint8_t* keep, float* pre1, hipStream_t s);
 // AR: scatter the blocked per-step projections proj[t][PSB/8][B][8], t < steps, into mel_out [B][M][Tmax], gate_out [B][Tmax]
-hipError_t launch_ar_emit_all(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, hipStream_t s);
-// dst[b][t][:] = src[t][b][:] for t < steps, dst rows have Tdst time slots
-hipError_t launch_permute01_partial(const float* src, float* dst, int steps, int Tdst, int B, int n, hipStream_t s);
+// frames t >= n_frames[b] get the padding values of the reference's mask_padding: mel 0, gate 1e3
+hipError_t launch_ar_emit_all(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps,
+                              const int32_t* n_frames, hipStream_t s);
+// dst[b][t][:] = src[t][b][:] for t < steps (0 for t >= n_frames[b]), dst rows have Tdst time slots
+hipError_t launch_permute01_partial(const float* src, float* dst, int steps, int Tdst, int B, int n, const int32_t* n_frames,
+                                    hipStream_t s);
 
 }  // namespace gvx

@@ -34,6 +34,9 @@ struct Tr3 {
     const float* add;
     float* extra; long extra_bs; int extra_col;
     int nj_main;  // columns [0, nj_main) go to dst
+    // optional per-sequence lengths along the TIME axis (len_axis: 0 = i is time, 1 = j is time): elements at or past
+    // lens[b] are written as zeros; halo > 0 (len_axis 1 only): dst rows j in [-halo, 0) and [nj, nj + halo) are zeroed
+    const int32_t* lens; int len_axis; int halo;
 };
 
 __global__ void transpose3_kernel(Tr3 p) {
@@ -46,15 +49,27 @@ __global__ void transpose3_kernel(Tr3 p) {
         tile[r][tx] = (i < p.ni && j < p.nj) ? p.src[(long)b * p.sb + (long)i * p.si + j] : 0.f;
     }
     __syncthreads();
+    const int len = p.lens ? p.lens[b] : 0x7fffffff;
     for (int r = ty; r < 32; r += 8) {
         const int j = j0 + r, i = i0 + tx;
         if (i >= p.ni || j >= p.nj) continue;
         const float v = tile[tx][r];
         if (j < p.nj_main) {
             const long o = (long)b * p.db + (long)j * p.dj + i;
-            p.dst[o] = p.add ? v + p.add[o] : v;
+            const bool live = (p.len_axis ? j : i) < len;
+            p.dst[o] = live ? (p.add ? v + p.add[o] : v) : 0.f;
         } else if (p.extra && j == p.extra_col) {
             p.extra[(long)b * p.extra_bs + i] = v;
+        }
+    }
+    if (p.halo > 0 && blockIdx.x == 0 && blockIdx.y == 0) {   // one block per sequence also clears the halo rows
+        const int tid = ty * 32 + tx, n = p.halo * p.ni;
+        float* front = p.dst + (long)b * p.db - (long)p.halo * p.dj;
+        float* back = p.dst + (long)b * p.db + (long)p.nj * p.dj;
+        for (int e = tid; e < n; e += 256) {
+            const int hr = e / p.ni, c = e - hr * p.ni;
+            front[(long)hr * p.dj + c] = 0.f;
+            back[(long)hr * p.dj + c] = 0.f;
         }
     }
 }
@@ -84,19 +99,22 @@ hipError_t launch_split_projection(const float* proj, float* mel_out, float* gat
     return launch_tr3(p, B, s);
 }
 
-hipError_t launch_to_channels_last(const float* src, float* dst, int B, int M, int T, int halo, hipStream_t s) {
+hipError_t launch_to_channels_last(const float* src, float* dst, int B, int M, int T, int halo, const int32_t* lens, hipStream_t s) {
     Tr3 p{};
     p.src = src; p.sb = (long)M * T; p.si = T; p.ni = M; p.nj = T;
     p.dst = dst + (long)halo * M; p.db = (long)(T + 2 * halo) * M; p.dj = M;
     p.nj_main = T;
+    p.lens = lens; p.len_axis = 1; p.halo = halo;
     return launch_tr3(p, B, s);
 }
 
-hipError_t launch_residual_to_channels_first(const float* mel, const float* y, float* mel_post, int B, int M, int T, hipStream_t s) {
+hipError_t launch_residual_to_channels_first(const float* mel, const float* y, float* mel_post, int B, int M, int T,
+                                             const int32_t* lens, hipStream_t s) {
     Tr3 p{};
     p.src = y; p.sb = (long)T * M; p.si = M; p.ni = T; p.nj = M;
     p.dst = mel_post; p.db = (long)M * T; p.dj = T; p.add = mel;
     p.nj_main = M;
+    p.lens = lens; p.len_axis = 0;
     return launch_tr3(p, B, s);
 }
 
@@ -277,41 +295,47 @@ hipError_t launch_ar_project(const float* p_slab, int n_slabs, const float* p_ct
     return hipGetLastError();
 }
 
-__global__ void ar_emit_all_kernel(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, int PSB) {
+__global__ void ar_emit_all_kernel(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, int PSB,
+                                   const int32_t* n_frames) {
     // thread = (b, m); loops over time so that writes along t are contiguous per thread row
     const int b = blockIdx.y;
+    const int nf = n_frames ? n_frames[b] : steps;
     for (int m = blockIdx.x * blockDim.y + threadIdx.y; m <= M; m += gridDim.x * blockDim.y) {
         const long src = (long)(m >> 3) * B * 8 + b * 8 + (m & 7);
         for (int t = threadIdx.x; t < steps; t += blockDim.x) {
             const float v = proj[(long)t * B * PSB + src];
-            if (m < M) mel_out[((long)b * M + m) * Tmax + t] = v;
-            else gate_out[(long)b * Tmax + t] = v;
+            if (m < M) mel_out[((long)b * M + m) * Tmax + t] = t < nf ? v : 0.f;
+            else gate_out[(long)b * Tmax + t] = t < nf ? v : 1e3f;
         }
     }
 }
 
-hipError_t launch_ar_emit_all(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps, hipStream_t s) {
+hipError_t launch_ar_emit_all(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps,
+                              const int32_t* n_frames, hipStream_t s) {
     if (steps <= 0) return hipSuccess;
     const int PSB = (M + 1 + 7) & ~7;
-    hipLaunchKernelGGL(ar_emit_all_kernel, dim3((M + 1 + 3) / 4, B), dim3(64, 4), 0, s, proj, mel_out, gate_out, B, M, Tmax, steps, PSB);
+    hipLaunchKernelGGL(ar_emit_all_kernel, dim3((M + 1 + 3) / 4, B), dim3(64, 4), 0, s, proj, mel_out, gate_out, B, M, Tmax, steps, PSB,
+                       n_frames);
     return hipGetLastError();
 }
 
-__global__ void permute01_partial_kernel(const float* src, float* dst, int steps, int Tdst, int B, int n) {
+__global__ void permute01_partial_kernel(const float* src, float* dst, int steps, int Tdst, int B, int n, const int32_t* n_frames) {
     const long rows = (long)steps * B;
     for (long r = blockIdx.x; r < rows; r += gridDim.x) {
         const int t = (int)(r / B), b = (int)(r - (long)t * B);
+        const bool live = !n_frames || t < n_frames[b];
         const float* sp = src + r * n;
         float* dp = dst + ((long)b * Tdst + t) * n;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) dp[i] = sp[i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) dp[i] = live ? sp[i] : 0.f;
     }
 }
 
-hipError_t launch_permute01_partial(const float* src, float* dst, int steps, int Tdst, int B, int n, hipStream_t s) {
+hipError_t launch_permute01_partial(const float* src, float* dst, int steps, int Tdst, int B, int n, const int32_t* n_frames,
+                                    hipStream_t s) {
     const long rows = (long)steps * B;
     if (rows <= 0) return hipSuccess;
     const int grid = (int)(rows < 4096 ? rows : 4096);
-    hipLaunchKernelGGL(permute01_partial_kernel, dim3(grid), dim3(128), 0, s, src, dst, steps, Tdst, B, n);
+    hipLaunchKernelGGL(permute01_partial_kernel, dim3(grid), dim3(128), 0, s, src, dst, steps, Tdst, B, n, n_frames);
     return hipGetLastError();
 }
 

@@ -13,33 +13,33 @@ import torch
 import torch.distributed as dist
 
 
-def _world() -> Tuple[int, int]:
+def _world_info() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 
 
 def broadcast_packed_weights(model, src: int = 0) -> None:
-    """Make every rank's model use rank ``src``'s weights: src packs, one broadcast, the others bind the blob."""
-    rank, world = _world()
+    """Make every rank's model use rank ``src``'s weights: src packs, ONE broadcast of the packed blob, the others bind it.
+
+    Works on the model's device: "nccl" (= RCCL) for CUDA models; with "gloo" and CPU-resident models the same protocol
+    runs without a GPU (the blob is then only kept, see ``Tacotron2.bind_packed_blob``)."""
     if not (dist.is_available() and dist.is_initialized()):
-        model._ensure_packed()
+        if model._device().type == "cuda":
+            model._ensure_packed()
         return
-    import ctypes as C
-
-    from . import _lib
-    from .tacotron2 import dims_from_configs
-
-    lib = _lib.load()
+    rank, _world = _world_info()
     if rank == src:
         blob = model.packed_blob()
     else:
-        if model._handle is None:
-            h = C.c_void_p()
-            dims = dims_from_configs(model.model_config, model.audio_config, model.text_config)
-            _lib.check(lib.gvx_model_create(C.byref(dims), C.byref(h)))
-            model._handle = h.value
-        blob = torch.empty(lib.gvx_model_blob_bytes(model._handle) // 4, dtype=torch.float32, device=model._device())
+        blob = torch.empty(model.blob_numel(), dtype=torch.float32, device=model._device())
+    sizes = torch.tensor([blob.numel()], dtype=torch.int64, device=blob.device)
+    dist.broadcast(sizes, src=src)   # a rank built from different configs must fail here, not read a misaligned blob
+    ok = torch.tensor([int(int(sizes.item()) == blob.numel())], dtype=torch.int64, device=blob.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank learns of a mismatch, so nobody is left waiting in the broadcast
+    if int(ok.item()) != 1:
+        raise RuntimeError(f"rank {rank}: packed blob has {blob.numel()} floats, rank {src} broadcasts {int(sizes.item())}: "
+                           f"model configs differ between ranks")
     dist.broadcast(blob, src=src)
     if rank != src:
         model.bind_packed_blob(blob)
@@ -75,7 +75,7 @@ def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[s
 
 def gather_mels(mel: torch.Tensor, mel_lengths: torch.Tensor, t_max: int) -> List[torch.Tensor]:
     """Optional all-gather of per-rank mel shards [b_r, M, t_r] (padded to t_max) onto every rank."""
-    rank, world = _world()
+    rank, world = _world_info()
     pad = torch.zeros(mel.shape[0], mel.shape[1], t_max, dtype=mel.dtype, device=mel.device)
     pad[:, :, : mel.shape[2]] = mel
     if world == 1:

@@ -113,50 +113,65 @@ class Tacotron2(nn.Module):
         sd = self.state_dict()
         return (str(self._device()),) + tuple((v.data_ptr(), v._version) for v in sd.values())
 
-    def _ensure_packed(self) -> None:
-        """Fold / repack the current state_dict into the device blob the kernels read (once per weight version)."""
-        dev = self._require_gpu()
-        key = self._weights_key()
-        if self._packed_key == key:
-            return
-        lib = _lib.load()
+    def _ensure_handle(self) -> int:
         if self._handle is None:
             h = C.c_void_p()
             dims = dims_from_configs(self.model_config, self.audio_config, self.text_config)
-            _lib.check(lib.gvx_model_create(C.byref(dims), C.byref(h)))
+            _lib.check(_lib.load().gvx_model_create(C.byref(dims), C.byref(h)))
             self._handle = h.value
+        return self._handle
+
+    def blob_numel(self) -> int:
+        """Number of fp32 elements of this model's packed weight blob (fixed by the configs)."""
+        return _lib.load().gvx_model_blob_bytes(self._ensure_handle()) // 4
+
+    def pack_weights_host(self) -> torch.Tensor:
+        """Fold / repack the current state_dict into the blob layout the kernels read (host memory, host-only work:
+        BatchNorm folding, LSTM gate-row permutation, MFMA-fragment order).  Needs no GPU."""
+        lib = _lib.load()
+        h = self._ensure_handle()
         host = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()
                 if v.is_floating_point()}
         table = (_lib.gvx_weight_desc * len(host))()
         for i, (k, v) in enumerate(host.items()):
             table[i] = _lib.gvx_weight_desc(k.encode(), v.data_ptr(), v.numel())
-        nbytes = lib.gvx_model_blob_bytes(self._handle)
-        blob_host = torch.empty(nbytes // 4, dtype=torch.float32)
-        _lib.check(lib.gvx_model_pack_weights(self._handle, table, len(host), blob_host.data_ptr()))
-        self._blob = blob_host.to(dev)
-        _lib.check(lib.gvx_model_bind_blob(self._handle, self._blob.data_ptr()))
-        if self._timing:
-            _lib.check(lib.gvx_stage_timing_enable(self._handle, 1))
+        blob_host = torch.empty(self.blob_numel(), dtype=torch.float32)
+        _lib.check(lib.gvx_model_pack_weights(h, table, len(host), blob_host.data_ptr()))
+        return blob_host
+
+    def _ensure_packed(self) -> None:
+        """Make the device blob match the current state_dict (once per weight version)."""
+        dev = self._require_gpu()
+        key = self._weights_key()
+        if self._packed_key == key:
+            return
+        self._bind(self.pack_weights_host().to(dev))
         self._packed_key = key
 
+    def _bind(self, blob: torch.Tensor) -> None:
+        lib = _lib.load()
+        _lib.check(lib.gvx_model_bind_blob(self._ensure_handle(), blob.data_ptr()))
+        self._blob = blob   # replaces (and frees) the previous blob only after the handle points at the new one
+        if self._timing:
+            _lib.check(lib.gvx_stage_timing_enable(self._handle, 1))
+
     def packed_blob(self) -> torch.Tensor:
-        """The packed device weight blob (what a multi-GPU start-up broadcasts, see genvox_amd.dist)."""
+        """The packed weight blob on the model's device (what a multi-GPU start-up broadcasts, see genvox_amd.dist).
+        On a CPU-resident model this is the host blob (rehearsal of the broadcast protocol; nothing can run on it)."""
+        if self._device().type != "cuda":
+            return self.pack_weights_host()
         self._ensure_packed()
         return self._blob
 
     def bind_packed_blob(self, blob: torch.Tensor) -> None:
-        """Adopt a packed blob produced by another rank's ``packed_blob()`` (same configs)."""
-        dev = self._require_gpu()
-        lib = _lib.load()
-        if self._handle is None:
-            h = C.c_void_p()
-            dims = dims_from_configs(self.model_config, self.audio_config, self.text_config)
-            _lib.check(lib.gvx_model_create(C.byref(dims), C.byref(h)))
-            self._handle = h.value
-        assert blob.dtype == torch.float32 and blob.device == dev and blob.is_contiguous()
-        assert blob.numel() * 4 == lib.gvx_model_blob_bytes(self._handle), "blob size does not match this model's dims"
-        self._blob = blob
-        _lib.check(lib.gvx_model_bind_blob(self._handle, blob.data_ptr()))
+        """Adopt a packed blob produced by another rank's ``packed_blob()`` (same configs).  On a CUDA model the kernels
+        read it from now on; on a CPU model it is only kept (``_blob``) so that the protocol can be checked without a GPU."""
+        assert blob.dtype == torch.float32 and blob.is_contiguous() and blob.device == self._device()
+        assert blob.numel() == self.blob_numel(), "blob size does not match this model's dims"
+        if blob.device.type == "cuda":
+            self._bind(blob)
+        else:
+            self._blob = blob
         self._packed_key = self._weights_key()
 
     def _get_workspace(self, B: int, L: int, T: int) -> torch.Tensor:
@@ -165,9 +180,8 @@ class Tacotron2(nn.Module):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self._device())
         return self._workspace
 
-    @staticmethod
-    def _stream() -> int:
-        return torch.cuda.current_stream().cuda_stream
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self._device()).cuda_stream
 
     def check_status(self) -> None:
         """Read the device-side status word of the last calls (synchronises the stream): raises IndexError for a token
@@ -259,7 +273,9 @@ class Tacotron2(nn.Module):
         """Autoregressive text->mel (reference: models/tts/tacotron2.py:483-499; Decoder.inference :390-414).
 
         inputs: ``tokens`` [B, L] (the reference: B = 1); optional ``token_lengths`` [B] for padded batches and
-        ``prenet_keep_masks`` uint8 [2, max_decoder_steps, B, prenet_dim].  Outputs are trimmed to the longest row."""
+        ``prenet_keep_masks`` uint8 [2, max_decoder_steps, B, prenet_dim].  Outputs are trimmed to the longest row; for B > 1
+        ``mel_lengths`` holds every row's frame count and frames past it carry the padding values of the reference's
+        mask_padding (mel / mel_postnet / alignment 0, gate 1e3) - row b up to its length is what a batch-1 run gives."""
         dev = self._require_gpu()
         self._ensure_packed()
         tokens = inputs["tokens"].to(device=dev, dtype=torch.int64).contiguous()
@@ -286,13 +302,15 @@ class Tacotron2(nn.Module):
             float(mc.gate_threshold), masks.data_ptr(), mel_out.data_ptr(), gate_out.data_ptr(), align.data_ptr(),
             n_frames.data_ptr(), C.byref(steps), ws.data_ptr(), ws.numel(), s))
         n_host = n_frames.cpu()
+        self.check_status()   # the decoder call has synchronised already: a bad token id raises here like nn.Embedding does
         Tn = int(n_host.max())
-        if int((n_host >= S).sum()) > 0 and Tn >= S:
+        if steps.value >= S and int((n_host >= S).sum()) > 0:
             print("Warning! Reached max decoder steps")
         mel_out = mel_out[:, :, :Tn].contiguous()
         mel_post = torch.empty_like(mel_out)
-        _lib.check(lib.gvx_postnet_forward(self._handle, mel_out.data_ptr(), B, Tn, mel_post.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), s))
+        # every row is post-processed as a sequence of its own length (what a batch-1 run of the reference sees)
+        _lib.check(lib.gvx_postnet_forward(self._handle, mel_out.data_ptr(), n_frames.data_ptr() if B > 1 else None, B, Tn,
+                                           mel_post.data_ptr(), ws.data_ptr(), ws.numel(), s))
         out = {"mel_outputs": mel_out, "mel_outputs_postnet": mel_post,
                "gate_outputs": gate_out[:, :Tn].contiguous(), "alignments": align[:, :Tn].contiguous()}
         if B > 1:
@@ -312,15 +330,21 @@ class Tacotron2(nn.Module):
                                                    B, L, memory.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return memory
 
-    def postnet_residual(self, mel: torch.Tensor) -> torch.Tensor:
+    def postnet_residual(self, mel: torch.Tensor, mel_lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """mel + Postnet(mel) for any batch size; with ``mel_lengths`` every row is treated as a sequence of its own length."""
         dev = self._require_gpu()
         self._ensure_packed()
         mel = mel.to(device=dev, dtype=torch.float32).contiguous()
         B, M, T = mel.shape
-        ws = self._get_workspace(B, 1, T)
+        lens = mel_lengths.to(device=dev, dtype=torch.int32).contiguous() if mel_lengths is not None else None
+        lib = _lib.load()
+        need = lib.gvx_postnet_workspace_bytes(self._handle, B, T)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = self._workspace
         out = torch.empty_like(mel)
-        _lib.check(_lib.load().gvx_postnet_forward(self._handle, mel.data_ptr(), B, T, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                   self._stream()))
+        _lib.check(lib.gvx_postnet_forward(self._handle, mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T,
+                                           out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
 
     # ---- reference contract: batches, checkpoints, configs (models/tts/__init__.py:91-95, tacotron2.py:574-596)

@@ -12,7 +12,9 @@
  *  - extern "C", plain pointers and sizes, no torch types.
  *  - Unless a parameter says "host", every pointer is a DEVICE pointer (e.g. tensor.data_ptr()
  *    of a PyTorch-ROCm tensor).  Outputs and workspaces are caller-allocated; nothing is
- *    retained after a call returns except the blob pointer given to gvx_model_bind_blob.
+ *    retained after a call returns except the blob pointer given to gvx_model_bind_blob and
+ *    cached hipGraphs of the step loops, which reference the workspace and the blob by address
+ *    (keyed by both; re-binding a blob drops them).
  *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
  *    Calls enqueue work and return; they do not synchronise unless stated.
  *  - Every int-returning call returns GVX_OK (0) or a negative gvx_status;
@@ -116,8 +118,8 @@ int gvx_decoder_teacher_forced(gvx_model* model, const float* memory, const int3
 
 /* ---- Autoregressive decoder, batched.  Replaces Decoder.inference (models/tts/tacotron2.py:390-414),
  * which is batch-1 only; here every row stops on its own: n_frames_out[b] = index of the first step
- * whose sigmoid(gate) > gate_threshold, plus one (or max_steps).  Frames past n_frames_out[b] are
- * unspecified.  keep_masks: uint8 [2, max_steps, B, prenet_dim].  Outputs are sized for max_steps:
+ * whose sigmoid(gate) > gate_threshold, plus one (or max_steps).  Frames past n_frames_out[b] carry the
+ * reference's padding values (mel 0, gate 1e3, alignment 0; mask_padding, :466-473).  keep_masks: uint8 [2, max_steps, B, prenet_dim].  Outputs are sized for max_steps:
  * mel_out [B, n_mels, max_steps], gate_out [B, max_steps], align_out [B, max_steps, L].
  * This call synchronises the stream (it polls the all-rows-finished flag between step chunks).
  * steps_run_out (HOST int) receives the number of steps actually executed. */
@@ -127,8 +129,13 @@ int gvx_decoder_autoregressive(gvx_model* model, const float* memory, const int3
                                int* steps_run_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Postnet + residual: mel_post_out = mel_in + Postnet(mel_in).  Replaces Postnet.forward and the
- * residual add (models/tts/tacotron2.py:194-200, :464/:491).  Tensors are [B, n_mels, T]. */
-int gvx_postnet_forward(gvx_model* model, const float* mel_in, int B, int T, float* mel_post_out,
+ * residual add (models/tts/tacotron2.py:194-200, :464/:491).  Tensors are [B, n_mels, T]; any B (GEMM-only
+ * path, no per-call batch limit).  mel_lengths: int32 [B] or NULL.  With lengths, row b is processed as a
+ * sequence of mel_lengths[b] frames (the convolutions see zeros from that frame on, as a batch-1 run of the
+ * reference sees its zero padding) and mel_post_out is 0 there.  The workspace needs
+ * gvx_postnet_workspace_bytes(B, T) bytes (a gvx_workspace_bytes(B, L, T) workspace is always large enough). */
+size_t gvx_postnet_workspace_bytes(const gvx_model* model, int B, int T);
+int gvx_postnet_forward(gvx_model* model, const float* mel_in, const int32_t* mel_lengths, int B, int T, float* mel_post_out,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Output padding mask (models/tts/tacotron2.py:466-473): frames >= mel_lengths[b] get

@@ -34,10 +34,29 @@ def _worker(rank, world, port, results):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        # the weight broadcast protocol: src owns the blob, the others receive into an empty buffer of the same size
-        blob = torch.arange(1000, dtype=torch.float32) * (1 if rank == 0 else 0)
-        dist.broadcast(blob, src=0)
-        ok = bool(torch.equal(blob, torch.arange(1000, dtype=torch.float32)))
+        # the product's weight broadcast (genvox_amd.dist.broadcast_packed_weights) on CPU-resident models: rank 0 holds the
+        # "checkpoint", rank 1 a different random init; afterwards rank 1 must hold rank 0's packed blob bit for bit
+        from genvox_amd import weights as gw
+        from genvox_amd.tacotron2 import Tacotron2
+        from tests.golden.cases import TF_CASES, case_configs
+
+        mc, ac, tc = case_configs(TF_CASES["tf_small"])
+        model = Tacotron2(mc, ac, tc)
+        sd0 = gw.generate_state_dict(mc, ac, tc, seed=2)
+        model.load_state_dict(sd0 if rank == 0 else gw.generate_state_dict(mc, ac, tc, seed=99))
+        gdist.broadcast_packed_weights(model, src=0)
+        want = Tacotron2(mc, ac, tc)
+        want.load_state_dict(sd0)
+        want_blob = want.pack_weights_host()
+        mine = model.packed_blob() if rank == 0 else model._blob
+        ok = bool(torch.equal(mine, want_blob)) and mine.numel() == model.blob_numel()
+        # ranks built from different configs must all fail loudly instead of binding a misaligned blob
+        other = Tacotron2(*case_configs(TF_CASES["tf_full" if rank == 1 else "tf_small"]))
+        try:
+            gdist.broadcast_packed_weights(other, src=0)
+            ok = False
+        except RuntimeError as e:
+            ok &= "configs differ" in str(e)
         B, M, T = 5, 8, 12
         batch = {
             "token_padded": torch.arange(B * 6).reshape(B, 6), "token_lengths": torch.tensor([6, 5, 4, 3, 2]),

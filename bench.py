@@ -1,33 +1,46 @@
 #!/usr/bin/env python3
-"""Headline benchmark: teacher-forced Tacotron2 forward, mel-frames/s (BASELINE.json metric).
+"""Headline benchmark: teacher-forced Tacotron2 forward, mel-frames/s, plus the rest of BASELINE.json's metric
+(autoregressive RTF, batch 64 x 800, Postnet MFMA rate, Griffin-Lim) as extra keys of the same JSON line.
 
     python bench.py [--gpus N --steps K --warmup W]
 
-A "step" is one pass of the hot path (encoder -> Prenet -> T decoder steps -> projection -> Postnet ->
-padding mask, Prenet keep masks drawn on device) over one synthetic batch that is already resident in
-HBM.  Default workload = BASELINE.json configs[1]: batch 32 x 800 mel frames x 80 bins, 128 tokens, fp32,
-random-init default-size weights (seed 0).  With N > 1 (launched by torch.distributed.run, one process per
-GPU) rank 0 packs the weights and broadcasts the packed blob over RCCL; every rank then runs its own
-independent batch (weak scaling, no data-path collective).
+A "step" is one pass of the hot path (encoder -> Prenet -> T decoder steps -> projection -> Postnet -> padding mask,
+Prenet keep masks drawn on device) over one synthetic batch that is already resident in HBM.  Headline workload =
+BASELINE.json configs[1]: batch 32 x 800 mel frames x 80 bins, 128 tokens, fp32, random-init default-size weights
+(seed 0).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the decoder LSTM step launch):
-algorithmic bytes per launch / its average duration, measured with HIP events on the launch stream
-around 64 back-to-back replays of a mid-sequence step launch in an instrumented pass right after the timed region.  `cpu_baseline` times the oracle (the CPU
-restatement of the reference) on the host cores on a bounded sample of the same workload.
+Multi-GPU (weak scaling, B rows per GPU, no data-path collective): one process per GPU.  Either the caller launches
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / WORLD_SIZE in the environment), or
+`python bench.py --gpus N` alone: it then starts that launcher itself as a child process - before this process has
+touched the GPU - and relays the child's output (rank 0's JSON line) and exit code.  Rank 0 packs the weights and
+broadcasts the packed blob over RCCL; every rank then runs its own independent batch.
+
+Rank 0 prints ONE JSON line.
+  roofline      dominant kernel (decoder LSTM step launch): algorithmic bytes per launch / its average duration.
+                The duration is measured live with HIP events on the launch stream around 64 back-to-back launches of a
+                mid-sequence step in an instrumented pass right after the timed region (inside the replayed hipGraph a
+                single kernel cannot be bracketed); `decoder_step_us` next to it is the whole step (3 launches incl. their
+                boundaries) taken from HIP events recorded around the decoder loop INSIDE the timed region.  `traffic` is
+                null here: HBM bytes come from separate rocprofv3 --pmc passes (profiles/README.md), never from a file.
+  cpu_baseline  the oracle (CPU restatement of the reference) on the host cores, bounded sample of the same workload.
+  extra         (N = 1 only) the other BASELINE configurations, each timed like the headline (warm-up, then K runs
+                bracketed by synchronize) with its own roofline fraction and CPU-oracle figure:
+                tf_b64x800, ar_b64_1000, ar_b1_1000, postnet_b256x800, gl_60it_b256x800.
 """
 import argparse
+import contextlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (same guide): v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
 
 
 def algorithmic_bytes_lstm_launch(mc, B, L):
@@ -42,6 +55,11 @@ def algorithmic_bytes_lstm_launch(mc, B, L):
     return 4 * (weights + B * (per_row + slabs + loc))
 
 
+def flops_lstm_launch(mc, B):
+    P, E, A, D = mc.prenet_dim, mc.encoder_embedding_dim, mc.attention_rnn_dim, mc.decoder_rnn_dim
+    return 2 * B * (4 * A * (P + E + A) + 4 * D * (A + E + D))
+
+
 def algorithmic_bytes_decoder_step(mc, B, L):
     """SURVEY.md section 8d figure for one whole decoder step (weights once + per-row traffic)."""
     return 4 * (18103953 + B * (645 * L + 9553))
@@ -49,6 +67,53 @@ def algorithmic_bytes_decoder_step(mc, B, L):
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_threads():
+    # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribe the cgroup
+    return max(1, min(int(os.environ.get("GVX_CPU_THREADS", "16")), os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start torch.distributed.run as a CHILD (this process has not touched the GPU and never
+    will: on this pool a process that initialised HIP must not exec another program) and relay its exit code."""
+    import torch
+
+    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    if have < (1 if args.rehearse_one_gpu else args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible on this node")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def timed(torch, fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
 
 
 def main():
@@ -60,20 +125,35 @@ def main():
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (extra key)")
+    ap.add_argument("--only-extra", default="", help="comma list of extra configurations to run (default: all)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks share cuda:0 over the gloo backend: exercises the launcher / barrier / broadcast / JSON "
+                         "flow on a 1-GPU box; the line is marked \"rehearsal\" and is not a scaling measurement")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = "RANK" in os.environ   # launched by torch.distributed.run (any N, also N = 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     from genvox_amd import weights as gw
     from genvox_amd.configs import AudioConfig, Tacotron2Config, TextConfig
@@ -86,7 +166,7 @@ def main():
     if rank == 0:
         model.load_state_dict(gw.generate_state_dict(mc, ac, tc, seed=0))
     model = model.to(dev)
-    broadcast_packed_weights(model, src=0)  # one RCCL broadcast of the packed blob (no-op for a single process)
+    broadcast_packed_weights(model, src=0)  # one RCCL broadcast of the packed blob (no collective for a single process)
 
     inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=3 + rank)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
@@ -99,7 +179,8 @@ def main():
             torch.cuda.synchronize()
 
     log(f"rank {rank}: weights bound, inputs resident; warmup {args.warmup}")
-    for _ in range(args.warmup):
+    model.enable_stage_timing(True)   # 6 HIP event records per forward, on the launch stream, inside the timed region
+    for _ in range(max(args.warmup, 0)):
         model.forward(batch)
     sync_all()
     log("timed region")
@@ -115,67 +196,147 @@ def main():
     assert torch.isfinite(out["mel_outputs_postnet"]).all()
     log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
 
-    # ---- instrumented pass (not part of the timed region): per-launch and per-stage device times
+    def lstm_roofline(m, b, batch_b, loop_ms):
+        """HBM and MFMA fractions of the decoder LSTM step launch at batch b (instrumented pass, see module docstring)."""
+        m.enable_kernel_timing(True)
+        m.forward(batch_b)
+        torch.cuda.synchronize()
+        kt = m.kernel_times_ms()
+        m.enable_kernel_timing(False)
+        alg = algorithmic_bytes_lstm_launch(mc, b, L)
+        sec = kt["decoder_lstm_step"] * 1e-3
+        gbs, tfl = alg / sec / 1e9, flops_lstm_launch(mc, b) / sec / 1e12
+        return {"bound": "hbm", "kernel": f"decoder_lstm_step_kernel<{2 if b > 32 else 1}>", "achieved": round(gbs, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(kt["decoder_lstm_step"] * 1e3, 2),
+                "attention_launch_us": round(kt["attention_step"] * 1e3, 2),
+                "mfma_tflops": round(tfl, 1), "mfma_frac_of_157TF": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
+                "decoder_step_us": round(loop_ms * 1e3 / T, 2),
+                "decoder_step_GBs_survey_8d": round(algorithmic_bytes_decoder_step(mc, b, L) * T / (loop_ms * 1e-3) / 1e9, 1)}
+
     roofline, stages = None, None
     if rank == 0:
-        model.enable_stage_timing(True)       # pass 1: HIP events between the stages of one eager forward
-        model.forward(batch)
-        torch.cuda.synchronize()
-        st, launches = model.stage_times_ms()
+        st, launches = model.stage_times_ms()   # events of the last forward of the timed region
         model.enable_stage_timing(False)
-        model.enable_kernel_timing(True)      # pass 2: the step's launches replayed back to back between events
-        model.forward(batch)
-        torch.cuda.synchronize()
-        kt = model.kernel_times_ms()
-        model.enable_kernel_timing(False)
-        alg = algorithmic_bytes_lstm_launch(mc, B, L)
-        achieved = alg / (kt["decoder_lstm_step"] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("batch") == B:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "decoder_lstm_step_kernel", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": alg,
-                    "avg_launch_us": round(kt["decoder_lstm_step"] * 1e3, 2),
-                    "attention_launch_us": round(kt["attention_step"] * 1e3, 2),
-                    "decoder_step_GBs_survey_8d": round(algorithmic_bytes_decoder_step(mc, B, L) * T / (st["decoder_loop"] * 1e-3) / 1e9, 1)}
         stages = {k: round(v, 3) for k, v in st.items()}
+        roofline = lstm_roofline(model, B, batch, st["decoder_loop"])
+
+    n_thr = cpu_threads()
+    cpu_model = host_cpu_model()
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle on the host cores, bounded sample of the same workload
     cpu = None
+    sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tacotron2_ref
 
-        # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribe
-        n_thr = max(1, min(int(os.environ.get("GVX_CPU_THREADS", "16")), os.cpu_count() or 1, len(os.sched_getaffinity(0))))
         torch.set_num_threads(n_thr)
-        sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+        sd_cpu = gw.generate_state_dict(mc, ac, tc, seed=0)
 
         def run_cpu(Tc):
             sub = gw.synthetic_inputs(B, L, Tc, tc.n_tokens, ac.n_mels, seed=3)
             cb = {k: torch.from_numpy(v) for k, v in sub.items()}
             masks = torch.from_numpy(gw.prenet_keep_masks((Tc + 1) * B, mc.prenet_dim))
             c0 = time.perf_counter()
-            tacotron2_ref.tacotron2_forward(sd, cb, masks, mask_padding=True)
+            tacotron2_ref.tacotron2_forward(sd_cpu, cb, masks, mask_padding=True)
             return time.perf_counter() - c0
 
-        log(f"cpu baseline: oracle on {n_thr} threads")
+        log(f"cpu baseline: oracle on {n_thr} threads ({cpu_model})")
         Tc = min(T, 16)
-        probe_s = run_cpu(Tc)  # short probe sizes the sample to ~10-20 s of CPU work
+        probe_s = run_cpu(Tc)  # short probe sizes the sample to ~10 s of CPU work
         log(f"cpu probe: {Tc} frames in {probe_s:.2f} s")
-        Tc = int(max(Tc, min(T, Tc * 15.0 / max(probe_s, 1e-3))))
+        Tc = int(max(Tc, min(T, Tc * 10.0 / max(probe_s, 1e-3))))
         cpu_s = run_cpu(Tc)
         log(f"cpu sample: {Tc} frames in {cpu_s:.2f} s")
-        cpu = {"value": round(B * Tc / cpu_s, 1), "unit": "mel-frames/s", "cores": n_thr, "kind": "port",
+        cpu = {"value": round(B * Tc / cpu_s, 1), "unit": "mel-frames/s", "cores": n_thr, "kind": "port", "host_cpu": cpu_model,
                "sample": f"oracle teacher-forced forward, batch {B} x {Tc} frames x {L} tokens (first {Tc} of {T} frames), "
                          f"{cpu_s:.1f} s, torch {torch.__version__} CPU"}
+
+    # ---- the other BASELINE configurations (rank 0, N = 1 only)
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        want = set(filter(None, args.only_extra.split(","))) or {"tf_b64x800", "ar_b64_1000", "ar_b1_1000", "postnet_b256x800",
+                                                                  "gl_60it_b256x800"}
+        with_cpu = not args.no_cpu_baseline
+        extra = {"host_cpu": cpu_model, "cpu_threads": n_thr}
+        audio_s_per_frame = ac.hop_length / ac.sampling_rate
+        if with_cpu:
+            from oracle import audio_ref, tacotron2_ref
+            if sd_cpu is None:
+                sd_cpu = gw.generate_state_dict(mc, ac, tc, seed=0)
+            torch.set_num_threads(n_thr)
+        if "tf_b64x800" in want:   # the north_star's target batch
+            log("extra: teacher-forced batch 64 x 800")
+            b64 = {k: torch.from_numpy(v).to(dev) for k, v in gw.synthetic_inputs(64, L, T, tc.n_tokens, ac.n_mels, seed=3).items()}
+            model.enable_stage_timing(True)
+            dt = timed(torch, lambda: model.forward(b64), 2, args.steps)
+            st64, _ = model.stage_times_ms()
+            model.enable_stage_timing(False)
+            extra["tf_b64x800"] = {"mel_frames_per_s": round(64 * T / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
+                                   "stage_ms": {k: round(v, 3) for k, v in st64.items()},
+                                   "roofline": lstm_roofline(model, 64, b64, st64["decoder_loop"])}
+            del b64
+        for key, bb in (("ar_b64_1000", 64), ("ar_b1_1000", 1)):
+            if key not in want:
+                continue
+            log(f"extra: autoregressive batch {bb} x {mc.max_decoder_steps} steps")
+            mc.gate_threshold = 1.0   # never fires: exactly max_decoder_steps frames (BASELINE configs[2])
+            tok = torch.from_numpy(gw.synthetic_inputs(bb, L, 8, tc.n_tokens, ac.n_mels, seed=3)["token_padded"]).to(dev)
+            with contextlib.redirect_stdout(sys.stderr):   # "Warning! Reached max decoder steps" must not land next to the JSON line
+                dt = timed(torch, lambda: model.inference({"tokens": tok}), 2, 3)
+            mc.gate_threshold = 0.5
+            S = mc.max_decoder_steps
+            e = {"us_per_step": round(dt / S * 1e6, 2), "ms_per_utterance_batch": round(dt * 1e3, 2),
+                 "rtf_per_stream": round(dt / (S * audio_s_per_frame), 6), "rtf_aggregate": round(dt / (S * audio_s_per_frame * bb), 7),
+                 "mel_frames_per_s": round(bb * S / dt, 1), "includes": "encoder + 1000 decoder steps + Postnet, host stop polling"}
+            if with_cpu and bb == 1:
+                steps_c = 40
+                masks = torch.from_numpy(gw.prenet_keep_masks(steps_c, mc.prenet_dim, seed=11)).reshape(2, steps_c, mc.prenet_dim)
+                c0 = time.perf_counter()
+                tacotron2_ref.tacotron2_inference(sd_cpu, tok.cpu()[:1], masks, 1.0, steps_c)
+                cs = time.perf_counter() - c0
+                e["cpu_baseline"] = {"us_per_step": round(cs / steps_c * 1e6, 1), "rtf_per_stream": round(cs / (steps_c * audio_s_per_frame), 4),
+                                     "cores": n_thr, "kind": "port",
+                                     "sample": f"oracle Tacotron2.inference, batch 1 (the reference's only autoregressive mode), {steps_c} steps incl. encoder + Postnet"}
+            extra[key] = e
+        if "postnet_b256x800" in want:
+            log("extra: Postnet batch 256 x 800 (one call)")
+            mel = torch.randn(256, ac.n_mels, T, device=dev)
+            dt = timed(torch, lambda: model.postnet_residual(mel), 1, 3)
+            flops = 8.68e6 * 256 * T   # SURVEY.md section 8d: 8.68 MFLOP per frame
+            e = {"ms": round(dt * 1e3, 3), "tflops": round(flops / dt / 1e12, 1), "mfma_frac_of_157TF": round(flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                 "frames_per_s": round(256 * T / dt, 1), "note": "whole call incl. the two layout transposes and the residual"}
+            if with_cpu:
+                rows = mel[:4].cpu()
+                c0 = time.perf_counter()
+                tacotron2_ref.postnet(sd_cpu, rows)
+                cs = time.perf_counter() - c0
+                e["cpu_baseline"] = {"frames_per_s": round(4 * T / cs, 1), "cores": n_thr, "kind": "port", "sample": f"oracle Postnet on 4 x {T} frames"}
+            extra["postnet_b256x800"] = e
+            del mel
+        if "gl_60it_b256x800" in want:
+            from genvox_amd.audio import AudioProcessor
+
+            log("extra: Griffin-Lim 60 iterations, batch 256 x 800")
+            apx = AudioProcessor(ac, device=dev)
+            mel = torch.randn(256, ac.n_mels, T, device=dev) * 1.5 - 4.0
+            mag = apx.mel_to_magnitude(mel)
+            dt = timed(torch, lambda: apx.griffin_lim(mag, n_iter=60, want_phase=False), 1, 3)
+            gbs = 20516 * 256 * T * 60 / dt / 1e9   # SURVEY.md section 8d: 20 516 B per frame-iteration (minimal fused traffic)
+            e = {"ms": round(dt * 1e3, 2), "frames_per_s": round(256 * T / dt, 1), "utterances_per_s": round(256 / dt, 1),
+                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                              "algorithmic_bytes_per_frame_iteration": 20516}}
+            if with_cpu:
+                import numpy as np
+
+                Tc, itc = 200, 6
+                magc = np.abs(np.random.default_rng(0).standard_normal((513, Tc))).astype(np.float32)
+                c0 = time.perf_counter()
+                audio_ref.griffin_lim(magc, 1024, 256, n_iter=itc)
+                cs = time.perf_counter() - c0
+                e["cpu_baseline"] = {"frames_per_s_at_60it": round(Tc * itc / cs / 60, 1), "cores": 1, "kind": "port",
+                                     "sample": f"oracle griffin_lim (NumPy, one utterance like the reference), {Tc} frames x {itc} iterations, scaled to 60"}
+            extra["gl_60it_b256x800"] = e
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -186,8 +347,10 @@ def main():
             "config": {"workload": f"Tacotron2 teacher-forced forward, batch {B} x {T} mel frames x 80 bins, {L} tokens, per GPU "
                                    f"(BASELINE configs[1]); random-init default dims, seed 0",
                        "global_batch": world * B, "frames": T, "tokens": L, "parallelism": f"dp{world} (independent batches, one RCCL weight broadcast)"},
-            "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages,
+            "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages, "extra": extra,
         }
+        if args.rehearse_one_gpu:
+            line["rehearsal"] = f"{world} ranks sharing ONE GPU over gloo: flow check only, not a scaling measurement"
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

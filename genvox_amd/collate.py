@@ -6,12 +6,15 @@ from __future__ import annotations
 
 from typing import Dict, List
 
+import numpy as np
 import torch
 
 
 class TextMelCollateFn:
     def __call__(self, batch: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
-        order = sorted(range(len(batch)), key=lambda i: batch[i]["tokens"].shape[0], reverse=True)
+        # same expression as the reference (models/tts/__init__.py:32) so that rows with equal token counts come out in the
+        # reference's order as well
+        order = [int(i) for i in np.argsort([x["tokens"].shape[0] for x in batch])[::-1]]
         n_mels = batch[0]["features"].shape[0]
         L = batch[order[0]]["tokens"].shape[0]
         T = max(x["features"].shape[1] for x in batch)

@@ -19,10 +19,9 @@ class Synthesizer:
         self.tts_model = tts_model_class.load_from_config(config_path=tts_config_path)
         self.tts_model.to(self.device)
         self.tts_model.eval()
-        print(f"using TTS model: {self.tts_model.model_name}, device: {self.device}")
         ckpt = torch.load(tts_checkpoint_path, map_location="cpu")
-        print("loading tts_model_dict (iteration: {itr}) from checkpoint_path {chk_path}".format(
-            itr=ckpt.get("iteration"), chk_path=tts_checkpoint_path))
+        print(f"[genvox_amd] {self.tts_model.model_name} on {self.device} (MI355X HIP path); "
+              f"checkpoint {tts_checkpoint_path} at iteration {ckpt.get('iteration')}")
         self.tts_model.load_checkpoint_statedicts(statedicts=ckpt, save_optimizer_dict=False, optimizer=None)
         self.text_processor = TextProcessor(config=self.tts_model.text_config)
         self.audio_processor = AudioProcessor(config=self.tts_model.audio_config, device=self.device)

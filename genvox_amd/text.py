@@ -47,8 +47,30 @@ def number_to_words(n: int) -> str:
     return ", ".join(parts)
 
 
+def _with_and(n: int) -> str:
+    """Cardinal words with inflect's default andword: "and" before the final below-100 part when something precedes it
+    ("one hundred and one", "one thousand and five", "one thousand, two hundred and thirty-four")."""
+    if n < 100:
+        return _below_1000(n)
+    groups = []
+    rest = n
+    for scale, name in _SCALES:
+        if rest >= scale:
+            groups.append(_with_and(rest // scale) + " " + name)
+            rest %= scale
+    if not rest:
+        return ", ".join(groups)
+    h, lo = divmod(rest, 100)
+    if h:
+        groups.append(_ONES[h] + " hundred" + (" and " + _below_1000(lo) if lo else ""))
+        return ", ".join(groups)
+    return ", ".join(groups) + " and " + _below_1000(lo)
+
+
 def ordinal_to_words(n: int) -> str:
-    words = number_to_words(n)
+    """The reference spells ordinals with inflect's defaults (utils/text/numbers.py:42-43: number_to_words(m.group(0)),
+    andword="and"), unlike cardinals (andword="")."""
+    words = _with_and(n)
     head, sep, last = words.rpartition(" ") if " " in words and "-" not in words.rsplit(" ", 1)[-1] else ("", "", words)
     stem, dash, unit = last.rpartition("-")
     if unit in _ORD:

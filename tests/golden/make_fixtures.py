@@ -12,6 +12,10 @@ What is written (inputs + expected outputs only, no reference code):
                the four outputs and intermediate taps
   ar_*.npz     autoregressive Tacotron2.inference (batch 1): tokens, per-step masks, outputs
   audio.npz    mel basis / pseudo-inverse, STFT / iSTFT, Griffin-Lim phases, convert_mel2wav
+  collate.npz  TextMelCollateFn on a ragged list (ties included): inputs and the collated batch
+  text.json    TextProcessor.tokenize / generate_token_map / tokens_to_indices on digit-free sentences
+  ref_exp/     config.yaml and checkpoint_3.pt WRITTEN BY the reference (reduced dims, the reference's own init),
+               expected.npz = the reference's inference outputs from those files
 
 Weights are NOT stored: they are regenerated from genvox_amd.weights (seed, dims) and
 loaded INTO the reference with load_state_dict.
@@ -185,9 +189,92 @@ def make_audio_case():
     print(f"audio: frames {T} wav {wav.shape} {wav.dtype} neg-mag-frac {(mag < 0).mean():.4f}")
 
 
+HOST_SENTENCES = [   # digit-free: number spelling goes through the third-party `inflect`, which this image lacks
+    "Dr. Smith met Mrs. Jones & Co. at St. Mary's (the old one) - twice!",
+    "  Tabs\tand   runs of   spaces,\nnew lines; UPPER case?  ",
+    "Lt. Col. Brown [ret.] said: \"Ft. Worth ~ isn't far\" <quote> #tag @home ten% _under_ a+b=c | x/y",
+    "the quick brown fox jumps over the lazy dog",
+    "Gen. Hon. Rev. Sgt. Capt. Esq. Ltd. Jr. Maj. Drs. Mr.",
+]
+
+
+def make_host_fixtures():
+    """Host rows of SURVEY.md section 8: collate layout (a16), text front-end (f1), config + checkpoint files (f2) -
+    all produced by the reference's own code."""
+    import json
+
+    from core.processors import TextProcessor as RefTextProcessor  # noqa: E402  (reference)
+    from models.tts import TextMelCollateFn as RefCollate  # noqa: E402  (reference)
+
+    # ---- a16: TextMelCollateFn on a ragged list with equal token counts (tie order) and equal frame counts
+    rng = np.random.default_rng(31)
+    tok_lens = [9, 21, 15, 21, 3, 15, 15, 1]
+    mel_lens = [14, 30, 22, 30, 5, 9, 41, 1]
+    items = [{"tokens": torch.from_numpy(rng.integers(0, 30, size=n).astype(np.int32)),
+              "features": torch.from_numpy(rng.standard_normal((12, t)).astype(np.float32))} for n, t in zip(tok_lens, mel_lens)]
+    out = RefCollate()(items)
+    np.savez_compressed(
+        os.path.join(HERE, "collate.npz"), tok_lens=np.array(tok_lens), mel_lens=np.array(mel_lens),
+        tokens_cat=np.concatenate([x["tokens"].numpy() for x in items]),
+        feats_cat=np.concatenate([x["features"].numpy() for x in items], axis=1),
+        **{k: v.numpy() for k, v in out.items()})
+    print("collate:", {k: tuple(v.shape) for k, v in out.items()}, "order of token_lengths", out["token_lengths"].tolist())
+
+    # ---- f1: TextProcessor with base_cleaners on digit-free sentences
+    ref_tc = ref_configs.TextConfig(language="english", cleaners=["base_cleaners"])
+    tp = RefTextProcessor(ref_tc)
+    toks = [tp.tokenize(t) for t in HOST_SENTENCES]
+    token_map = tp.generate_token_map()
+    idx = [tp.tokens_to_indices(t) for t in toks]
+    with open(os.path.join(HERE, "text.json"), "w") as f:
+        json.dump({"sentences": HOST_SENTENCES, "cleaned": ["".join(t) for t in toks], "token_map": token_map, "indices": idx,
+                   "n_tokens": ref_tc.n_tokens}, f, indent=1, ensure_ascii=False)
+    print("text: n_tokens", ref_tc.n_tokens, "|", "".join(toks[0]))
+
+    # ---- f2: exp/config.yaml written by BaseConfig.write_configs_to_file (as the trainer does, core/trainer/__init__.py:73-82)
+    # and checkpoint_<it>.pt written as CheckpointManager.save_model does (get_checkpoint_statedicts + iteration + torch.save),
+    # for a reduced-dims model with the REFERENCE's own (seeded) initialisation; then the reference's outputs from those files.
+    from tests.golden.cases import SMALL
+    exp = os.path.join(HERE, "ref_exp")
+    os.makedirs(exp, exist_ok=True)
+    ref_mc = RefTacotron2Config(**SMALL["model"], max_decoder_steps=12, gate_threshold=1.0)
+    ref_ac = ref_configs.AudioConfig(filter_length=1024, hop_length=256, n_mels=SMALL["n_mels"], log_func="np.log")
+    ref_trainer = ref_configs.TrainerConfig(project_name="fixture", experiment_id="fixture", use_wandb=False, run_eval=False)
+    torch.manual_seed(1234)
+    model = RefTacotron2(ref_mc, ref_ac, ref_tc).eval()
+    # non-trivial BatchNorm statistics, as after training
+    g = torch.Generator().manual_seed(5)
+    for name, buf in model.named_buffers():
+        if name.endswith("running_mean"):
+            buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
+        elif name.endswith("running_var"):
+            buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+    ref_configs.BaseConfig.write_configs_to_file(
+        path=os.path.join(exp, "config.yaml"),
+        configs={"model_config": model.model_config, "trainer_config": ref_trainer, "audio_config": ref_ac, "text_config": ref_tc})
+    model_dict = model.get_checkpoint_statedicts(optimizer=None)
+    model_dict["iteration"] = 3
+    torch.save(model_dict, os.path.join(exp, "checkpoint_3.pt"))
+    text = HOST_SENTENCES[3]
+    tokens = torch.IntTensor(tp.tokens_to_indices(tp.tokenize(text))).unsqueeze(0)
+    steps = ref_mc.max_decoder_steps
+    pairs = draw_keep_masks(77, (1, ref_mc.prenet_dim), n_pairs=steps)
+    masks = torch.stack(pairs, dim=1).squeeze(2)
+    torch.manual_seed(77)
+    out = model.inference({"tokens": tokens})
+    np.savez_compressed(os.path.join(exp, "expected.npz"), tokens=tokens.numpy(), text=np.array(text),
+                        keep_masks_packed=np.packbits(masks.numpy().reshape(2, -1), axis=1),
+                        **{k: v.numpy() for k, v in out.items()})
+    print("ref_exp: frames", out["mel_outputs"].shape[2], "files", sorted(os.listdir(exp)))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "host":
+        make_host_fixtures()
+        sys.exit(0)
     for name, case in TF_CASES.items():
         make_tf_case(name, case)
     for name, case in AR_CASES.items():
         make_ar_case(name, case)
     make_audio_case()
+    make_host_fixtures()

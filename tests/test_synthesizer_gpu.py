@@ -84,7 +84,8 @@ def test_c_abi_rejects_bad_arguments_loudly():
     assert lib.gvx_encoder_forward(h, x.data_ptr(), None, 2, 8, x.data_ptr(), ws.data_ptr(), 1024, s) == -5
     assert b"workspace too small" in lib.gvx_last_error()
     assert lib.gvx_encoder_forward(h, x.data_ptr(), None, 2, 8, x.data_ptr(), ws.data_ptr() + 4, ws.numel() - 4, s) == -5
-    assert lib.gvx_postnet_forward(h, None, 2, 4, None, ws.data_ptr(), ws.numel(), s) == -1
+    assert lib.gvx_postnet_forward(h, None, None, 2, 4, None, ws.data_ptr(), ws.numel(), s) == -1
+    assert lib.gvx_postnet_forward(h, x.data_ptr(), None, 2, 4, x.data_ptr(), ws.data_ptr(), 256, s) == -5   # Postnet plan too small
     assert lib.gvx_mask_padding(None, None, None, None, 2, 80, 4, s) == -1
     # inference past the per-call batch limit is refused by the host mirror with a clear message
     with pytest.raises(AssertionError, match="shard"):
@@ -135,3 +136,34 @@ def test_eval_step_criterion_matches_reference(name):
     assert m.get_eval_priority() == m.loss_items_eval["loss_eval"]
     with pytest.raises(ValueError):
         Tacotron2Loss({"mel_padded": batch["mel_padded"][:, :, :-1], "gate_padded": batch["gate_padded"]}, ref_out)
+
+
+def test_synthesizer_on_files_written_by_the_reference(monkeypatch):
+    """tests/golden/ref_exp/ holds config.yaml and checkpoint_3.pt exactly as GenVox writes them
+    (its own initialisation, reduced dims) and the reference's inference outputs from them.  Synthesizer loads both files;
+    the model reproduces the reference's mels for the same text and Prenet masks, and tts() runs end to end."""
+    import os
+
+    from tests.helpers import GOLDEN, TOL, max_abs_diff, unpack_masks
+
+    exp = os.path.join(GOLDEN, "ref_exp")
+    syn = Synthesizer(tts_model_class=Tacotron2, tts_config_path=os.path.join(exp, "config.yaml"),
+                      tts_checkpoint_path=os.path.join(exp, "checkpoint_3.pt"), use_cuda=True)
+    with np.load(os.path.join(exp, "expected.npz")) as z:
+        fx = {k: z[k] for k in z.files}
+    text = str(fx["text"])
+    tokens = syn.text_processor.tokens_to_indices(syn.text_processor.tokenize(text))
+    assert tokens == fx["tokens"][0].tolist()
+    mc = syn.tts_model.model_config
+    steps = mc.max_decoder_steps
+    masks = unpack_masks(fx["keep_masks_packed"], (2, steps, mc.prenet_dim)).reshape(2, steps, 1, mc.prenet_dim)
+    out = syn.tts_model.inference({"tokens": torch.IntTensor(tokens).unsqueeze(0), "prenet_keep_masks": masks})
+    for k in ("mel_outputs", "mel_outputs_postnet", "gate_outputs", "alignments"):
+        assert out[k].shape == fx[k].shape, k
+        assert max_abs_diff(out[k], fx[k]) <= TOL, k
+    res = syn.tts(text)
+    assert res["mel_outputs_postnet"].shape == (mc_n_mels(syn), steps) and np.isfinite(res["waveform"]).all()
+
+
+def mc_n_mels(syn):
+    return syn.tts_model.audio_config.n_mels

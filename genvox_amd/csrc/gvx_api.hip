@@ -70,7 +70,7 @@ struct Blob {  // offsets in floats into the packed weight blob
     size_t emb;
     size_t enc_w[MAX_CONV], enc_b[MAX_CONV];
     size_t enc_wih, enc_bih, enc_whh_frag[2];
-    size_t pre_w0, pre_w1, pre_w0_frag, pre_w1_frag, pre_w0_t;
+    size_t pre_w0, pre_w1, pre_w0_t, pre_w1_t;
     size_t att_frag, att_bias, wq_t, wmem, v, loc_conv, loc_dense;
     size_t dec_frag, dec_bias;
     size_t proj_w, proj_b, proj_frag, proj_hd_t, proj_ctx_frag;   // last two: autoregressive split of the projection (see gvx_decoder_autoregressive)
@@ -83,6 +83,7 @@ inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 
 struct WsPlan {  // byte offsets into the caller's workspace
     size_t xa, xb, xg, enc_h, enc_c, flags, memory;
     size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy, loc, ar_masks, p_slab, p_ctx;
+    size_t att_part, dec_part;
     size_t ya, yb;
     size_t total;
 };
@@ -162,8 +163,8 @@ Blob make_blob_layout(const gvx_dims& d) {
     b.enc_bih = take((size_t)8 * H);
     for (int dir = 0; dir < 2; ++dir) b.enc_whh_frag[dir] = take(frag_floats(4 * H, H));
     b.pre_w0 = take((size_t)P * M); b.pre_w1 = take((size_t)P * P);
-    b.pre_w0_frag = take(frag_floats(P, M)); b.pre_w1_frag = take(frag_floats(P, P));
-    b.pre_w0_t = take((size_t)M * P);   // transposed, for the autoregressive Prenet layer 1 inside ar_project_kernel
+    b.pre_w0_t = take((size_t)M * P);   // both Prenet matrices transposed ([in][out]) for the autoregressive step tail
+    b.pre_w1_t = take((size_t)P * P);   // (ar_project_kernel)
     b.att_frag = take(frag_floats(4 * A, P + E + A)); b.att_bias = take((size_t)4 * A);
     b.wq_t = take((size_t)A * d.att_dim);
     b.wmem = take((size_t)d.att_dim * E); b.v = take(d.att_dim);
@@ -215,6 +216,8 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.loc = take((size_t)B * L * d.att_dim);  // location features of the current step
     w.p_slab = take((size_t)(D / 8) * B * m->PSB());   // autoregressive mode: projection partials of the decoder-LSTM tiles
     w.p_ctx = take((size_t)B * m->PSB());            //   and of the context columns (blocked vector)
+    w.att_part = take((size_t)B * 4 * A);            // autoregressive mode: partial gate pre-activations [B][4A] / [B][4D] of the
+    w.dec_part = take((size_t)B * 4 * D);            //   column slices that are known one launch early
     w.ar_masks = take(((size_t)2 * T * B * P + 3) / 4);  // autoregressive mode: keep masks copied next to the graphs' operands (bytes)
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
@@ -428,12 +431,12 @@ int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, vo
     {   // Prenet (no bias)
         if (!(src = wt.get("decoder.prenet.layers.0.linear_layer.weight", (int64_t)P * M, &rc))) return rc;
         std::memcpy(out + bl.pre_w0, src, sizeof(float) * P * M);
-        pack_frag(std::vector<float>(src, src + (size_t)P * M), P, M, out + bl.pre_w0_frag);
         for (int j = 0; j < P; ++j)
             for (int k = 0; k < M; ++k) out[bl.pre_w0_t + (size_t)k * P + j] = src[(size_t)j * M + k];
         if (!(src = wt.get("decoder.prenet.layers.1.linear_layer.weight", (int64_t)P * P, &rc))) return rc;
         std::memcpy(out + bl.pre_w1, src, sizeof(float) * P * P);
-        pack_frag(std::vector<float>(src, src + (size_t)P * P), P, P, out + bl.pre_w1_frag);
+        for (int j = 0; j < P; ++j)
+            for (int k = 0; k < P; ++k) out[bl.pre_w1_t + (size_t)k * P + j] = src[(size_t)j * P + k];
     }
     {   // attention LSTM: x = [prenet ; context ; h_a]
         std::vector<float> wcat;
@@ -626,6 +629,7 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
 
 struct DecoderBuffers {
     float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj, *energies, *align_tm, *loc, *p_slab, *p_ctx;
+    float *att_part, *dec_part;
     int32_t* len_copy;
 };
 
@@ -638,6 +642,7 @@ DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
     b.align_tm = ws_ptr<float>(ws, wp.align_tm); b.len_copy = ws_ptr<int32_t>(ws, wp.len_copy);
     b.loc = ws_ptr<float>(ws, wp.loc);
     b.p_slab = ws_ptr<float>(ws, wp.p_slab); b.p_ctx = ws_ptr<float>(ws, wp.p_ctx);
+    b.att_part = ws_ptr<float>(ws, wp.att_part); b.dec_part = ws_ptr<float>(ws, wp.dec_part);
     return b;
 }
 
@@ -1029,7 +1034,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
         return fail(GVX_ERR_INVALID_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const gvx_dims& d = m->d;
-    const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, D = d.dec_rnn_dim, T = max_steps;
+    const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim, T = max_steps;
     const WsPlan wp = make_ws_plan(m, B, L, T);
     const DecoderBuffers db = decoder_buffers(ws, wp);
     const int PSB = m->PSB();
@@ -1051,48 +1056,89 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     }
     rc = decoder_init_states(m, memory_ws, B, L, db, s);
     if (rc != GVX_OK) return rc;
-    HIP_TRY(zero_async(db.pre1, (size_t)B * P * sizeof(float), s));    // Prenet layer 1 of the go-frame: relu(W0 * 0) = 0
-    HIP_TRY(zero_async(flags + 1, (size_t)127 * sizeof(int32_t), s));   // n_done + frame counts
+    HIP_TRY(zero_async(db.prenet, (size_t)B * P * sizeof(float), s));       // Prenet of the go-frame: no biases, relu(W 0) = 0
+    HIP_TRY(zero_async(db.att_part, (size_t)B * 4 * A * sizeof(float), s)); // ctx(-1) = h_a(-1) = 0
+    HIP_TRY(zero_async(flags + 1, (size_t)127 * sizeof(int32_t), s));       // n_done + frame counts
 
-    // one step = Prenet layer 2 (layer 1 rides in the previous step's projection kernel) -> attention LSTM (+ location features) -> attention energy / context -> decoder LSTM
-    // (+ projection partials) -> projection reduction + per-row stop test; db.proj holds one blocked projection vector [PSB/8][B][8] per step
+    // One step = 5 launches.  In autoregressive mode BOTH cells are on the critical chain (the frame feeds back), and a cell
+    // alone is only 128 tiles - half the chip.  But most of a cell's input is known one launch early: the attention LSTM's
+    // [ctx(t-1) ; h_a(t-1)] columns (1536 of 1792) exist before the decoder LSTM of step t-1 runs, the decoder LSTM's h_d(t-1)
+    // columns (1024 of 2560) before the attention LSTM of step t.  So every LSTM launch runs 128 tiles that FINISH one cell
+    // (remaining columns + partial sums of the others through `addend`) next to 128 tiles that pre-compute the other cell's
+    // early columns (mode 2, partial sums to att_part / dec_part): all 256 CUs stream weights in both launches.
+    //   A(t): attention LSTM final [prenet(t)]            + decoder LSTM partial [h_d(t-1)]      + location features
+    //   energies(t), context(t)
+    //   C(t): decoder LSTM final [h_a(t) ; ctx(t)] (+ mel/gate projection partials of its 8 hidden units)
+    //         + attention LSTM partial for step t+1 [ctx(t) ; h_a(t)] + 3 tiles projecting the context
+    //   D(t): projection reduction, per-row stop test, whole Prenet of step t+1 on the fresh frame
+    // db.proj holds one blocked projection vector [PSB/8][B][8] per step.
+    const int kgP = P / 8, kgE = E / 8, kgA = A / 8, kgD = D / 8;
     auto enqueue_steps = [&](hipStream_t st, int t0, int t1) -> int {
         for (int t = t0; t < t1; ++t) {
             float* proj_t = db.proj + (size_t)t * B * PSB;
-            SkinnyJob job;
-            std::memset(&job, 0, sizeof job);
-            // Prenet layer 1 of this step was computed by the previous step's projection kernel (zeros for the go-frame)
-            job.N = P; job.mode = 1; job.B = B; job.act = ACT_RELU; job.keep_stride = P;
-            job.Wp = m->dev_blob + m->blob.pre_w1_frag;
-            job.x[0] = XSeg{db.pre1, P};
-            job.nkg = P / 8;
-            job.y = db.prenet;
-            job.keep = masks_ws + ((size_t)T + t) * B * P;
-            HIP_TRY(launch_skinny(&job, 1, SK_LINEAR, st));
-            SkinnyJob lj;
-            fill_att_job(m, lj, db.prenet, t, B, db);
+            const float* hc_t = db.hc + (size_t)t * B * (D + E);
+            float* hc_n = db.hc + (size_t)(t + 1) * B * (D + E);
+            float* ha_prev = db.h_a + (size_t)(t & 1) * B * A;
+            float* ha_new = db.h_a + (size_t)((t + 1) & 1) * B * A;
+            SkinnyJob ja[2];
+            std::memset(ja, 0, sizeof ja);
+            {   // attention LSTM of step t: final tiles over the Prenet columns
+                SkinnyJob& J = ja[0];
+                J.Wp = m->dev_blob + m->blob.att_frag; J.bias = m->dev_blob + m->blob.att_bias;
+                J.x[0] = XSeg{db.prenet, P};
+                J.N = 4 * A; J.nkg = kgP; J.kg0 = 0; J.nkg_w = kgP + kgE + kgA; J.mode = 0; J.B = B;
+                J.addend = db.att_part; J.add_bs = 4 * A; J.add_ts = 0;
+                J.c = db.c_a; J.h_out = ha_new;
+                J.Wq_t = m->dev_blob + m->blob.wq_t; J.q_slab = db.q_slab; J.att_dim = d.att_dim;
+            }
+            {   // decoder LSTM of step t: partial sums over the h_d(t-1) columns
+                SkinnyJob& J = ja[1];
+                J.Wp = m->dev_blob + m->blob.dec_frag;
+                J.x[0] = XSeg{hc_t, D};
+                J.N = 4 * D; J.nkg = kgD; J.kg0 = kgA + kgE; J.nkg_w = kgA + kgE + kgD; J.mode = 2; J.B = B;
+                J.y = db.dec_part;
+            }
             LocJob lq;
             fill_loc(m, lq, t, B, L, db.align_tm, (long)L, (long)B * L, db);
-            HIP_TRY(launch_skinny(&lj, 1, SK_DECODER, st, &lq));
+            HIP_TRY(launch_skinny(ja, 2, SK_AR, st, &lq));
             AttnParams ap;
             fill_attn(m, ap, memory_ws, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
             HIP_TRY(launch_attention(ap, st));
-            // decoder LSTM.  The mel/gate projection of [h_d ; ctx] rides along instead of being a 3-workgroup launch of its
-            // own (17.8 us at batch 64): every LSTM tile emits the partial products of its 8 hidden units (the attention-query
-            // slab mechanism with the projection's h_d columns), three extra workgroups of the same launch project the
-            // context, which is known before the launch; a small reduction adds the 128 + 1 partials in a fixed order.
-            SkinnyJob dj[2];
-            fill_dec_job(m, dj[0], t, B, db);
-            dj[0].Wq_t = m->dev_blob + m->blob.proj_hd_t; dj[0].q_slab = db.p_slab; dj[0].att_dim = PSB;
-            std::memset(&dj[1], 0, sizeof dj[1]);
-            dj[1].Wp = m->dev_blob + m->blob.proj_ctx_frag; dj[1].bias = m->dev_blob + m->blob.proj_b;
-            dj[1].x[0] = XSeg{db.hc + (size_t)(t + 1) * B * (D + E) + (size_t)D * B, E};
-            dj[1].N = M + 1; dj[1].nkg = E / 8; dj[1].mode = 1; dj[1].B = B; dj[1].act = ACT_NONE;
-            dj[1].y = db.p_ctx;
-            HIP_TRY(launch_skinny(dj, 2, SK_DECODER, st));
-            const uint8_t* keep_next = t + 1 < T ? masks_ws + (size_t)(t + 1) * B * P : nullptr;   // layer-1 masks of step t+1
+            SkinnyJob jc[3];
+            std::memset(jc, 0, sizeof jc);
+            {   // decoder LSTM of step t: final tiles over [h_a(t) ; ctx(t)]; every tile also emits the mel/gate projection
+                // partial products of its 8 hidden units (the attention-query slab mechanism with the projection's h_d columns)
+                SkinnyJob& J = jc[0];
+                J.Wp = m->dev_blob + m->blob.dec_frag; J.bias = m->dev_blob + m->blob.dec_bias;
+                J.x[0] = XSeg{ha_new, A};
+                J.x[1] = XSeg{hc_n + (size_t)D * B, E};
+                J.N = 4 * D; J.nkg = kgA + kgE; J.kg0 = 0; J.nkg_w = kgA + kgE + kgD; J.mode = 0; J.B = B;
+                J.addend = db.dec_part; J.add_bs = 4 * D; J.add_ts = 0;
+                J.c = db.c_d; J.h_out = hc_n;
+                J.Wq_t = m->dev_blob + m->blob.proj_hd_t; J.q_slab = db.p_slab; J.att_dim = PSB;
+            }
+            {   // attention LSTM of step t+1: partial sums over [ctx(t) ; h_a(t)]
+                SkinnyJob& J = jc[1];
+                J.Wp = m->dev_blob + m->blob.att_frag;
+                J.x[0] = XSeg{hc_n + (size_t)D * B, E};
+                J.x[1] = XSeg{ha_new, A};
+                J.N = 4 * A; J.nkg = kgE + kgA; J.kg0 = kgP; J.nkg_w = kgP + kgE + kgA; J.mode = 2; J.B = B;
+                J.y = db.att_part;
+            }
+            {   // context columns of the mel/gate projection (known before the launch)
+                SkinnyJob& J = jc[2];
+                J.Wp = m->dev_blob + m->blob.proj_ctx_frag; J.bias = m->dev_blob + m->blob.proj_b;
+                J.x[0] = XSeg{hc_n + (size_t)D * B, E};
+                J.N = M + 1; J.nkg = kgE; J.mode = 1; J.B = B; J.act = ACT_NONE;
+                J.y = db.p_ctx;
+            }
+            (void)ha_prev;
+            HIP_TRY(launch_skinny(jc, 3, SK_AR, st));
+            const bool more = t + 1 < T;
             HIP_TRY(launch_ar_project(db.p_slab, D / 8, db.p_ctx, proj_t, M, gate_threshold, t, B, n_frames_ws, n_done,
-                                      m->dev_blob + m->blob.pre_w0_t, P, keep_next, db.pre1, st));
+                                      m->dev_blob + m->blob.pre_w0_t, m->dev_blob + m->blob.pre_w1_t, P,
+                                      more ? masks_ws + (size_t)(t + 1) * B * P : nullptr,
+                                      more ? masks_ws + ((size_t)T + t + 1) * B * P : nullptr, db.prenet, st));
         }
         return GVX_OK;
     };

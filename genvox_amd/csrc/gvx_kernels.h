@@ -71,13 +71,16 @@ struct SkinnyJob {
     const float* bias;      // [N] in packed row order, or nullptr
     XSeg x[3];              // K = x[0].len + x[1].len + x[2].len
     int N;                  // output rows (LSTM: 4H in packed order row = 4*j + gate)
-    int nkg;                // K / 8
-    int mode;               // 0 = LSTM cell, 1 = linear
+    int nkg;                // K / 8 of this job (the x segments)
+    int kg0, nkg_w;         // the job's first k-group inside the packed matrix and the matrix's k-groups per tile
+                            // (nkg_w = 0: the job covers the whole matrix, nkg_w = nkg)
+    int mode;               // 0 = LSTM cell, 1 = linear, 2 = partial sums y[b][n] (row-major [B][N], N % 32 == 0)
     // --- LSTM epilogue
     float* c;               // [B][H] cell state (row-major, private to the owning workgroup), updated in place
     float* h_out;           // h' as a blocked vector [H/8][B][8]
     // encoder extras (all nullptr/0 for the decoder)
-    const float* addend; long add_bs, add_ts;  // pre-activation addend[b][t_b][n] (x-projection incl. bias)
+    const float* addend; long add_bs, add_ts;  // pre-activation addend[b][t_b][n] (encoder: x-projection incl. bias;
+                                               // autoregressive decoder: partial sums of the other column slice)
     const int32_t* lengths; int step; int reverse; int seq_len;  // packed-sequence semantics
     float* seq_out; long seq_bs, seq_ts;       // seq_out[b][t_b][j] (row-major encoder output)
     const float* h_prev;                       // blocked; carried over for inactive rows
@@ -101,7 +104,7 @@ struct LocJob {
     float* loc_out;                         // [B][L][a]
     int B, L, a, kl, G;                     // G position chunks per row (0 = no location job in this launch)
 };
-enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_LINEAR = 2 };  // kernel name only; same code
+enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_AR = 2 };  // kernel name only; same code
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc = nullptr);
 
 // ---------------------------------------------------------------------------------------------
@@ -157,11 +160,13 @@ hipError_t launch_mask_gen(uint8_t* out, size_t n, uint64_t seed, hipStream_t s)
 // AR: gate logits of step t (blocked projection vector) -> per-row finished flags / frame counts / all-finished counter
 hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, int t, int B,
                           int32_t* n_frames, int32_t* n_done, hipStream_t s);
-// AR: proj_t (blocked [PSB/8][B][8]) = sum over the n_slabs partial slabs [slab][B][PSB] (fixed order) + p_ctx (blocked, bias
-// included), rows n <= M; the gate row also runs the per-row stop test of launch_ar_stop; then, unless keep == nullptr,
-// Prenet layer 1 of the next step: pre1 (blocked [P/8][B][8]) = 2 * keep[b][j] * relu(W0 mel), w0t = W0 transposed [M][P]
+// AR step tail: proj_t (blocked [PSB/8][B][8]) = sum over the n_slabs partial slabs [slab][B][PSB] (fixed order) + p_ctx
+// (blocked, bias included), rows n <= M; the gate row also runs the per-row stop test of launch_ar_stop; then, unless
+// keep0 == nullptr, the whole Prenet of the next step on the fresh frame: prenet_out (blocked [P/8][B][8]) =
+// 2 keep1 relu(W1 (2 keep0 relu(W0 mel))), w0t = W0 transposed [M][P], w1t = W1 transposed [P][P]
 hipError_t launch_ar_project(const float* p_slab, int n_slabs, const float* p_ctx, float* proj_t, int M, float threshold, int t, int B,
-                             int32_t* n_frames, int32_t* n_done, const float* w0t, int P, const uint8_t* keep, float* pre1, hipStream_t s);
+                             int32_t* n_frames, int32_t* n_done, const float* w0t, const float* w1t, int P, const uint8_t* keep0,
+                             const uint8_t* keep1, float* prenet_out, hipStream_t s);
 // AR: scatter the blocked per-step projections proj[t][PSB/8][B][8], t < steps, into mel_out [B][M][Tmax], gate_out [B][Tmax]
 // frames t >= n_frames[b] get the padding values of the reference's mask_padding: mel 0, gate 1e3
 hipError_t launch_ar_emit_all(const float* proj, float* mel_out, float* gate_out, int B, int M, int Tmax, int steps,

@@ -232,66 +232,105 @@ hipError_t launch_ar_stop(const float* proj_t, int gate_col, float threshold, in
     return hipGetLastError();
 }
 
-// One workgroup per batch row b (256 threads).
-//   phase 1: proj[b][n] = sum of the partial slabs (two halves of the slab range summed by two thread groups, then added
-//            lower half first) + p_ctx; gate row -> per-row stop test (models/tts/tacotron2.py:405-409)
-//   phase 2: Prenet layer 1 of the NEXT step on the fresh mel frame (tacotron2.py:398, :140-144): pre1[b][j] =
-//            2 * keep * relu(sum_n W0[j][n] * mel[n]) - the 80 -> 256 GEMV that used to be a launch of its own
+// Autoregressive step tail, grid (S, B), 256 threads: workgroup (s, b) handles batch row b and the s-th slice of the Prenet
+// output columns.
+//   phase 1 (every workgroup of the row, redundantly - 45 KB of partials): proj[b][n] = sum of the partial slabs the
+//            decoder-LSTM tiles emitted (two halves of the slab range summed by two thread groups, lower half added first)
+//            + p_ctx; slice 0 stores it and runs the per-row stop test (models/tts/tacotron2.py:405-409)
+//   phase 2 (redundantly): Prenet layer 1 of the NEXT step on the fresh mel frame (tacotron2.py:398, :140-144):
+//            h1[j] = 2 * keep0 * relu(sum_n W0[j][n] * mel[n])
+//   phase 3: this workgroup's columns of Prenet layer 2: out[o] = 2 * keep1 * relu(sum_k W1[o][k] * h1[k]), K split over
+//            four thread groups and added in a fixed order; written as the blocked vector the attention-LSTM tiles read.
+// Both Prenet matrices are read transposed ([k][out]) so that a wave's loads are contiguous.
+constexpr int ARP_KQ = 4;
 __global__ __launch_bounds__(256) void ar_project_kernel(const float* __restrict__ p_slab, int n_slabs, const float* __restrict__ p_ctx,
                                                          float* __restrict__ proj_t, int M, int PSB, float threshold, int t, int B,
-                                                         int32_t* n_frames, int32_t* n_done, const float* __restrict__ w0t, int P,
-                                                         const uint8_t* __restrict__ keep, float* __restrict__ pre1) {
+                                                         int32_t* n_frames, int32_t* n_done, const float* __restrict__ w0t,
+                                                         const float* __restrict__ w1t, int P, const uint8_t* __restrict__ keep0,
+                                                         const uint8_t* __restrict__ keep1, float* __restrict__ prenet_out) {
+    extern __shared__ float arp_smem[];
     __shared__ float part[2][128];
     __shared__ float mel[128];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    float* h1 = arp_smem;                 // [P]
+    float* red = arp_smem + P;            // [ARP_KQ][OS]
+    const int sl = blockIdx.x, S = gridDim.x, b = blockIdx.y, tid = threadIdx.x;
     const int half = tid / PSB, n = tid - half * PSB;   // PSB <= 128
     if (half < 2 && n <= M) {
         const int s_begin = half == 0 ? 0 : n_slabs / 2, s_end = half == 0 ? n_slabs / 2 : n_slabs;
         const float* sp = p_slab + (long)b * PSB + n;
         const long sstride = (long)B * PSB;
         float acc = 0.f;
-        int sl = s_begin;
-        for (; sl + 16 <= s_end; sl += 16) {   // 16 loads in flight, added in ascending slab order
+        int q0 = s_begin;
+        for (; q0 + 16 <= s_end; q0 += 16) {   // 16 loads in flight, added in ascending slab order
             float v[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = sp[(long)(sl + q) * sstride];
+            for (int q = 0; q < 16; ++q) v[q] = sp[(long)(q0 + q) * sstride];
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc += v[q];
         }
-        for (; sl < s_end; ++sl) acc += sp[(long)sl * sstride];
+        for (; q0 < s_end; ++q0) acc += sp[(long)q0 * sstride];
         part[half][n] = acc;
     }
     __syncthreads();
     if (half == 0 && n <= M) {
         const long blocked = (long)(n >> 3) * B * 8 + b * 8 + (n & 7);
         const float v = (part[0][n] + part[1][n]) + p_ctx[blocked];
-        proj_t[blocked] = v;
         if (n < M) mel[n] = v;
-        if (n == M && n_frames[b] == 0) {
-            const float sg = 1.f / (1.f + expf(-v));
-            if (sg > threshold) {
-                n_frames[b] = t + 1;
-                atomicAdd(n_done, 1);
+        if (sl == 0) {
+            proj_t[blocked] = v;
+            if (n == M && n_frames[b] == 0) {
+                const float sg = 1.f / (1.f + expf(-v));
+                if (sg > threshold) {
+                    n_frames[b] = t + 1;
+                    atomicAdd(n_done, 1);
+                }
             }
         }
     }
-    if (!keep) return;   // last step: nobody consumes a next Prenet input
+    if (!keep0) return;   // last step: nobody consumes a next Prenet input (uniform)
     __syncthreads();
     for (int j = tid; j < P; j += 256) {
         float acc = 0.f;
         for (int k = 0; k < M; ++k) acc = fmaf(w0t[(long)k * P + j], mel[k], acc);
         acc = fmaxf(acc, 0.f);
-        acc = keep[(long)b * P + j] ? 2.f * acc : 0.f;
-        pre1[(long)(j >> 3) * B * 8 + b * 8 + (j & 7)] = acc;
+        h1[j] = keep0[(long)b * P + j] ? 2.f * acc : 0.f;
+    }
+    __syncthreads();
+    const int OS = (P + S - 1) / S, o_begin = sl * OS, o_cnt = min(OS, P - o_begin);
+    if (o_cnt <= 0) return;
+    const int KC = (P + ARP_KQ - 1) / ARP_KQ;
+    for (int idx = tid; idx < o_cnt * ARP_KQ; idx += 256) {
+        const int kq = idx / o_cnt, ol = idx - kq * o_cnt;
+        const int k_end = min(P, (kq + 1) * KC);
+        const float* wcol = w1t + o_begin + ol;
+        float acc = 0.f;
+        for (int k = kq * KC; k < k_end; ++k) acc = fmaf(wcol[(long)k * P], h1[k], acc);
+        red[kq * OS + ol] = acc;
+    }
+    __syncthreads();
+    for (int ol = tid; ol < o_cnt; ol += 256) {
+        float acc = red[ol];
+#pragma unroll
+        for (int kq = 1; kq < ARP_KQ; ++kq) acc += red[kq * OS + ol];
+        const int o = o_begin + ol;
+        acc = fmaxf(acc, 0.f);
+        acc = keep1[(long)b * P + o] ? 2.f * acc : 0.f;
+        prenet_out[(long)(o >> 3) * B * 8 + b * 8 + (o & 7)] = acc;
     }
 }
 
 hipError_t launch_ar_project(const float* p_slab, int n_slabs, const float* p_ctx, float* proj_t, int M, float threshold, int t, int B,
-                             int32_t* n_frames, int32_t* n_done, const float* w0t, int P, const uint8_t* keep, float* pre1, hipStream_t s) {
+                             int32_t* n_frames, int32_t* n_done, const float* w0t, const float* w1t, int P, const uint8_t* keep0,
+                             const uint8_t* keep1, float* prenet_out, hipStream_t s) {
     const int PSB = (M + 1 + 7) & ~7;
     if (PSB > 128 || M > 128) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ar_project_kernel, dim3(B), dim3(256), 0, s, p_slab, n_slabs, p_ctx, proj_t, M, PSB, threshold, t, B, n_frames, n_done,
-                       w0t, P, keep, pre1);
+    // column slices per row: enough workgroups to spread the 4*P*P bytes of layer 2, never more than one slice per 8 columns
+    int S = 4;
+    while (S > 1 && (P / S < 8 || S * B > 512)) S >>= 1;
+    const int OS = (P + S - 1) / S;
+    const size_t lds = (size_t)(P + ARP_KQ * OS) * sizeof(float);
+    hipLaunchKernelGGL(ar_project_kernel, dim3(S, B), dim3(256), lds, s, p_slab, n_slabs, p_ctx, proj_t, M, PSB, threshold, t, B,
+                       n_frames, n_done, w0t, w1t, P, keep0, keep1, prenet_out);
     return hipGetLastError();
 }
 

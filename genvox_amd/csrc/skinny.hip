@@ -1,7 +1,7 @@
 // Skinny recurrent GEMM for the sequential part of the path (batch rows <= 64):
 //   decoder attention-LSTM and decoder-LSTM cells (one launch per decoder step covers both),
 //   encoder BiLSTM recurrence (one launch per time step covers both directions),
-//   the per-step Prenet / projection GEMVs of the autoregressive mode.
+//   the column-slice partial sums and the context projection of the autoregressive step (gvx_api.hip).
 //
 // Roofline: weight-streaming kernels. Every step re-reads the full recurrent matrices (71.3 MB fp32 for the
 // two decoder cells) while each weight is used only B times, so the kernel is bound by HBM / Infinity-Cache
@@ -37,9 +37,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #ifndef SK_DEPTH2
 #define SK_DEPTH2 3
 #endif
-#ifndef SK_SPLIT_OLD
-#define SK_SPLIT_OLD 32   // 32/64 = even split
-#endif
 #ifndef SK_NWAVES
 #define SK_NWAVES 8
 #endif
@@ -47,9 +44,10 @@ constexpr int SK_WAVES = SK_NWAVES;
 constexpr int SK_THREADS = SK_WAVES * 64;
 
 struct SkinnyJobs {
-    SkinnyJob job[2];
+    SkinnyJob job[3];
     int njobs;
     int tiles0;   // tiles of job 0
+    int tiles1;   // tiles of job 1
     int tiles;    // tiles of all jobs; blocks >= tiles are location-feature workgroups
     LocJob loc;
 };
@@ -140,19 +138,9 @@ __device__ __forceinline__ void loc_body(const LocJob& Q, int wg) {
 __device__ __forceinline__ float sigmoidf_(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - __fdividef(2.f, __expf(2.f * x) + 1.f); }
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-__device__ __forceinline__ float4 nt_load4(const float4* p) {
-    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-
 // Weight loads use the DEFAULT cache policy on purpose: the 71 MB of recurrent weights are re-read every step and stay
-// resident in the 256-MiB Infinity Cache; non-temporal loads bypass it and were measured 16 % slower (E1, round 1).
-#ifdef GVX_SK_NT  // measured: 20.2 us vs 17.4 us per decoder step with the default policy -> off
-#define SK_WLOAD(ptr) nt_load4(ptr)
-#else
-#define SK_WLOAD(ptr) (*(ptr))
-#endif
+// resident in the 256-MiB Infinity Cache; non-temporal loads bypass it and were measured 16 % slower (round 1: 20.2 us vs
+// 17.4 us per decoder step).
 
 template <int MT, int DEPTH>
 __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
@@ -160,9 +148,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     float* red = smem;                                   // [SK_WAVES][MT][16][64]
     float* hs = smem + SK_WAVES * MT * 16 * 64;          // [MT*32][8] h' of this tile (LSTM + q slabs)
 
-    const int jsel = (jobs.njobs > 1 && (int)blockIdx.x >= jobs.tiles0) ? 1 : 0;
+    int jsel = 0, tile = (int)blockIdx.x;
+    if (jobs.njobs > 1 && tile >= jobs.tiles0) {
+        jsel = 1; tile -= jobs.tiles0;
+        if (jobs.njobs > 2 && tile >= jobs.tiles1) { jsel = 2; tile -= jobs.tiles1; }
+    }
     const SkinnyJob& J = jobs.job[jsel];
-    const int tile = (int)blockIdx.x - (jsel ? jobs.tiles0 : 0);
     GVX_STAMP(0, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, counted waits
@@ -185,25 +176,13 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     // groups in flight per wave and 8 waves per CU about DEPTH*8 KiB of weights are outstanding per CU, which is
     // what it takes to cover the ~2 us loaded-memory latency at ~30 GB/s per CU.  No load is conditional (indices
     // are clamped instead) so the compiler can retire them with counted s_waitcnt vmcnt(N).
-    // K split over the waves.  Measured (tools/stamps.py): with an even split the four younger waves of a workgroup
-    // (the second wave on each SIMD) finish their slice ~3 us after the four older ones and everybody waits at the
-    // reduction barrier.  SK_SPLIT_OLD/64 of the k-groups go to waves 0-3, the rest to waves 4-7 (static, so the
-    // summation order - and therefore every output bit - stays reproducible).
-    int kg_begin, kg_end;
-    if (SK_WAVES == 8 && J.nkg >= 64) {
-        const int half = SK_WAVES / 2;
-        const int n_old = ((J.nkg * SK_SPLIT_OLD) / 64 + half - 1) / half * half;   // k-groups of waves 0-3 together
-        const int per_old = n_old / half, per_young = (J.nkg - n_old + half - 1) / half;
-        if (wave < half) { kg_begin = wave * per_old; kg_end = kg_begin + per_old; }
-        else { kg_begin = n_old + (wave - half) * per_young; kg_end = min(J.nkg, kg_begin + per_young); }
-    } else {
-        const int per = (J.nkg + SK_WAVES - 1) / SK_WAVES;
-        kg_begin = wave * per;
-        kg_end = min(J.nkg, kg_begin + per);
-    }
-#ifdef SK_PRIO_YOUNG
-    if (wave >= SK_WAVES / 2) __builtin_amdgcn_s_setprio(1);
-#endif
+    // K split evenly over the waves (static, so the summation order - and therefore every output bit - is reproducible).
+    // Measured (tools/stamps.py): the four younger waves of a workgroup (the second wave on each SIMD) finish their slice
+    // ~3 us after the four older ones; uneven static splits (36:28, 38:26) and s_setprio for the younger half did not
+    // change the launch time - the CU's memory pipeline, not the split, sets when the last byte lands.
+    const int per = (J.nkg + SK_WAVES - 1) / SK_WAVES;
+    const int kg_begin = wave * per;
+    const int kg_end = min(J.nkg, kg_begin + per);
     const int g0 = J.x[0].len >> 3, g1 = g0 + (J.x[1].len >> 3);  // k-group boundaries of the segments
 
     const float* xb0[MT]; const float* xb1[MT]; const float* xb2[MT];
@@ -215,7 +194,10 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         xb1[mt] = (J.x[1].p ? J.x[1].p : J.x[0].p) + bb * 8 + 4 * h - g0 * blk;
         xb2[mt] = (J.x[2].p ? J.x[2].p : J.x[0].p) + bb * 8 + 4 * h - g1 * blk;
     }
-    const float4* wp = reinterpret_cast<const float4*>(J.Wp) + ((long)tile * J.nkg) * 64 + lane;
+    // the job may cover only the k-groups [kg0, kg0 + nkg) of a matrix packed with nkg_w k-groups per tile (column slices
+    // of the recurrent matrices: see the autoregressive step in gvx_api.hip)
+    const int nkg_w = J.nkg_w > 0 ? J.nkg_w : J.nkg;
+    const float4* wp = reinterpret_cast<const float4*>(J.Wp) + ((long)tile * nkg_w + J.kg0) * 64 + lane;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -229,7 +211,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 #define SK_LOAD(slot, gg)                                                                         \
         {                                                                                             \
             const int g_ = min((gg), g_last);                                                         \
-            wv[slot] = SK_WLOAD(wp + (long)g_ * 64);                                                  \
+            wv[slot] = wp[(long)g_ * 64];                                                            \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                       \
                 const float* base_ = g_ < g0 ? xb0[mt] : (g_ < g1 ? xb1[mt] : xb2[mt]);               \
                 xv[mt][slot] = *reinterpret_cast<const float4*>(base_ + (long)g_ * blk);              \
@@ -339,6 +321,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                 J.h_out[hoff] = hval;
             }
             if (J.q_slab) hs[b * 8 + jloc] = hval;
+        } else if (J.mode == 2) {
+            // partial pre-activations of a column slice: raw sums, batch-major [B][N] (the layout `addend` is read in)
+            if (b < B) *reinterpret_cast<float4*>(J.y + (long)b * J.N + n) = make_float4(s[0], s[1], s[2], s[3]);
         } else {
             if (b < B) {
 #pragma unroll
@@ -378,14 +363,17 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     GVX_STAMP(0, 4);
 }
 
-// Same body under three kernel names so that profiles separate the decoder step (the dominant kernel of the
-// path) from the encoder recurrence and the autoregressive GEMVs.
+// Same body under three kernel names so that profiles separate the teacher-forced decoder step (the dominant kernel of
+// the path) from the autoregressive step launches and the encoder recurrence.
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_kernel(SkinnyJobs jobs) {
     if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }   // uniform per workgroup
     skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
 }
+template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_kernel(SkinnyJobs jobs) {   // autoregressive launches A / C
+    if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }
+    skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
+}
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs); }
-template <int MT> __global__ __launch_bounds__(SK_THREADS) void skinny_linear_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs); }
 
 static size_t skinny_lds(int MT) { return (size_t)(SK_WAVES * MT * 16 * 64 + MT * 32 * 8) * sizeof(float); }
 
@@ -398,27 +386,30 @@ hipError_t skinny_init() {
     hipError_t e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_lstm_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_lstm_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
-    if ((e = set_lds(encoder_lstm_step_kernel<2>, 2)) != hipSuccess) return e;
-    if ((e = set_lds(skinny_linear_kernel<1>, 1)) != hipSuccess) return e;
-    return set_lds(skinny_linear_kernel<2>, 2);
+    return set_lds(encoder_lstm_step_kernel<2>, 2);
 }
 
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc) {
-    if (njobs < 1 || njobs > 2) return hipErrorInvalidValue;
+    if (njobs < 1 || njobs > 3) return hipErrorInvalidValue;
     SkinnyJobs js;
     js.njobs = njobs;
-    js.job[0] = jobs[0];
-    js.job[1] = jobs[njobs - 1];
+    for (int i = 0; i < 3; ++i) js.job[i] = jobs[i < njobs ? i : njobs - 1];
     js.tiles0 = (jobs[0].N + 31) / 32;
-    js.tiles = js.tiles0 + (njobs > 1 ? (jobs[1].N + 31) / 32 : 0);
+    js.tiles1 = njobs > 1 ? (jobs[1].N + 31) / 32 : 0;
+    js.tiles = js.tiles0 + js.tiles1 + (njobs > 2 ? (jobs[2].N + 31) / 32 : 0);
     const int B = jobs[0].B;
-    if (njobs > 1 && jobs[1].B != B) return hipErrorInvalidValue;
+    for (int i = 1; i < njobs; ++i)
+        if (jobs[i].B != B) return hipErrorInvalidValue;
+    for (int i = 0; i < njobs; ++i)
+        if (jobs[i].mode == 2 && (jobs[i].N & 31)) return hipErrorInvalidValue;   // partial tiles store whole float4 rows
     if (B < 1 || B > 64) return hipErrorInvalidValue;
     int extra = 0;
     js.loc = LocJob{};
     if (loc && loc->G > 0) {
-        if (kind != SK_DECODER) return hipErrorInvalidValue;
+        if (kind == SK_ENCODER) return hipErrorInvalidValue;
         js.loc = *loc;
         extra = loc->B * loc->G;
     }
@@ -433,11 +424,11 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
     if (MT == 2) {
         if (kind == SK_DECODER) decoder_lstm_step_kernel<2><<<grid, block, lds, s>>>(js);
         else if (kind == SK_ENCODER) encoder_lstm_step_kernel<2><<<grid, block, lds, s>>>(js);
-        else skinny_linear_kernel<2><<<grid, block, lds, s>>>(js);
+        else ar_lstm_step_kernel<2><<<grid, block, lds, s>>>(js);
     } else {
         if (kind == SK_DECODER) decoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
         else if (kind == SK_ENCODER) encoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
-        else skinny_linear_kernel<1><<<grid, block, lds, s>>>(js);
+        else ar_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
     }
     return hipGetLastError();
 }

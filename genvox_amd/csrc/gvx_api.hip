@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -38,6 +39,7 @@ using namespace gvx;
 
 namespace {
 thread_local std::string g_err;
+std::mutex g_capture_mutex;
 }
 namespace gvx {
 int set_error(int code, const char* msg) { g_err = msg; return code; }
@@ -122,6 +124,7 @@ struct gvx_model {
     std::vector<GraphSet> ar_graphs, loop_graphs, enc_graphs;
     uint64_t use_clock = 0;
     bool capture_first = false;   // GVX_GRAPH_FIRST=1: capture at the first sighting (tests of the replay path)
+    bool attn_one_launch = true;  // GVX_ATTN_SPLIT=1: energy + context as two launches (the round-1 step, kept for A/B runs)
     void drop_graphs() {
         for (auto* c : {&ar_graphs, &loop_graphs, &enc_graphs}) {
             for (auto& gs : *c)
@@ -344,6 +347,10 @@ int run_chunk(gvx_model* m, gvx_model::GraphSet* gs, size_t chunk, hipStream_t s
     if (gs->execs.size() <= chunk) gs->execs.resize(chunk + 1, nullptr);
     hipGraphExec_t exec = gs->execs[chunk];
     if (!exec) {
+        // Captures are serialised across handles: the host mirror drives two handles from two threads (chunk lanes), and
+        // although each records on its own stream in thread-local mode, concurrent capture / instantiate is not something
+        // to lean on in the runtime.  A one-time cost per graph; launches of existing graphs are not serialised.
+        std::lock_guard<std::mutex> lock(g_capture_mutex);
         hipGraph_t graph = nullptr;
         if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
@@ -376,6 +383,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     m->blob = make_blob_layout(*dims);
     if (const char* e = std::getenv("GVX_NO_GRAPH")) m->use_graph = !(e[0] == '1');
     if (const char* e = std::getenv("GVX_GRAPH_FIRST")) m->capture_first = e[0] == '1';
+    if (const char* e = std::getenv("GVX_ATTN_SPLIT")) m->attn_one_launch = !(e[0] == '1');
     *out = m;
     return GVX_OK;
 }
@@ -704,6 +712,7 @@ void fill_loc(const gvx_model* m, LocJob& q, int t, int B, int L, const float* a
     q.w_cum = db.w_cum;
     q.loc_conv_t = m->dev_blob + m->blob.loc_conv; q.loc_dense_t = m->dev_blob + m->blob.loc_dense;
     q.loc_out = db.loc;
+    q.pm = m->attn_one_launch ? db.pm : nullptr;
     q.B = B; q.L = L; q.a = d.att_dim; q.kl = d.att_loc_kernel; q.G = attention_groups(B, L);
 }
 
@@ -720,7 +729,11 @@ void fill_attn(const gvx_model* m, AttnParams& p, const float* memory, const int
     p.ctx_out = db.hc + (size_t)(t + 1) * B * (D + E) + (size_t)D * B;
     p.energies = db.energies;
     p.B = B; p.L = L; p.a = d.att_dim; p.F = d.att_loc_filters; p.kl = d.att_loc_kernel; p.E = E;
-    p.G = attention_groups(B, L);
+    p.G = m->attn_one_launch ? attention_slices(B, E) : attention_groups(B, L);
+}
+
+hipError_t launch_attn(const gvx_model* m, const AttnParams& p, hipStream_t s) {
+    return m->attn_one_launch ? launch_attention_step(p, s) : launch_attention(p, s);
 }
 
 int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
@@ -778,8 +791,8 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
             HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, SK_DECODER, st, &lq));
             AttnParams ap;
             fill_attn(m, ap, memory, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
-            HIP_TRY(launch_attention(ap, st));
-            launches += 3;
+            HIP_TRY(launch_attn(m, ap, st));
+            launches += m->attn_one_launch ? 2 : 3;
         }
         SkinnyJob job;
         fill_dec_job(m, job, T - 1, B, db);
@@ -791,7 +804,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr};
         rc = run_chunk(m, touch_graph_set(m, m->loop_graphs, key), 0, s, enqueue_loop);
         if (rc != GVX_OK) return rc;
-        launches = 3 * T + 1;
+        launches = (m->attn_one_launch ? 2 : 3) * T + 1;
     } else {
         rc = enqueue_loop(s);
         if (rc != GVX_OK) return rc;
@@ -809,12 +822,12 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         fill_loc(m, lq, tm, B, L, db.align_tm, (long)L, (long)B * L, db);
         AttnParams ap;
         fill_attn(m, ap, memory, len_ws, tm, B, L, db.align_tm, (long)L, (long)B * L, db);
-        ap.w_out = db.energies;  // do not disturb the real alignments / cumulative weights
-        ap.w_cum = db.loc;
+        ap.w_out = db.energies;  // do not disturb the real alignments / cumulative weights (db.loc is an INPUT of the
+        ap.w_cum = db.energies;  // one-launch step: it must not be scribbled on)
         HIP_TRY(hipEventRecord(m->kev[0], s));
         for (int i = 0; i < REPS; ++i) HIP_TRY(launch_skinny(jobs, tm > 0 ? 2 : 1, SK_DECODER, s, &lq));
         HIP_TRY(hipEventRecord(m->kev[1], s));
-        for (int i = 0; i < REPS; ++i) HIP_TRY(launch_attention(ap, s));
+        for (int i = 0; i < REPS; ++i) HIP_TRY(launch_attn(m, ap, s));
         HIP_TRY(hipEventRecord(m->kev[2], s));
         m->n_lstm_ev = m->n_attn_ev = REPS;
     }
@@ -1103,7 +1116,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
             HIP_TRY(launch_skinny(ja, 2, SK_AR, st, &lq));
             AttnParams ap;
             fill_attn(m, ap, memory_ws, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
-            HIP_TRY(launch_attention(ap, st));
+            HIP_TRY(launch_attn(m, ap, st));
             SkinnyJob jc[3];
             std::memset(jc, 0, sizeof jc);
             {   // decoder LSTM of step t: final tiles over [h_a(t) ; ctx(t)]; every tile also emits the mel/gate projection

@@ -101,6 +101,7 @@ struct LocJob {
     const float* w_cum;                     // [B][L]
     const float* loc_conv_t;                // [2][kl][32]
     const float* loc_dense_t;               // [32/4][a][4]
+    const float* pm;                        // [B][L][a] processed memory added to the features (one-launch attention step), or nullptr
     float* loc_out;                         // [B][L][a]
     int B, L, a, kl, G;                     // G position chunks per row (0 = no location job in this launch)
 };
@@ -127,7 +128,11 @@ struct AttnParams {
     float* ctx_out;                         // blocked context vector [E/8][B][8]
     int B, L, a, F, kl, E, G;
 };
-hipError_t launch_attention(const AttnParams& p, hipStream_t s);   // both kernels
+hipError_t launch_attention(const AttnParams& p, hipStream_t s);   // energy + context kernels (p.loc = location features)
+// one launch: energies of the whole row (redundantly per slice), softmax, context slice; p.loc = pm + location features
+// (LocJob.pm set), p.G = attention_slices(B, E)
+hipError_t launch_attention_step(const AttnParams& p, hipStream_t s);
+int attention_slices(int B, int E);
 int attention_groups(int B, int L);                                // G for a batch / length
 bool attention_supported(int L, int a, int F, int kl, int E);
 

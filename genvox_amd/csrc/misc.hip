@@ -319,14 +319,177 @@ __global__ __launch_bounds__(256) void ar_project_kernel(const float* __restrict
     }
 }
 
+// The same step tail for the common sizes (P <= 256, <= 128 slabs), written for latency: the kernel sits on the
+// autoregressive critical chain between the decoder LSTM and the next attention LSTM, and small dependent kernels like this
+// one are bound by instruction issue and by the number of memory round trips, not by bytes.  1024 threads; every global
+// access is a 16-byte load; the only loads that depend on the previous launch (the partial slabs) are issued first and
+// behind them - before anything waits - the Prenet weights each thread needs, so one round trip covers everything.
+//   slabs    thread (sg, n4): slabs 4 sg .. 4 sg + 3 of float4 column n4            -> sp4[32][PSB/4] -> 88 threads add 32
+//   layer 1  thread (kq, j4): k in [KPT kq, KPT kq + KPT) of output float4 j4       -> l1p[16][P/4]   -> P threads add 16
+//   layer 2  thread (kq, o4): k in [4 kq, 4 kq + 4) of this slice's output float4   -> l2p[64][16] -> l2q[16][16] -> add 16
+// (fixed summation orders everywhere: bitwise reproducible).
+constexpr int ARP_THREADS = 1024;
+template <int KPT>   // layer-1 k values per thread: n_mels <= 16 * KPT
+__global__ __launch_bounds__(ARP_THREADS) void ar_project_fast_kernel(const float* __restrict__ p_slab, int n_slabs,
+                                                                      const float* __restrict__ p_ctx, float* __restrict__ proj_t, int M,
+                                                                      int PSB, float threshold, int t, int B, int32_t* n_frames,
+                                                                      int32_t* n_done, const float* __restrict__ w0t,
+                                                                      const float* __restrict__ w1t, int P,
+                                                                      const uint8_t* __restrict__ keep0, const uint8_t* __restrict__ keep1,
+                                                                      float* __restrict__ prenet_out) {
+    __shared__ float4 sp4[32][32];
+    __shared__ float4 l1p[16][64];
+    __shared__ float4 l2p[64][16];
+    __shared__ float4 l2q[16][16];
+    __shared__ __attribute__((aligned(16))) float mel[128];
+    __shared__ __attribute__((aligned(16))) float h1[256];
+    const int sl = blockIdx.x, S = gridDim.x, b = blockIdx.y;
+    const unsigned tid = threadIdx.x;
+    const bool more = keep0 != nullptr;   // uniform: false for the last step (nobody consumes a next Prenet input)
+    // ---- dependent loads first: partial slabs
+    const unsigned n4c = (unsigned)PSB >> 2;                  // float4 per slab row (<= 32)
+    const unsigned sg = tid / n4c, n4 = tid - sg * n4c;
+    const bool slab_thread = sg < 32;
+    float4 sv[4];
+    {
+        const float4* sp = reinterpret_cast<const float4*>(p_slab) + (unsigned)b * n4c + n4;
+        const unsigned sstride = (unsigned)B * n4c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned sidx = min(sg * 4u + q, (unsigned)n_slabs - 1u);
+            sv[q] = slab_thread ? sp[sidx * sstride] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sg * 4u + q >= (unsigned)n_slabs) sv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const unsigned nn = min(tid, (unsigned)PSB - 1u);
+    const long blocked = (long)(nn >> 3) * B * 8 + b * 8 + (nn & 7);
+    const float pc = p_ctx[blocked];
+    // ---- Prenet weights into registers (independent of the previous launch; L2-resident, shared by all rows)
+    const unsigned j4c = (unsigned)P >> 2;                    // float4 per Prenet row (<= 64)
+    const unsigned kq1 = tid / j4c, j4 = tid - kq1 * j4c;    // layer 1: 16 k slices
+    const unsigned OS = (unsigned)P / S, o4c = OS >> 2, o_begin = sl * OS;   // host guarantees P % (4 S) == 0
+    const unsigned kq2 = tid >> 4, o4 = tid & 15;             // layer 2: 64 k slices of 4
+    float4 w0v[KPT], w1v[4];
+    unsigned char k0 = 0, k1 = 0;
+    if (more) {
+        const float4* w0 = reinterpret_cast<const float4*>(w0t) + j4;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) w0v[i] = w0[min(min(kq1, 15u) * KPT + i, (unsigned)M - 1u) * j4c];
+        const float4* w1 = reinterpret_cast<const float4*>(w1t) + (o_begin >> 2) + min(o4, o4c - 1u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w1v[i] = w1[min(kq2 * 4u + i, (unsigned)P - 1u) * j4c];
+        if (tid < (unsigned)P) k0 = keep0[(long)b * P + tid];
+        if (tid < OS) k1 = keep1[(long)b * P + o_begin + tid];
+    }
+    // ---- phase 1: slab reduction
+    if (slab_thread) {
+        float4 acc = sv[0];
+        acc.x += sv[1].x; acc.y += sv[1].y; acc.z += sv[1].z; acc.w += sv[1].w;
+        acc.x += sv[2].x; acc.y += sv[2].y; acc.z += sv[2].z; acc.w += sv[2].w;
+        acc.x += sv[3].x; acc.y += sv[3].y; acc.z += sv[3].z; acc.w += sv[3].w;
+        sp4[sg][n4] = acc;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float v = 0.f;
+        if (tid <= (unsigned)M) {
+            const float* col = reinterpret_cast<const float*>(sp4) + tid;
+            float acc = col[0];
+#pragma unroll
+            for (int q = 1; q < 32; ++q) acc += col[q * 128];
+            v = acc + pc;
+            if (sl == 0) {
+                proj_t[blocked] = v;
+                if (tid == (unsigned)M && n_frames[b] == 0) {
+                    const float sgm = 1.f / (1.f + expf(-v));
+                    if (sgm > threshold) {
+                        n_frames[b] = t + 1;
+                        atomicAdd(n_done, 1);
+                    }
+                }
+            }
+        }
+        mel[tid] = tid < (unsigned)M ? v : 0.f;   // zeros past the mel bins: clamped weight loads contribute nothing
+    }
+    if (!more) return;
+    __syncthreads();
+    // ---- phase 2: Prenet layer 1
+    if (kq1 < 16 && j4 < j4c) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const float x = mel[kq1 * KPT + i];
+            acc.x = fmaf(w0v[i].x, x, acc.x); acc.y = fmaf(w0v[i].y, x, acc.y);
+            acc.z = fmaf(w0v[i].z, x, acc.z); acc.w = fmaf(w0v[i].w, x, acc.w);
+        }
+        l1p[kq1][j4] = acc;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        float r = 0.f;
+        if (tid < (unsigned)P) {
+            const float* col = reinterpret_cast<const float*>(l1p) + tid;
+            float acc = col[0];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) acc += col[q * 256];
+            acc = fmaxf(acc, 0.f);
+            r = k0 ? 2.f * acc : 0.f;
+        }
+        h1[tid] = r;   // zeros past P
+    }
+    __syncthreads();
+    // ---- phase 3: this workgroup's layer-2 columns
+    {
+        const float4 h4 = reinterpret_cast<const float4*>(h1)[kq2];
+        float4 acc;
+        acc.x = w1v[0].x * h4.x; acc.y = w1v[0].y * h4.x; acc.z = w1v[0].z * h4.x; acc.w = w1v[0].w * h4.x;
+        acc.x = fmaf(w1v[1].x, h4.y, acc.x); acc.y = fmaf(w1v[1].y, h4.y, acc.y); acc.z = fmaf(w1v[1].z, h4.y, acc.z); acc.w = fmaf(w1v[1].w, h4.y, acc.w);
+        acc.x = fmaf(w1v[2].x, h4.z, acc.x); acc.y = fmaf(w1v[2].y, h4.z, acc.y); acc.z = fmaf(w1v[2].z, h4.z, acc.z); acc.w = fmaf(w1v[2].w, h4.z, acc.w);
+        acc.x = fmaf(w1v[3].x, h4.w, acc.x); acc.y = fmaf(w1v[3].y, h4.w, acc.y); acc.z = fmaf(w1v[3].z, h4.w, acc.z); acc.w = fmaf(w1v[3].w, h4.w, acc.w);
+        l2p[kq2][o4] = acc;
+    }
+    __syncthreads();
+    if (tid < 256) {   // (r, o4): add k slices 4 r .. 4 r + 3
+        const unsigned r = tid >> 4;
+        float4 acc = l2p[4 * r][o4];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 v = l2p[4 * r + q][o4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        l2q[r][o4] = acc;
+    }
+    __syncthreads();
+    if (tid < OS) {
+        const float* col = reinterpret_cast<const float*>(l2q) + tid;
+        float acc = col[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) acc += col[q * 64];
+        const unsigned o = o_begin + tid;
+        acc = fmaxf(acc, 0.f);
+        acc = k1 ? 2.f * acc : 0.f;
+        prenet_out[(long)(o >> 3) * B * 8 + b * 8 + (o & 7)] = acc;
+    }
+}
+
 hipError_t launch_ar_project(const float* p_slab, int n_slabs, const float* p_ctx, float* proj_t, int M, float threshold, int t, int B,
                              int32_t* n_frames, int32_t* n_done, const float* w0t, const float* w1t, int P, const uint8_t* keep0,
                              const uint8_t* keep1, float* prenet_out, hipStream_t s) {
     const int PSB = (M + 1 + 7) & ~7;
     if (PSB > 128 || M > 128) return hipErrorInvalidValue;
-    // column slices per row: enough workgroups to spread the 4*P*P bytes of layer 2, never more than one slice per 8 columns
+    // column slices per row: enough workgroups to spread the 4*P*P bytes of layer 2, whole float4 groups per slice
     int S = 4;
-    while (S > 1 && (P / S < 8 || S * B > 512)) S >>= 1;
+    while (S > 1 && (P % (4 * S) != 0 || P / S < 8 || S * B > 512)) S >>= 1;
+    if (P <= 256 && P % (4 * S) == 0 && n_slabs >= 1 && n_slabs <= 128) {
+        const dim3 grid(S, B), block(ARP_THREADS);
+#define GVX_ARP(K) ar_project_fast_kernel<K><<<grid, block, 0, s>>>(p_slab, n_slabs, p_ctx, proj_t, M, PSB, threshold, t, B, n_frames, \
+                                                                    n_done, w0t, w1t, P, keep0, keep1, prenet_out)
+        if (M <= 32) GVX_ARP(2);
+        else if (M <= 80) GVX_ARP(5);
+        else GVX_ARP(8);
+#undef GVX_ARP
+        return hipGetLastError();
+    }
     const int OS = (P + S - 1) / S;
     const size_t lds = (size_t)(P + ARP_KQ * OS) * sizeof(float);
     hipLaunchKernelGGL(ar_project_kernel, dim3(S, B), dim3(256), lds, s, p_slab, n_slabs, p_ctx, proj_t, M, PSB, threshold, t, B,

@@ -106,26 +106,41 @@ __device__ __forceinline__ void loc_body(const LocJob& Q, int wg) {
         }
         __syncthreads();
         // dense: wave -> positions wave, wave+8, ...; lane -> attention dims lane, lane+64, ...
+        // (register budget: this body shares a kernel with the LSTM tiles and must stay under 128 VGPRs, or its workgroups
+        // can no longer be co-resident with them - the loop over d0 stays rolled)
+        constexpr int PM_L = LOC_LC / SK_WAVES;   // positions per wave and pass
         for (int d0 = 0; d0 < a; d0 += 64) {
             const int d = min(d0 + lane, a - 1);
+            // processed-memory addends of this pass (one-launch attention step): issued together with the dense weights, so
+            // they share that round trip instead of adding one per stored value
+            float pmr[PM_L];
+            if (Q.pm) {
+#pragma unroll
+                for (int li = 0; li < PM_L; ++li)
+                    pmr[li] = Q.pm[((long)b * L + min(l0 + wave + li * SK_WAVES, l_end - 1)) * a + d];
+            }
             float wd[LOC_FP];
 #pragma unroll
             for (int c4 = 0; c4 < LOC_FP / 4; ++c4) {
                 const float4 w4 = reinterpret_cast<const float4*>(Q.loc_dense_t)[(long)c4 * a + d];
                 wd[4 * c4 + 0] = w4.x; wd[4 * c4 + 1] = w4.y; wd[4 * c4 + 2] = w4.z; wd[4 * c4 + 3] = w4.w;
             }
-            for (int ll = wave; ll < lc; ll += SK_WAVES) {
-                const float* frow = fb + ll * LOC_FP;
-                float s = 0.f;   // one k-ordered chain: same summation order as a plain dot product over the filters
 #pragma unroll
-                for (int c4 = 0; c4 < LOC_FP / 4; ++c4) {
-                    const float4 fv = *reinterpret_cast<const float4*>(frow + 4 * c4);
-                    s = fmaf(wd[4 * c4 + 0], fv.x, s);
-                    s = fmaf(wd[4 * c4 + 1], fv.y, s);
-                    s = fmaf(wd[4 * c4 + 2], fv.z, s);
-                    s = fmaf(wd[4 * c4 + 3], fv.w, s);
+            for (int li = 0; li < PM_L; ++li) {
+                const int ll = wave + li * SK_WAVES;
+                if (ll < lc) {
+                    const float* frow = fb + ll * LOC_FP;
+                    float s = 0.f;   // one k-ordered chain: same summation order as a plain dot product over the filters
+#pragma unroll
+                    for (int c4 = 0; c4 < LOC_FP / 4; ++c4) {
+                        const float4 fv = *reinterpret_cast<const float4*>(frow + 4 * c4);
+                        s = fmaf(wd[4 * c4 + 0], fv.x, s);
+                        s = fmaf(wd[4 * c4 + 1], fv.y, s);
+                        s = fmaf(wd[4 * c4 + 2], fv.z, s);
+                        s = fmaf(wd[4 * c4 + 3], fv.w, s);
+                    }
+                    if (d0 + lane < a) Q.loc_out[((long)b * L + l0 + ll) * a + d0 + lane] = Q.pm ? s + pmr[li] : s;
                 }
-                if (d0 + lane < a) Q.loc_out[((long)b * L + l0 + ll) * a + d0 + lane] = s;
             }
         }
         __syncthreads();
@@ -135,8 +150,9 @@ __device__ __forceinline__ void loc_body(const LocJob& Q, int wg) {
 
 // v_exp_f32 / v_rcp_f32 forms (abs error ~1e-7): the cell update sits on the per-step critical path after the
 // workgroup barrier, where the libm expf/tanhf sequences cost ~1 us per step.
-__device__ __forceinline__ float sigmoidf_(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.f - __fdividef(2.f, __expf(2.f * x) + 1.f); }
+// (v_rcp_f32 by name: __fdividef compiles to the 10-instruction IEEE division sequence under this library's flags)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
 // Weight loads use the DEFAULT cache policy on purpose: the 71 MB of recurrent weights are re-read every step and stay
 // resident in the 256-MiB Infinity Cache; non-temporal loads bypass it and were measured 16 % slower (round 1: 20.2 us vs

@@ -90,6 +90,7 @@ class Tacotron2(nn.Module):
         self._workspace: Optional[torch.Tensor] = None
         self._lane_ws = [None, None]     # workspaces of the two concurrent chunk lanes
         self._lane_streams = None
+        self._lane_handles = [None, None]   # autoregressive lanes run on host threads: one C-ABI handle each (same blob)
         self._timing = False
         self.eval()
 
@@ -100,8 +101,9 @@ class Tacotron2(nn.Module):
     # ------------------------------------------------------------------ C-ABI plumbing
     def __del__(self):
         try:
-            if self._handle is not None:
-                _lib.load().gvx_model_destroy(self._handle)
+            for h in [self._handle] + list(getattr(self, "_lane_handles", [])):
+                if h is not None:
+                    _lib.load().gvx_model_destroy(h)
         except Exception:
             pass
 
@@ -157,6 +159,9 @@ class Tacotron2(nn.Module):
     def _bind(self, blob: torch.Tensor) -> None:
         lib = _lib.load()
         _lib.check(lib.gvx_model_bind_blob(self._ensure_handle(), blob.data_ptr()))
+        for h in self._lane_handles:
+            if h is not None:
+                _lib.check(lib.gvx_model_bind_blob(h, blob.data_ptr()))
         self._blob = blob   # replaces (and frees) the previous blob only after the handle points at the new one
         if self._timing:
             _lib.check(lib.gvx_stage_timing_enable(self._handle, 1))
@@ -193,13 +198,24 @@ class Tacotron2(nn.Module):
         """Read the device-side status word of the last calls (synchronises the stream): raises IndexError for a token
         id outside the embedding table, which is what nn.Embedding does in the reference (models/tts/tacotron2.py:459).
         Not called by forward(): one check after a batch of calls is enough."""
-        if self._workspace is None:
-            return
         out = (C.c_int32 * 2)()
-        _lib.check(_lib.load().gvx_workspace_status(self._handle, self._workspace.data_ptr(), self._workspace.numel(),
-                                                    self._stream(), out))
-        if out[0]:
+        bad = False
+        for ws in [self._workspace] + self._lane_ws:
+            if ws is None:
+                continue
+            _lib.check(_lib.load().gvx_workspace_status(self._handle, ws.data_ptr(), ws.numel(), self._stream(), out))
+            bad |= bool(out[0])
+        if bad:
             raise IndexError("genvox_amd: token id outside [0, n_tokens)")
+
+    def _lanes(self, dev, need_bytes: int):
+        """Two side streams with a workspace each (chunks of a large batch run on them concurrently)."""
+        if self._lane_streams is None:
+            self._lane_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        for i in range(2):
+            if self._lane_ws[i] is None or self._lane_ws[i].numel() < need_bytes or self._lane_ws[i].device != dev:
+                self._lane_ws[i] = torch.empty(need_bytes, dtype=torch.uint8, device=dev)
+        return self._lane_streams, self._lane_ws
 
     def enable_stage_timing(self, enable: bool = True) -> None:
         self._timing = enable
@@ -269,19 +285,15 @@ class Tacotron2(nn.Module):
         # results); the caller's stream waits for both lanes before anything downstream may touch the outputs
         n_chunks = -(-B // STREAM_ROWS)
         bounds = [(B * i) // n_chunks for i in range(n_chunks + 1)]
-        if self._lane_streams is None:
-            self._lane_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         need = lib.gvx_workspace_bytes(self._handle, max(hi - lo for lo, hi in zip(bounds, bounds[1:])), L, T)
-        for i in range(2):
-            if self._lane_ws[i] is None or self._lane_ws[i].numel() < need or self._lane_ws[i].device != dev:
-                self._lane_ws[i] = torch.empty(need, dtype=torch.uint8, device=dev)
+        streams, wss = self._lanes(dev, need)
         cur = torch.cuda.current_stream(dev)
-        for lane in self._lane_streams:
+        for lane in streams:
             lane.wait_stream(cur)
         for ci, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
-            with torch.cuda.stream(self._lane_streams[ci % 2]):
-                run(lo, hi, self._lane_ws[ci % 2])
-        for lane in self._lane_streams:
+            with torch.cuda.stream(streams[ci % 2]):
+                run(lo, hi, wss[ci % 2])
+        for lane in streams:
             cur.wait_stream(lane)
         return out
 
@@ -291,42 +303,101 @@ class Tacotron2(nn.Module):
         inputs: ``tokens`` [B, L] (the reference: B = 1); optional ``token_lengths`` [B] for padded batches and
         ``prenet_keep_masks`` uint8 [2, max_decoder_steps, B, prenet_dim].  Outputs are trimmed to the longest row; for B > 1
         ``mel_lengths`` holds every row's frame count and frames past it carry the padding values of the reference's
-        mask_padding (mel / mel_postnet / alignment 0, gate 1e3) - row b up to its length is what a batch-1 run gives."""
+        mask_padding (mel / mel_postnet / alignment 0, gate 1e3) - row b up to its length is what a batch-1 run gives.
+
+        Batches above STREAM_ROWS rows are decoded as chunks on two streams at once (each chunk a C-ABI call of its own,
+        driven by its own host thread because the call polls the stop flags): like the teacher-forced path, a second
+        independent batch fills the latency gaps of the first."""
         dev = self._require_gpu()
         self._ensure_packed()
         tokens = inputs["tokens"].to(device=dev, dtype=torch.int64).contiguous()
         B, L = tokens.shape
-        assert B <= MAX_CALL_BATCH, f"inference batch {B} > {MAX_CALL_BATCH}: shard across calls or GPUs"
         lens = inputs.get("token_lengths")
         lens_t = lens.to(device=dev, dtype=torch.int32).contiguous() if lens is not None else None
         mc = self.model_config
         M, E, P, S = self.audio_config.n_mels, mc.encoder_embedding_dim, mc.prenet_dim, mc.max_decoder_steps
-        masks = self._keep_masks(inputs.get("prenet_keep_masks"), 2 * S * B * P, dev)
+        given = inputs.get("prenet_keep_masks")
+        if given is not None:
+            given = given.to(device=dev, dtype=torch.uint8).reshape(2, S, B, P)
         lib = _lib.load()
-        ws = self._get_workspace(B, L, S)
-        memory = torch.empty(B, L, E, device=dev)
         mel_out = torch.zeros(B, M, S, device=dev)
         gate_out = torch.zeros(B, S, device=dev)
         align = torch.zeros(B, S, L, device=dev)
         n_frames = torch.zeros(B, dtype=torch.int32, device=dev)
-        steps = C.c_int(0)
-        s = self._stream()
-        _lib.check(lib.gvx_encoder_forward(self._handle, tokens.data_ptr(), lens_t.data_ptr() if lens_t is not None else None,
-                                           B, L, memory.data_ptr(), ws.data_ptr(), ws.numel(), s))
-        _lib.check(lib.gvx_decoder_autoregressive(
-            self._handle, memory.data_ptr(), lens_t.data_ptr() if lens_t is not None else None, B, L, S,
-            float(mc.gate_threshold), masks.data_ptr(), mel_out.data_ptr(), gate_out.data_ptr(), align.data_ptr(),
-            n_frames.data_ptr(), C.byref(steps), ws.data_ptr(), ws.numel(), s))
+        steps_run = []
+
+        def run(lo: int, hi: int, handle: int, ws: torch.Tensor, seed) -> None:
+            n = hi - lo
+            if given is not None:
+                masks = given[:, :, lo:hi].contiguous()
+            else:
+                masks = torch.empty(2 * S * n * P, dtype=torch.uint8, device=dev)
+                _lib.check(lib.gvx_prenet_masks_generate(masks.data_ptr(), masks.numel(), seed, self._stream()))
+            memory = torch.empty(n, L, E, device=dev)
+            ln = lens_t[lo:hi].data_ptr() if lens_t is not None else None
+            steps = C.c_int(0)
+            st = self._stream()
+            _lib.check(lib.gvx_encoder_forward(handle, tokens[lo:hi].data_ptr(), ln, n, L, memory.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            _lib.check(lib.gvx_decoder_autoregressive(
+                handle, memory.data_ptr(), ln, n, L, S, float(mc.gate_threshold), masks.data_ptr(), mel_out[lo:hi].data_ptr(),
+                gate_out[lo:hi].data_ptr(), align[lo:hi].data_ptr(), n_frames[lo:hi].data_ptr(), C.byref(steps), ws.data_ptr(),
+                ws.numel(), st))
+            steps_run.append(steps.value)
+
+        n_chunks = -(-B // STREAM_ROWS)
+        seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(n_chunks)]  # CPU generator: manual_seed repeats runs
+        if n_chunks == 1:
+            run(0, B, self._handle, self._get_workspace(B, L, S), seeds[0])
+        else:
+            import threading
+
+            bounds = [(B * i) // n_chunks for i in range(n_chunks + 1)]
+            chunks = list(zip(bounds, bounds[1:]))
+            need = lib.gvx_workspace_bytes(self._handle, max(hi - lo for lo, hi in chunks), L, S)
+            streams, wss = self._lanes(dev, need)
+            for i in range(2):   # the C-ABI handle is not re-entrant: one per lane, bound to the same weight blob
+                if self._lane_handles[i] is None:
+                    h = C.c_void_p()
+                    dims = dims_from_configs(self.model_config, self.audio_config, self.text_config)
+                    _lib.check(lib.gvx_model_create(C.byref(dims), C.byref(h)))
+                    _lib.check(lib.gvx_model_bind_blob(h.value, self._blob.data_ptr()))
+                    self._lane_handles[i] = h.value
+            cur = torch.cuda.current_stream(dev)
+            errors = []
+
+            def lane_main(lane: int) -> None:
+                try:
+                    with torch.cuda.device(dev), torch.cuda.stream(streams[lane]):
+                        for ci in range(lane, n_chunks, 2):
+                            run(chunks[ci][0], chunks[ci][1], self._lane_handles[lane], wss[lane], seeds[ci])
+                except BaseException as e:  # re-raised on the calling thread
+                    errors.append(e)
+
+            for st in streams:
+                st.wait_stream(cur)
+            threads = [threading.Thread(target=lane_main, args=(i,)) for i in range(2)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for st in streams:
+                cur.wait_stream(st)
+            if errors:
+                raise errors[0]
         n_host = n_frames.cpu()
-        self.check_status()   # the decoder call has synchronised already: a bad token id raises here like nn.Embedding does
+        self.check_status()   # the decoder calls have synchronised already: a bad token id raises here like nn.Embedding does
         Tn = int(n_host.max())
-        if steps.value >= S and int((n_host >= S).sum()) > 0:
+        if max(steps_run) >= S and int((n_host >= S).sum()) > 0:
             print("Warning! Reached max decoder steps")
         mel_out = mel_out[:, :, :Tn].contiguous()
         mel_post = torch.empty_like(mel_out)
         # every row is post-processed as a sequence of its own length (what a batch-1 run of the reference sees)
+        need = lib.gvx_postnet_workspace_bytes(self._handle, B, Tn)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = self._workspace
         _lib.check(lib.gvx_postnet_forward(self._handle, mel_out.data_ptr(), n_frames.data_ptr() if B > 1 else None, B, Tn,
-                                           mel_post.data_ptr(), ws.data_ptr(), ws.numel(), s))
+                                           mel_post.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         out = {"mel_outputs": mel_out, "mel_outputs_postnet": mel_post,
                "gate_outputs": gate_out[:, :Tn].contiguous(), "alignments": align[:, :Tn].contiguous()}
         if B > 1:

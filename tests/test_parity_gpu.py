@@ -168,8 +168,45 @@ def test_shapes_against_oracle(B, L, T, dims):
         assert d <= TOL, f"B={B} L={L} T={T} {k}: {d}"
 
 
+def test_autoregressive_two_batch_tiles_in_one_call():
+    """B = 36 rows in ONE C-ABI call (two batch tiles per MFMA pass, MT = 2, of the autoregressive launches) - the host
+    mirror would chunk this batch, so the call is made directly; first, middle and last row against batch-1 oracle runs."""
+    import ctypes as C
+
+    from genvox_amd import _lib
+    name = "ar_small_gate"
+    case, fx = AR_CASES[name], load_fixture(name)
+    steps = 10
+    m, (mc, ac, tc) = gpu_model(name, case, max_decoder_steps=steps, gate_threshold=1.0)
+    sd = case_state_dict(name)
+    B, L = 36, 11
+    tok = (gw.hashed_uniform(5, "ar36", B * L) * tc.n_tokens).astype(np.int64).reshape(B, L)
+    masks = torch.from_numpy(gw.prenet_keep_masks(steps * B, mc.prenet_dim, seed=3)).reshape(2, steps, B, mc.prenet_dim)
+    lib = _lib.load()
+    m._ensure_packed()
+    dev = torch.device("cuda:0")
+    ws = m._get_workspace(B, L, steps)
+    tk, mk = torch.from_numpy(tok).to(dev), masks.to(dev).contiguous()
+    memory = torch.empty(B, L, mc.encoder_embedding_dim, device=dev)
+    mel = torch.zeros(B, ac.n_mels, steps, device=dev)
+    gate = torch.zeros(B, steps, device=dev)
+    align = torch.zeros(B, steps, L, device=dev)
+    nf = torch.zeros(B, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ran = C.c_int(0)
+    _lib.check(lib.gvx_encoder_forward(m._handle, tk.data_ptr(), None, B, L, memory.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    _lib.check(lib.gvx_decoder_autoregressive(m._handle, memory.data_ptr(), None, B, L, steps, 1.0, mk.data_ptr(), mel.data_ptr(),
+                                              gate.data_ptr(), align.data_ptr(), nf.data_ptr(), C.byref(ran), ws.data_ptr(), ws.numel(), st))
+    assert ran.value == steps and nf.cpu().tolist() == [steps] * B
+    got = {"mel_outputs": mel, "gate_outputs": gate, "alignments": align}
+    for b in (0, 17, 35):
+        want = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(tok[b:b + 1]), masks[:, :, b], 1.0, steps)
+        for k in got:
+            assert max_abs_diff(got[k][b:b + 1], want[k]) <= TOL, (b, k)
+
+
 def test_autoregressive_batch_over_32_rows():
-    """B = 36 autoregressive rows (MT = 2 path of the per-step GEMVs), first and last row against batch-1 oracle runs."""
+    """B = 36 autoregressive rows through the host mirror (two chunks on two lanes), first and last row against batch-1 oracle runs."""
     name = "ar_small_gate"
     case, fx = AR_CASES[name], load_fixture(name)
     steps = 10

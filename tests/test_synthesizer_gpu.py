@@ -87,9 +87,9 @@ def test_c_abi_rejects_bad_arguments_loudly():
     assert lib.gvx_postnet_forward(h, None, None, 2, 4, None, ws.data_ptr(), ws.numel(), s) == -1
     assert lib.gvx_postnet_forward(h, x.data_ptr(), None, 2, 4, x.data_ptr(), ws.data_ptr(), 256, s) == -5   # Postnet plan too small
     assert lib.gvx_mask_padding(None, None, None, None, 2, 80, 4, s) == -1
-    # inference past the per-call batch limit is refused by the host mirror with a clear message
-    with pytest.raises(AssertionError, match="shard"):
-        m.inference({"tokens": torch.zeros(65, 4, dtype=torch.long)})
+    # the recurrent entry points take at most 64 rows per call; the host mirror chunks larger batches itself (below)
+    assert lib.gvx_decoder_autoregressive(h, x.data_ptr(), None, 65, 8, 4, 0.5, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                          x.data_ptr(), None, ws.data_ptr(), ws.numel(), s) == -2
     # a teacher-forced batch over the limit is split transparently and matches per-chunk calls
     B, L, T = 70, 6, 3
     g = torch.Generator().manual_seed(1)

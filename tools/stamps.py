@@ -25,10 +25,14 @@ torch.cuda.synchronize()
 lib = C.CDLL(_lib.LIB_PATH)
 buf = (C.c_ulonglong * 96)()
 assert lib.gvx_debug_read_stamps(buf) == 0
+one_launch = os.environ.get("GVX_ATTN_SPLIT", "0") != "1"
 names = {0: ["start", "mainloop done", "red synced", "cell done", "qslab done"],
-         1: ["start", "loads issued", "q summed + synced", "tanh partials done", "reduced + stored"],
-         2: ["start", "softmax done", "ctx partial", "ctx written"]}
-for k, title in enumerate(["decoder_lstm_step (wg 0)", "attn_energy (wg 0,0)", "attn_context (wg 0,0)"]):
+         1: (["start", "loads issued", "q summed", "energies done + synced", "softmax done + synced", "ctx written"] if one_launch else
+             ["start", "loads issued", "q summed + synced", "tanh partials done", "reduced + stored"]),
+         2: [] if one_launch else ["start", "softmax done", "ctx partial", "ctx written"]}
+for k, title in enumerate(["decoder_lstm_step (wg 0)", "attn_step (row 0, slice 0)" if one_launch else "attn_energy (wg 0,0)", "attn_context (wg 0,0)"]):
+    if not names[k]:
+        continue
     v = [buf[k * 32 + i] for i in range(len(names[k]))]
     print(title)
     for i in range(1, len(v)):

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_inverse_ola_kernel(const f
             if (tt >= 0 && tt < T) sacc += fall[(long)(hb + 3 - d) * (FPAD * 2) + d * 256 + q];
         }
         const float w = wss[i];
-        y[(long)b * n + i] = w > 1.17549435e-38f ? sacc / w : sacc;
+        y[(long)b * n + i] = w > 1.17549435e-38f ? sacc * __builtin_amdgcn_rcpf(w) : sacc;   // v_rcp_f32: 1 ulp
     }
 }
 
@@ -582,7 +582,8 @@ __global__ __launch_bounds__(GLF_FRAMES * 64) void gl_forward_update_kernel(cons
     float2* buf = fsm + wave * FPAD;
     float2 v[8];
     if (valid) {
-        const int b = (int)(f / T), t = (int)(f - (long)b * T);
+        const unsigned fu = (unsigned)f;   // frames < 2^32 (checked on the host): 32-bit division, the 64-bit one is ~150 instructions
+        const int b = (int)(fu / (unsigned)T), t = (int)(fu - (unsigned)b * (unsigned)T);
         const float* yb = y + (long)b * (long)(T + 3) * 256 + (long)t * 256;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -630,8 +631,16 @@ __global__ __launch_bounds__(GLF_FRAMES * 64) void gl_forward_update_kernel(cons
             a.x = reb.x - c * pv[r].x;
             a.y = reb.y - c * pv[r].y;
         }
-        const float d = hypotf(a.x, a.y) + 1.17549435e-38f;
-        spec[base + k] = make_float2(a.x / d * mg[r], a.y / d * mg[r]);
+        // a / (|a| + tiny) * mag with v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of libm hypotf and two IEEE divisions,
+        // which together were half of this kernel's vector instructions.  Operands are pre-scaled by a power of two when
+        // they are so small that their squares would underflow (hypotf's only advantage here), so tiny bins keep their phase.
+        const float big = fmaxf(fabsf(a.x), fabsf(a.y));
+        const float sc = big < 1e-15f ? 1.8446744e19f : 1.f;         // 2^64 (exact)
+        const float isc = big < 1e-15f ? 5.4210109e-20f : 1.f;       // 2^-64
+        const float ax = a.x * sc, ay = a.y * sc;
+        const float d = __builtin_amdgcn_sqrtf(ax * ax + ay * ay) * isc + 1.17549435e-38f;
+        const float q = __builtin_amdgcn_rcpf(d) * mg[r];
+        spec[base + k] = make_float2(a.x * q, a.y * q);
         tprev[base + k] = reb;
     }
 }
@@ -649,7 +658,8 @@ __global__ __launch_bounds__(GLF_FRAMES * 64) void stft_magnitude_kernel(const f
     float2* buf = fsm + wave * FPAD;
     float2 v[8];
     if (valid) {
-        const int b = (int)(f / T), t = (int)(f - (long)b * T);
+        const unsigned fu = (unsigned)f;
+        const int b = (int)(fu / (unsigned)T), t = (int)(fu - (unsigned)b * (unsigned)T);
         const float* xb = x + (long)b * n_samples + (long)t * 256;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {

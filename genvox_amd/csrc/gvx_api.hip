@@ -29,6 +29,7 @@ namespace gvx {
 #ifdef GVX_STAMPS
 hipError_t read_stamps_skinny(unsigned long long* host96);
 hipError_t read_stamps_attention(unsigned long long* host96);
+hipError_t read_wg_spans(unsigned long long* host1024);
 #endif
 hipError_t skinny_init();
 hipError_t gemm_init();
@@ -1189,6 +1190,11 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
 int gvx_debug_read_stamps_skinny(unsigned long long* host96) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(gvx::read_stamps_skinny(host96));
+    return GVX_OK;
+}
+int gvx_debug_read_wg_spans(unsigned long long* host1024) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(gvx::read_wg_spans(host1024));
     return GVX_OK;
 }
 int gvx_debug_read_stamps(unsigned long long* host96) {

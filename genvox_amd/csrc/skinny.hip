@@ -185,6 +185,11 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         const int b_ = mt_ * 32 + bl, j_ = tile * 8 + 2 * g_ + h;
         if (b_ < B) c_pref = J.c[(long)b_ * (J.N >> 2) + j_];
         if (J.bias) bias_pref = *reinterpret_cast<const float4*>(J.bias + tile * 32 + 8 * g_ + 4 * h);
+        // decoder cells finished from partial sums (autoregressive launches): the addend is known at launch, fetch it now
+        if (J.addend && !J.seq_out && b_ < B) {
+            const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b_ * J.add_bs + tile * 32 + 8 * g_ + 4 * h);
+            bias_pref.x += ad.x; bias_pref.y += ad.y; bias_pref.z += ad.z; bias_pref.w += ad.w;
+        }
     }
 
     // ---- main loop: this wave's K slice, software pipelined DEPTH k-groups deep.
@@ -322,7 +327,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                 const long hoff = (long)tile * blk + b * 8 + jloc;  // blocked: k-group = tile, k & 7 = jloc
                 if (active) {
                     float pre[4] = {s[0] + bias_pref.x, s[1] + bias_pref.y, s[2] + bias_pref.z, s[3] + bias_pref.w};
-                    if (J.addend) {
+                    if (J.addend && J.seq_out) {   // encoder: the row's own time index picks the addend (decoder: prefetched above)
                         const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b * J.add_bs + (long)tb * J.add_ts + n);
                         pre[0] += ad.x; pre[1] += ad.y; pre[2] += ad.z; pre[3] += ad.w;
                     }
@@ -381,9 +386,20 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 
 // Same body under three kernel names so that profiles separate the teacher-forced decoder step (the dominant kernel of
 // the path) from the autoregressive step launches and the encoder recurrence.
+#ifdef GVX_STAMPS
+// diagnostic build: begin / end time of every workgroup of the last multi-job decoder launch (tools/stamps.py)
+namespace { __device__ unsigned long long gvx_wg_span[2][512]; }
+#define GVX_WG_BEGIN() do { if (threadIdx.x == 0 && jobs.njobs >= 2 && blockIdx.x < 512) gvx_wg_span[0][blockIdx.x] = wall_clock64(); } while (0)
+#define GVX_WG_END() do { if (threadIdx.x == 0 && jobs.njobs >= 2 && blockIdx.x < 512) gvx_wg_span[1][blockIdx.x] = wall_clock64(); } while (0)
+#else
+#define GVX_WG_BEGIN() do { } while (0)
+#define GVX_WG_END() do { } while (0)
+#endif
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_kernel(SkinnyJobs jobs) {
-    if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }   // uniform per workgroup
+    GVX_WG_BEGIN();
+    if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); GVX_WG_END(); return; }   // uniform per workgroup
     skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
+    GVX_WG_END();
 }
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_kernel(SkinnyJobs jobs) {   // autoregressive launches A / C
     if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }
@@ -452,6 +468,9 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
 #ifdef GVX_STAMPS
 hipError_t read_stamps_skinny(unsigned long long* host96) {
     return hipMemcpyFromSymbol(host96, HIP_SYMBOL(gvx_stamps), sizeof(unsigned long long) * 96);
+}
+hipError_t read_wg_spans(unsigned long long* host1024) {
+    return hipMemcpyFromSymbol(host1024, HIP_SYMBOL(gvx_wg_span), sizeof(unsigned long long) * 1024);
 }
 #endif
 

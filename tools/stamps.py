@@ -22,6 +22,8 @@ batch = {k: torch.from_numpy(v).cuda() for k, v in gw.synthetic_inputs(B, L, T, 
 for _ in range(2):
     m.forward(batch)
 torch.cuda.synchronize()
+# reset the launch-span slots (row 2, slots 20 / 21) by hand is not possible from here: they are min / max accumulators
+# over every launch since the module was loaded; a fresh process per measurement keeps them meaningful
 lib = C.CDLL(_lib.LIB_PATH)
 buf = (C.c_ulonglong * 96)()
 assert lib.gvx_debug_read_stamps(buf) == 0
@@ -50,3 +52,24 @@ if lib2.gvx_debug_read_stamps_skinny(raw) == 0:
         t0 = raw[2 * 32 + 7] if row == 2 else raw[0]
         ends = [(raw[row * 32 + 8 + w] - t0) * 10 for w in range(8)]
         print(f"{nm}: per-wave main-loop end (ns after block 0 start): {ends}  spread {max(ends) - min(ends)} ns")
+
+
+spans = (C.c_ulonglong * 1024)()
+lib2.gvx_debug_read_wg_spans.argtypes = [C.c_void_p]
+if lib2.gvx_debug_read_wg_spans(spans) == 0:
+    beg = [spans[i] for i in range(512)]
+    end = [spans[512 + i] for i in range(512)]
+    live = [i for i in range(512) if beg[i] and end[i]]
+    if live:
+        t0 = min(beg[i] for i in live)
+        def grp(name, ids):
+            ids = [i for i in ids if i in live]
+            if ids:
+                b = [(beg[i] - t0) * 10 for i in ids]
+                e = [(end[i] - t0) * 10 for i in ids]
+                worst = max(ids, key=lambda i: end[i])
+                print(f"{name:16s} {len(ids):4d} workgroups: begin {min(b):6d}..{max(b):6d} ns, end {min(e):6d}..{max(e):6d} ns (last: block {worst})")
+        print("last multi-job LSTM launch, per workgroup (ns after the first workgroup began):")
+        grp("attention tiles", range(0, 128))
+        grp("decoder tiles", range(128, 256))
+        grp("location", range(256, 512))

@@ -567,6 +567,147 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_inverse_ola_kernel(const f
     }
 }
 
+// One whole Griffin-Lim iteration per launch (n_fft 1024 / hop 256):
+//   y_in (the signal of the current angles) -> frames -> FFT -> rebuilt -> momentum update -> new spectrum S
+//   -> inverse FFT of S -> window -> overlap-add -> y_out (the signal of the new angles)
+// so the state that crosses iterations is the signal (1 KB per frame) and tprev (4 KB per frame); the spectrum itself never
+// goes to HBM except in the last iteration.  Per frame and iteration this moves 1 216 B (y_in incl. the 3-frame halo) +
+// 4 104 (tprev in) + 2 052 (mag) + 4 104 (tprev out) + 1 024 (y_out) = 12.5 KB (x 16/13 for the reads of halo frames: 14.1 KB)
+// against 21.5 KB of the forward / inverse kernel pair above (S written, then read x 1.23) and 20 516 B of SURVEY 8d's
+// "minimal" count, which assumed the spectrum has to make the round trip.
+// Workgroup = 16 frames (waves) = the 13 hop blocks they complete + 3 halo frames; frames h0 .. h0+12 are OWNED by the
+// workgroup (it writes their tprev / spectrum), the halo frames h0-3 .. h0-1 are recomputed from y_in and tprev_in, which is
+// why both are double buffered (a neighbour may still be reading what this workgroup would overwrite).
+__global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const float* __restrict__ y_in, float* __restrict__ y_out,
+                                                                       const float* __restrict__ win, const float* __restrict__ wss,
+                                                                       const float2* __restrict__ tw, const float* __restrict__ mag,
+                                                                       const float2* __restrict__ tprev_in, float2* __restrict__ tprev_out,
+                                                                       float2* __restrict__ spec_out, float c, int first, int do_inverse,
+                                                                       int T) {
+    extern __shared__ __attribute__((aligned(16))) float2 fsm[];   // [GLI_FRAMES][FPAD] float2; reused as [GLI_FRAMES][1024+] float
+    const int b = blockIdx.y, h0 = blockIdx.x * GLI_BLOCKS;
+    const int tid = threadIdx.x, j = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = h0 - 3 + wave;
+    const bool valid = t >= 0 && t < T;       // wave-uniform; every wave still joins the barriers
+    const bool owner = valid && wave >= 3;    // frames h0 .. h0+12
+    float2* buf = fsm + wave * FPAD;
+    const float2* tw2 = tw + FN;
+    const long n = (long)(T + 3) * 256;
+    float2 v[8];
+    if (valid) {
+        // ---- forward: frame of y_in, windowed
+        const float* yb = y_in + (long)b * n + (long)t * 256;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n2 = 2 * (j + 64 * r);
+            const float2 x = *reinterpret_cast<const float2*>(yb + n2);
+            const float2 w = *reinterpret_cast<const float2*>(win + n2);
+            v[r] = make_float2(w.x * x.x, w.y * x.y);
+        }
+        // the update's operands do not depend on the FFT: fetch them now so their latency hides under it.  (Measured the other
+        // way round as well: loading them after the FFT and capping the kernel at 64 VGPRs puts two workgroups on a CU, but the
+        // kernel is bound by instruction issue and LDS traffic, not by latency - 81 ms instead of 72 ms for 60 iterations.)
+        const long base = ((long)b * T + t) * 513;
+        float2 pv[9];
+        float mg[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int k = r < 8 ? j + 64 * r : 512;
+            const bool mine = r < 8 || j == 0;
+            pv[r] = (mine && !first) ? tprev_in[base + k] : make_float2(0.f, 0.f);
+            mg[r] = mine ? mag[base + k] : 0.f;
+        }
+        fft512_wave<false>(v, buf, tw, j, true);
+        wave_lds_fence();        // ---- rebuilt spectrum, momentum update, projection onto the magnitudes: bins k = j + 64 r and, on lane 0, k = 512
+        float2 S[9];
+        auto update_bin = [&](int k, float2 pvk, float mgk) -> float2 {
+            const float2 zk = buf[fpad(k & (FN - 1))];
+            float2 zc = buf[fpad((512 - k) & (FN - 1))];
+            zc.y = -zc.y;
+            const float2 sm = cadd(zk, zc), df = csub(zk, zc);
+            const float2 wd = cmul(tw2[k], df);                  // W^k (Z[k] - conj Z[512-k])
+            float2 reb = make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));   // 0.5*sm - 0.5i*wd
+            if (k == 0 || k == 512) reb.y = 0.f;                 // exactly real for a real signal
+            float2 a = reb;
+            if (!first) {
+                a.x = reb.x - c * pvk.x;
+                a.y = reb.y - c * pvk.y;
+            }
+            // a / (|a| + tiny) * mag with v_sqrt_f32 / v_rcp_f32; operands pre-scaled when their squares would underflow
+            const float big = fmaxf(fabsf(a.x), fabsf(a.y));
+            const float sc = big < 1e-15f ? 1.8446744e19f : 1.f, isc = big < 1e-15f ? 5.4210109e-20f : 1.f;   // 2^64, 2^-64
+            const float ax = a.x * sc, ay = a.y * sc;
+            const float dd = __builtin_amdgcn_sqrtf(ax * ax + ay * ay) * isc + 1.17549435e-38f;
+            const float q = __builtin_amdgcn_rcpf(dd) * mgk;
+            const float2 Sk = make_float2(a.x * q, a.y * q);
+            if (owner) {
+                tprev_out[base + k] = reb;
+                if (spec_out) spec_out[base + k] = Sk;
+            }
+            return Sk;
+        };
+#pragma unroll
+        for (int r = 0; r < 8; ++r) S[r] = update_bin(j + 64 * r, pv[r], mg[r]);
+        S[8] = make_float2(0.f, 0.f);
+        if (j == 0) S[8] = update_bin(512, pv[8], mg[8]);
+        if (do_inverse) {
+            // ---- inverse: S[k] and S[512-k] meet through this wave's LDS row (all reads of Z above are done)
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) buf[fpad(j + 64 * r)] = S[r];
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = j + 64 * r;
+                float2 a = S[r];
+                float2 cj = k == 0 ? S[8] : buf[fpad(512 - k)];   // lane 0 holds the Nyquist bin itself
+                if (k == 0) { a.y = 0.f; cj.y = 0.f; }             // c2r ignores the imaginary parts of the DC and Nyquist bins
+                cj.y = -cj.y;                                      // conj(S[512 - k])
+                const float2 w = tw2[k];                           // e^{-2 pi i k/1024}; need e^{+...}
+                const float2 d = csub(a, cj);
+                const float2 id = make_float2(-d.y, d.x);          // i * d
+                v[r] = cadd(cadd(a, cj), cmul(id, make_float2(w.x, -w.y)));
+            }
+            wave_lds_fence();
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
+    }
+    if (!do_inverse) return;   // uniform: the last iteration only needs the spectrum
+    fft512_wave<true>(v, buf, tw, j, false);
+    // windowed frame (same operation order as gl_ola_kernel: win[k] * (fr[k] * (1/n_fft))) into this wave's LDS row
+    float* frow = reinterpret_cast<float*>(buf);
+    __syncthreads();
+    if (valid) {
+        const float inv_n = 1.f / 1024.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n2 = 2 * (j + 64 * r);
+            const float2 w = *reinterpret_cast<const float2*>(win + n2);
+            *reinterpret_cast<float2*>(frow + n2) = make_float2(w.x * (v[r].x * inv_n), w.y * (v[r].y * inv_n));
+        }
+    }
+    __syncthreads();
+    // overlap-add of hop blocks h0 .. h0+12 (ascending frame order), divide by the window sum of squares
+    const float* fall = reinterpret_cast<const float*>(fsm);
+    for (int idx = tid; idx < GLI_BLOCKS * 256; idx += GLI_FRAMES * 64) {
+        const int hb = idx >> 8, q = idx & 255;
+        const int h = h0 + hb;
+        const long i = (long)h * 256 + q;
+        if (i >= n) break;
+        float sacc = 0.f;
+#pragma unroll
+        for (int d = 3; d >= 0; --d) {           // frames t = h-3 .. h  ->  waves hb .. hb+3
+            const int tt = h - d;
+            if (tt >= 0 && tt < T) sacc += fall[(long)(hb + 3 - d) * (FPAD * 2) + d * 256 + q];
+        }
+        const float w = wss[i];
+        y_out[(long)b * n + i] = w > 1.17549435e-38f ? sacc * __builtin_amdgcn_rcpf(w) : sacc;
+    }
+}
+
 constexpr int GLF_FRAMES = 4;   // frames (waves) per workgroup of the forward kernel
 
 // y -> rebuilt = rfft(win * frame); ang' = rebuilt - c*tprev; S = mag * ang' / (|ang'| + tiny); tprev = rebuilt  (in place)
@@ -757,6 +898,8 @@ int gvx_gl_plan_create(int n_fft, int hop, gvx_gl_plan** out) {
             return gl_fail(GVX_ERR_HIP, "twiddle table allocation failed");
         }
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gl_inverse_ola_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GLI_FRAMES * FPAD * (int)sizeof(float2)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iteration_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GLI_FRAMES * FPAD * (int)sizeof(float2)) != hipSuccess) {
             delete p;
             return gl_fail(GVX_ERR_HIP, "hipFuncSetAttribute failed");
@@ -879,7 +1022,22 @@ int gvx_griffin_lim(gvx_gl_plan* p, const float* mag, const float* window, int B
         GL_HIP(hipGetLastError());
         return GVX_OK;
     };
-    for (int it = 0; fused && it < n_iter; ++it) {
+    if (fused && n_iter > 0 && !getenv_flag("GVX_GL_TWO_KERNELS")) {
+        // one launch per iteration: signal -> rebuilt -> update -> new spectrum -> its signal (gl_iteration_kernel); the signal
+        // and tprev ping-pong between two buffers each (the framed-signal region of the rocFFT pipeline serves as the second y)
+        float* ybuf[2] = {wsp<float>(ws, w.y), wsp<float>(ws, w.fr)};
+        rc = inverse_ola(ang);                                  // signal of the initial angles
+        if (rc != GVX_OK) return rc;
+        const dim3 grid((unsigned)((T + 3 + GLI_BLOCKS - 1) / GLI_BLOCKS), B);
+        for (int it = 0; it < n_iter; ++it) {
+            const bool last = it == n_iter - 1;
+            gl_iteration_kernel<<<grid, GLI_FRAMES * 64, GLI_FRAMES * FPAD * sizeof(float2), s>>>(
+                ybuf[it & 1], ybuf[(it + 1) & 1], window, wsp<float>(ws, w.wss), p->tw, mag_t, reb[it & 1], reb[(it + 1) & 1],
+                last ? ang : nullptr, c, it == 0, !last, T);
+            GL_HIP(hipGetLastError());
+        }
+    } else
+    for (int it = 0; fused && it < n_iter; ++it) {              // GVX_GL_TWO_KERNELS=1: the two-launch iteration (A/B runs)
         rc = inverse_ola(ang);                                  // inverse = istft(angles)
         if (rc != GVX_OK) return rc;
         const long frames = (long)B * T;                        // rebuilt = stft(inverse); momentum update; tprev = rebuilt

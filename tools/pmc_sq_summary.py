@@ -12,13 +12,13 @@ import sys
 tag = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_sq", "pmc_tcc"):
-    for f in glob.glob(f"gpurun_out/{d}/*counter_collection.csv"):
+    for f in glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             if "gvx::" in k:
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = collections.defaultdict(list)   # kernel durations during the SQ pass (counter collection serialises and slows launches)
-for f in glob.glob("gpurun_out/pmc_sq/*kernel_trace.csv"):
+for f in glob.glob("gpurun_out/pmc_sq/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         dur[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 rows = []

@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/ (per-kernel averages + the traffic JSON
-bench.py reads).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly half the bytes of a wide
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/<tag>_pmc_traffic_b<batch>.json (per-kernel averages).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly half the bytes of a wide
 coalesced streaming read, WRITE_SIZE is exact; both are in KiB."""
 import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 tag, batch = sys.argv[1], int(sys.argv[2])
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"gpurun_out/pmc_{c}/*/*counter_collection.csv")[0]
+    f = sorted(glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == c:
@@ -25,7 +25,4 @@ for k in sorted(out["FETCH_SIZE"], key=lambda k: -out["FETCH_SIZE"][k]["avg_KiB"
                  "hbm_bytes_per_launch": round(fe + wr)})
 json.dump({"round": tag, "batch": batch, "note": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count) + WRITE_SIZE KiB x1024, separate --pmc passes",
            "kernels": rows}, open(f"profiles/{tag}_pmc_traffic_b{batch}.json", "w"), indent=1)
-dom = next(r for r in rows if "decoder_lstm_step" in r["kernel"])
-json.dump({"batch": batch, "kernel": dom["kernel"], "hbm_bytes_per_launch": dom["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_traffic_b{batch}.json"},
-          open("profiles/traffic_latest.json", "w"))
 print(json.dumps(rows[:4], indent=1))

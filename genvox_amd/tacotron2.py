@@ -479,6 +479,7 @@ class Tacotron2(nn.Module):
             outputs = self.forward(batch)
             loss = (criterion or self.get_criterion())["loss"](batch, outputs)
         self.loss_items_eval = {(key + "_eval"): val.item() for key, val in loss.items()}
+        self.check_status()   # the .item() calls above have synchronised: a bad token id raises here like nn.Embedding does
         return outputs
 
     def get_eval_priority(self) -> float:

@@ -46,7 +46,10 @@ lib2 = C.CDLL(_lib.LIB_PATH)
 raw = (C.c_ulonglong * 96)()
 lib2.gvx_debug_read_stamps_skinny.argtypes = [C.c_void_p]
 if lib2.gvx_debug_read_stamps_skinny(raw) == 0:
-    for row, nm in ((1, "attention-LSTM tile 0"), (2, "decoder-LSTM tile 0")):
+    # NOTE: block 0 of EVERY skinny launch writes row 1 (and the first tile of a launch's second job row 2): after a whole
+    # forward these are the stamps of the LAST launch that had such a block - the decoder-LSTM drain launch -, not of a
+    # mid-sequence step; the per-workgroup spans below are the ones to read for the steady-state launch
+    for row, nm in ((1, "block 0 of the last skinny launch"), (2, "first tile of the second job of the last 2-job launch")):
         # row 2 carries its own reference: block 0's start stamp of the launch the decoder tile ran in (slot 7); the last
         # launch of a sequence has decoder tiles only, so row 0 may belong to a different launch
         t0 = raw[2 * 32 + 7] if row == 2 else raw[0]

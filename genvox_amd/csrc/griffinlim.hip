@@ -503,6 +503,8 @@ __device__ __forceinline__ void fft512_wave(float2 v[8], float2* buf, const floa
 
 constexpr int GLI_FRAMES = 16;                 // frames (waves) per workgroup of the inverse kernel
 constexpr int GLI_BLOCKS = GLI_FRAMES - 3;     // hop blocks it completes (n_fft / hop - 1 = 3 halo frames)
+constexpr int GLI_TAB_WIN = FN + 520;          // LDS tables of gl_iteration_kernel, in float2: twiddles [FN + 513], pad, window [512]
+constexpr int GLI_TAB = GLI_TAB_WIN + 512;
 
 // S [B*T][513] (frame-major) -> y [B][(T+3)*256]: y[i] = (sum_t win[k] * (irfft(S_t)[k] / 1024)) / wss[i], k = i - 256 t
 __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_inverse_ola_kernel(const float2* __restrict__ spec, const float* __restrict__ win,
@@ -578,24 +580,40 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_inverse_ola_kernel(const f
 // Workgroup = 16 frames (waves) = the 13 hop blocks they complete + 3 halo frames; frames h0 .. h0+12 are OWNED by the
 // workgroup (it writes their tprev / spectrum), the halo frames h0-3 .. h0-1 are recomputed from y_in and tprev_in, which is
 // why both are double buffered (a neighbour may still be reading what this workgroup would overwrite).
+template <int FPW>   // frames per wave: a workgroup covers 16 FPW frames = 16 FPW - 3 hop blocks (halo share 3/16 or 3/32)
 __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const float* __restrict__ y_in, float* __restrict__ y_out,
-                                                                       const float* __restrict__ win, const float* __restrict__ wss,
-                                                                       const float2* __restrict__ tw, const float* __restrict__ mag,
+                                                                       const float* __restrict__ win_g, const float* __restrict__ wss,
+                                                                       const float2* __restrict__ tw_g, const float* __restrict__ mag,
                                                                        const float2* __restrict__ tprev_in, float2* __restrict__ tprev_out,
                                                                        float2* __restrict__ spec_out, float c, int first, int do_inverse,
                                                                        int T) {
-    extern __shared__ __attribute__((aligned(16))) float2 fsm[];   // [GLI_FRAMES][FPAD] float2; reused as [GLI_FRAMES][1024+] float
-    const int b = blockIdx.y, h0 = blockIdx.x * GLI_BLOCKS;
-    const int tid = threadIdx.x, j = tid & 63;
+    constexpr int NFR = GLI_FRAMES * FPW, NBL = NFR - 3;
+    extern __shared__ __attribute__((aligned(16))) float2 fsm[];   // [NFR][FPAD] float2; reused as [NFR][1024+] float
+    const int b = blockIdx.y, h0 = blockIdx.x * NBL;
+    const int tid = threadIdx.x, jj = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t = h0 - 3 + wave;
-    const bool valid = t >= 0 && t < T;       // wave-uniform; every wave still joins the barriers
-    const bool owner = valid && wave >= 3;    // frames h0 .. h0+12
-    float2* buf = fsm + wave * FPAD;
-    const float2* tw2 = tw + FN;
     const long n = (long)(T + 3) * 256;
-    float2 v[8];
-    if (valid) {
+    // twiddle and window tables live in LDS behind the frame rows: a table read from global memory costs the wave a
+    // round trip through L1 at every FFT pass (60 % of the wave cycles were s_waitcnt before this)
+    float2* tab = fsm + NFR * FPAD;
+    for (int i = tid; i < GLI_TAB; i += GLI_FRAMES * 64)
+        tab[i] = i < FN + 513 ? tw_g[i] : (i < GLI_TAB_WIN ? make_float2(0.f, 0.f) : reinterpret_cast<const float2*>(win_g)[i - GLI_TAB_WIN]);
+    __syncthreads();
+    const float2* tw_ = tab;
+    const float* win_ = reinterpret_cast<const float*>(tab + GLI_TAB_WIN);
+#pragma unroll 1
+    for (int f = 0; f < FPW; ++f) {
+        const int slot = wave + GLI_FRAMES * f;   // the wave's frames are 16 apart so that all waves stay busy in the last group
+        const int t = h0 - 3 + slot;
+        if (t < 0 || t >= T) continue;            // wave-uniform; the barrier below is outside the loop
+        const bool owner = slot >= 3;             // frames h0 .. h0+NBL-1
+        float2* buf = fsm + slot * FPAD;
+        float2 v[8];
+        // the tables are frame independent: without this the compiler hoists their loads out of the frame loop and spills
+        const float* win = win_;
+        const float2 *tw = tw_, *tw2 = tw_ + FN;
+        int j = jj;
+        if (FPW > 1) asm volatile("" : "+v"(j));
         // ---- forward: frame of y_in, windowed
         const float* yb = y_in + (long)b * n + (long)t * 256;
 #pragma unroll
@@ -651,36 +669,29 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const flo
         for (int r = 0; r < 8; ++r) S[r] = update_bin(j + 64 * r, pv[r], mg[r]);
         S[8] = make_float2(0.f, 0.f);
         if (j == 0) S[8] = update_bin(512, pv[8], mg[8]);
-        if (do_inverse) {
-            // ---- inverse: S[k] and S[512-k] meet through this wave's LDS row (all reads of Z above are done)
-            wave_lds_fence();
+        if (!do_inverse) continue;   // uniform: the last iteration only needs the spectrum
+        // ---- inverse: S[k] and S[512-k] meet through this wave's LDS row (all reads of Z above are done)
+        wave_lds_fence();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) buf[fpad(j + 64 * r)] = S[r];
-            wave_lds_fence();
+        for (int r = 0; r < 8; ++r) buf[fpad(j + 64 * r)] = S[r];
+        wave_lds_fence();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int k = j + 64 * r;
-                float2 a = S[r];
-                float2 cj = k == 0 ? S[8] : buf[fpad(512 - k)];   // lane 0 holds the Nyquist bin itself
-                if (k == 0) { a.y = 0.f; cj.y = 0.f; }             // c2r ignores the imaginary parts of the DC and Nyquist bins
-                cj.y = -cj.y;                                      // conj(S[512 - k])
-                const float2 w = tw2[k];                           // e^{-2 pi i k/1024}; need e^{+...}
-                const float2 d = csub(a, cj);
-                const float2 id = make_float2(-d.y, d.x);          // i * d
-                v[r] = cadd(cadd(a, cj), cmul(id, make_float2(w.x, -w.y)));
-            }
-            wave_lds_fence();
+        for (int r = 0; r < 8; ++r) {
+            const int k = j + 64 * r;
+            float2 a = S[r];
+            float2 cj = k == 0 ? S[8] : buf[fpad(512 - k)];   // lane 0 holds the Nyquist bin itself
+            if (k == 0) { a.y = 0.f; cj.y = 0.f; }             // c2r ignores the imaginary parts of the DC and Nyquist bins
+            cj.y = -cj.y;                                      // conj(S[512 - k])
+            const float2 w = tw2[k];                           // e^{-2 pi i k/1024}; need e^{+...}
+            const float2 d = csub(a, cj);
+            const float2 id = make_float2(-d.y, d.x);          // i * d
+            v[r] = cadd(cadd(a, cj), cmul(id, make_float2(w.x, -w.y)));
         }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
-    }
-    if (!do_inverse) return;   // uniform: the last iteration only needs the spectrum
-    fft512_wave<true>(v, buf, tw, j, false);
-    // windowed frame (same operation order as gl_ola_kernel: win[k] * (fr[k] * (1/n_fft))) into this wave's LDS row
-    float* frow = reinterpret_cast<float*>(buf);
-    __syncthreads();
-    if (valid) {
+        wave_lds_fence();
+        fft512_wave<true>(v, buf, tw, j, false);
+        // windowed frame (same operation order as gl_ola_kernel: win[k] * (fr[k] * (1/n_fft))) into this frame's LDS row, which
+        // only this wave touches until the barrier (the FFT's last exchange ended with a fence)
+        float* frow = reinterpret_cast<float*>(buf);
         const float inv_n = 1.f / 1024.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -689,17 +700,18 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const flo
             *reinterpret_cast<float2*>(frow + n2) = make_float2(w.x * (v[r].x * inv_n), w.y * (v[r].y * inv_n));
         }
     }
+    if (!do_inverse) return;
     __syncthreads();
-    // overlap-add of hop blocks h0 .. h0+12 (ascending frame order), divide by the window sum of squares
+    // overlap-add of hop blocks h0 .. h0+NBL-1 (ascending frame order), divide by the window sum of squares
     const float* fall = reinterpret_cast<const float*>(fsm);
-    for (int idx = tid; idx < GLI_BLOCKS * 256; idx += GLI_FRAMES * 64) {
+    for (int idx = tid; idx < NBL * 256; idx += GLI_FRAMES * 64) {
         const int hb = idx >> 8, q = idx & 255;
         const int h = h0 + hb;
         const long i = (long)h * 256 + q;
         if (i >= n) break;
         float sacc = 0.f;
 #pragma unroll
-        for (int d = 3; d >= 0; --d) {           // frames t = h-3 .. h  ->  waves hb .. hb+3
+        for (int d = 3; d >= 0; --d) {           // frames t = h-3 .. h  ->  rows hb .. hb+3
             const int tt = h - d;
             if (tt >= 0 && tt < T) sacc += fall[(long)(hb + 3 - d) * (FPAD * 2) + d * 256 + q];
         }
@@ -899,8 +911,10 @@ int gvx_gl_plan_create(int n_fft, int hop, gvx_gl_plan** out) {
         }
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gl_inverse_ola_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GLI_FRAMES * FPAD * (int)sizeof(float2)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iteration_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GLI_FRAMES * FPAD * (int)sizeof(float2)) != hipSuccess) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iteration_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (GLI_FRAMES * FPAD + GLI_TAB) * (int)sizeof(float2)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gl_iteration_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (2 * GLI_FRAMES * FPAD + GLI_TAB) * (int)sizeof(float2)) != hipSuccess) {
             delete p;
             return gl_fail(GVX_ERR_HIP, "hipFuncSetAttribute failed");
         }
@@ -1028,12 +1042,20 @@ int gvx_griffin_lim(gvx_gl_plan* p, const float* mag, const float* window, int B
         float* ybuf[2] = {wsp<float>(ws, w.y), wsp<float>(ws, w.fr)};
         rc = inverse_ola(ang);                                  // signal of the initial angles
         if (rc != GVX_OK) return rc;
-        const dim3 grid((unsigned)((T + 3 + GLI_BLOCKS - 1) / GLI_BLOCKS), B);
+        // two frames per wave (29 hop blocks per workgroup, 147 KB of LDS) unless the sequence is short
+        const bool two = T + 3 > GLI_BLOCKS && !getenv_flag("GVX_GL_ONE_FRAME");
+        const int nbl = two ? 2 * GLI_FRAMES - 3 : GLI_BLOCKS;
+        const dim3 grid((unsigned)((T + 3 + nbl - 1) / nbl), B);
         for (int it = 0; it < n_iter; ++it) {
             const bool last = it == n_iter - 1;
-            gl_iteration_kernel<<<grid, GLI_FRAMES * 64, GLI_FRAMES * FPAD * sizeof(float2), s>>>(
-                ybuf[it & 1], ybuf[(it + 1) & 1], window, wsp<float>(ws, w.wss), p->tw, mag_t, reb[it & 1], reb[(it + 1) & 1],
-                last ? ang : nullptr, c, it == 0, !last, T);
+            if (two)
+                gl_iteration_kernel<2><<<grid, GLI_FRAMES * 64, (2 * GLI_FRAMES * FPAD + GLI_TAB) * sizeof(float2), s>>>(
+                    ybuf[it & 1], ybuf[(it + 1) & 1], window, wsp<float>(ws, w.wss), p->tw, mag_t, reb[it & 1], reb[(it + 1) & 1],
+                    last ? ang : nullptr, c, it == 0, !last, T);
+            else
+                gl_iteration_kernel<1><<<grid, GLI_FRAMES * 64, (GLI_FRAMES * FPAD + GLI_TAB) * sizeof(float2), s>>>(
+                    ybuf[it & 1], ybuf[(it + 1) & 1], window, wsp<float>(ws, w.wss), p->tw, mag_t, reb[it & 1], reb[(it + 1) & 1],
+                    last ? ang : nullptr, c, it == 0, !last, T);
             GL_HIP(hipGetLastError());
         }
     } else

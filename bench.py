@@ -329,7 +329,9 @@ def main():
             gbs = 20516 * 256 * T * 60 / dt / 1e9   # 20 516 B per frame-iteration (minimal fused traffic)
             e = {"ms": round(dt * 1e3, 2), "frames_per_s": round(256 * T / dt, 1), "utterances_per_s": round(256 / dt, 1),
                  "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                              "algorithmic_bytes_per_frame_iteration": 20516}}
+                              "algorithmic_bytes_per_frame_iteration": 20516,
+                              # what gl_iteration_kernel itself moves (the spectrum stays on chip): 12 500 B per frame-iteration
+                              "moved_bytes_per_frame_iteration": 12500, "moved_gbs": round(12500 * 256 * T * 60 / dt / 1e9, 1)}}
             if with_cpu:
                 import numpy as np
 

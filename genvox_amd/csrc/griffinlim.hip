@@ -431,6 +431,8 @@ int iir_warmup_length(const IirCoef& c, int cap) {
 constexpr int FN = 512;              // complex points
 constexpr int FPAD = FN + FN / 8;    // LDS words (float2) per frame: index i lives at i + (i >> 3)
 __device__ __forceinline__ int fpad(int i) { return i + (i >> 3); }
+// (Measured: an XOR swizzle of the row instead of the padding removes the last two-way conflicts of the j + 64 r accesses, but
+// its addresses no longer fold into the instructions' immediate offsets; the extra VALU work costs more than the conflicts.)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -469,7 +471,9 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool INV>
+// CTW: per-pass twiddle tables (tw[(r-1)*8 + k] for the second pass, tw[64 + (r-1)*64 + j] for the third: the same values as
+// tw[(r k mult) & 511] of the plain table, gathered so that a half wave reads consecutive LDS words)
+template <bool INV, bool CTW = false>
 __device__ __forceinline__ void fft512_wave(float2 v[8], float2* buf, const float2* __restrict__ tw, int j, bool to_lds) {
 #pragma unroll
     for (int stage = 0; stage < 3; ++stage) {
@@ -479,7 +483,7 @@ __device__ __forceinline__ void fft512_wave(float2 v[8], float2* buf, const floa
             const int mult = 64 / Ns;   // twiddle w_{Ns*8}^{r k} = w_512^{r k mult}
 #pragma unroll
             for (int r = 1; r < 8; ++r) {
-                float2 w = tw[(r * k * mult) & (FN - 1)];
+                float2 w = CTW ? tw[(stage == 1 ? 0 : 64) + (r - 1) * Ns + k] : tw[(r * k * mult) & (FN - 1)];
                 if (INV) w.y = -w.y;
                 v[r] = cmul(v[r], w);
             }
@@ -577,9 +581,10 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_inverse_ola_kernel(const f
 // 4 104 (tprev in) + 2 052 (mag) + 4 104 (tprev out) + 1 024 (y_out) = 12.5 KB (x 16/13 for the reads of halo frames: 14.1 KB)
 // against 21.5 KB of the forward / inverse kernel pair above (S written, then read x 1.23) and 20 516 B of SURVEY 8d's
 // "minimal" count, which assumed the spectrum has to make the round trip.
-// Workgroup = 16 frames (waves) = the 13 hop blocks they complete + 3 halo frames; frames h0 .. h0+12 are OWNED by the
-// workgroup (it writes their tprev / spectrum), the halo frames h0-3 .. h0-1 are recomputed from y_in and tprev_in, which is
-// why both are double buffered (a neighbour may still be reading what this workgroup would overwrite).
+// Workgroup = 16 waves x FPW frames each = the 16 FPW - 3 hop blocks they complete + 3 halo frames; frames h0 .. are OWNED by
+// the workgroup (it writes their tprev / spectrum), the halo frames h0-3 .. h0-1 are recomputed from y_in and tprev_in, which
+// is why both are double buffered (a neighbour may still be reading what this workgroup would overwrite).  FPW = 2 (32 frames,
+// 29 blocks, 144 KB of rows + 12 KB of tables in LDS) recomputes 10 % of the frames instead of 23 %.
 template <int FPW>   // frames per wave: a workgroup covers 16 FPW frames = 16 FPW - 3 hop blocks (halo share 3/16 or 3/32)
 __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const float* __restrict__ y_in, float* __restrict__ y_out,
                                                                        const float* __restrict__ win_g, const float* __restrict__ wss,
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const flo
                                                                        float2* __restrict__ spec_out, float c, int first, int do_inverse,
                                                                        int T) {
     constexpr int NFR = GLI_FRAMES * FPW, NBL = NFR - 3;
-    extern __shared__ __attribute__((aligned(16))) float2 fsm[];   // [NFR][FPAD] float2; reused as [NFR][1024+] float
+    extern __shared__ __attribute__((aligned(16))) float2 fsm[];   // [NFR][FPAD] float2; reused as [NFR][1024+] float; then the tables
     const int b = blockIdx.y, h0 = blockIdx.x * NBL;
     const int tid = threadIdx.x, jj = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -597,7 +602,8 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const flo
     // round trip through L1 at every FFT pass (60 % of the wave cycles were s_waitcnt before this)
     float2* tab = fsm + NFR * FPAD;
     for (int i = tid; i < GLI_TAB; i += GLI_FRAMES * 64)
-        tab[i] = i < FN + 513 ? tw_g[i] : (i < GLI_TAB_WIN ? make_float2(0.f, 0.f) : reinterpret_cast<const float2*>(win_g)[i - GLI_TAB_WIN]);
+        tab[i] = i < FN ? tw_g[FN + 513 + i]      // per-pass twiddles
+                        : (i < FN + 513 ? tw_g[i] : (i < GLI_TAB_WIN ? make_float2(0.f, 0.f) : reinterpret_cast<const float2*>(win_g)[i - GLI_TAB_WIN]));
     __syncthreads();
     const float2* tw_ = tab;
     const float* win_ = reinterpret_cast<const float*>(tab + GLI_TAB_WIN);
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const flo
             pv[r] = (mine && !first) ? tprev_in[base + k] : make_float2(0.f, 0.f);
             mg[r] = mine ? mag[base + k] : 0.f;
         }
-        fft512_wave<false>(v, buf, tw, j, true);
+        fft512_wave<false, true>(v, buf, tw, j, true);
         wave_lds_fence();        // ---- rebuilt spectrum, momentum update, projection onto the magnitudes: bins k = j + 64 r and, on lane 0, k = 512
         float2 S[9];
         auto update_bin = [&](int k, float2 pvk, float mgk) -> float2 {
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const flo
         for (int r = 0; r < 8; ++r) {
             const int k = j + 64 * r;
             float2 a = S[r];
-            float2 cj = k == 0 ? S[8] : buf[fpad(512 - k)];   // lane 0 holds the Nyquist bin itself
+            float2 cj = k == 0 ? S[8] : buf[fpad((512 - k) & (FN - 1))];   // lane 0 holds the Nyquist bin itself
             if (k == 0) { a.y = 0.f; cj.y = 0.f; }             // c2r ignores the imaginary parts of the DC and Nyquist bins
             cj.y = -cj.y;                                      // conj(S[512 - k])
             const float2 w = tw2[k];                           // e^{-2 pi i k/1024}; need e^{+...}
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const flo
             v[r] = cadd(cadd(a, cj), cmul(id, make_float2(w.x, -w.y)));
         }
         wave_lds_fence();
-        fft512_wave<true>(v, buf, tw, j, false);
+        fft512_wave<true, true>(v, buf, tw, j, false);
         // windowed frame (same operation order as gl_ola_kernel: win[k] * (fr[k] * (1/n_fft))) into this frame's LDS row, which
         // only this wave touches until the barrier (the FFT's last exchange ended with a fence)
         float* frow = reinterpret_cast<float*>(buf);
@@ -900,10 +906,16 @@ int gvx_gl_plan_create(int n_fft, int hop, gvx_gl_plan** out) {
     gvx_gl_plan* p = new gvx_gl_plan();
     p->n_fft = n_fft; p->hop = hop; p->bins = n_fft / 2 + 1;
     if (n_fft == 1024 && hop == 256) {   // tables of the fused Griffin-Lim path
-        std::vector<float2> h(FN + 513);
+        std::vector<float2> h(FN + 513 + FN);   // w_512^m, w_1024^k, and gl_iteration_kernel's per-pass gather of the first table
         const double two_pi = 6.283185307179586476925286766559;
         for (int m = 0; m < FN; ++m) h[m] = make_float2((float)std::cos(two_pi * m / 512.0), (float)-std::sin(two_pi * m / 512.0));
         for (int k = 0; k <= 512; ++k) h[FN + k] = make_float2((float)std::cos(two_pi * k / 1024.0), (float)-std::sin(two_pi * k / 1024.0));
+        float2* g = h.data() + FN + 513;
+        for (int i = 0; i < FN; ++i) g[i] = make_float2(1.f, 0.f);
+        for (int r = 1; r < 8; ++r) {
+            for (int k = 0; k < 8; ++k) g[(r - 1) * 8 + k] = h[(r * k * 8) & (FN - 1)];
+            for (int k = 0; k < 64; ++k) g[64 + (r - 1) * 64 + k] = h[(r * k) & (FN - 1)];
+        }
         if (hipMalloc(&p->tw, h.size() * sizeof(float2)) != hipSuccess ||
             hipMemcpy(p->tw, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
             delete p;

@@ -645,26 +645,33 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const flo
         fft512_wave<false, true>(v, buf, tw, j, true);
         wave_lds_fence();        // ---- rebuilt spectrum, momentum update, projection onto the magnitudes: bins k = j + 64 r and, on lane 0, k = 512
         float2 S[9];
-        auto update_bin = [&](int k, float2 pvk, float mgk) -> float2 {
-            const float2 zk = buf[fpad(k & (FN - 1))];
-            float2 zc = buf[fpad((512 - k) & (FN - 1))];
+        // row addresses: bin k = j + 64 r sits at fpad(j) + 72 r and its mirror 512 - k at fpad(512 - j) - 72 r (both linear in r,
+        // so they fold into the LDS instructions' offsets); only k = 0 (lane 0, r = 0) mirrors onto itself
+        const int a_fwd = fpad(j), a_rev = fpad(512 - j);
+        auto update_bin = [&](const int r, float2 pvk, float mgk) -> float2 {   // r is a constant after unrolling
+            const int k = r < 8 ? j + 64 * r : 512;
+            const bool edge = r == 8 || (r == 0 && j == 0);       // DC / Nyquist
+            const float2 zk = buf[r < 8 ? a_fwd + 72 * r : 0];
+            float2 zc = buf[r == 8 ? 0 : (r == 0 && j == 0 ? 0 : a_rev - 72 * r)];
             zc.y = -zc.y;
             const float2 sm = cadd(zk, zc), df = csub(zk, zc);
             const float2 wd = cmul(tw2[k], df);                  // W^k (Z[k] - conj Z[512-k])
             float2 reb = make_float2(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));   // 0.5*sm - 0.5i*wd
-            if (k == 0 || k == 512) reb.y = 0.f;                 // exactly real for a real signal
+            if ((r == 0 || r == 8) && edge) reb.y = 0.f;         // exactly real for a real signal
             float2 a = reb;
             if (!first) {
                 a.x = reb.x - c * pvk.x;
                 a.y = reb.y - c * pvk.y;
             }
-            // a / (|a| + tiny) * mag with v_sqrt_f32 / v_rcp_f32; operands pre-scaled when their squares would underflow
-            const float big = fmaxf(fabsf(a.x), fabsf(a.y));
-            const float sc = big < 1e-15f ? 1.8446744e19f : 1.f, isc = big < 1e-15f ? 5.4210109e-20f : 1.f;   // 2^64, 2^-64
-            const float ax = a.x * sc, ay = a.y * sc;
-            const float dd = __builtin_amdgcn_sqrtf(ax * ax + ay * ay) * isc + 1.17549435e-38f;
-            const float q = __builtin_amdgcn_rcpf(dd) * mgk;
-            const float2 Sk = make_float2(a.x * q, a.y * q);
+            // a / (|a| + tiny) * mag with v_sqrt_f32 / v_rcp_f32; the operands are pre-scaled on the rare path where their
+            // squares would underflow (|a| < 1e-15), like the hypot behind the reference's abs()
+            float dd = __builtin_amdgcn_sqrtf(a.x * a.x + a.y * a.y);
+            if (fmaxf(fabsf(a.x), fabsf(a.y)) < 1e-15f) {
+                const float ax = a.x * 1.8446744e19f, ay = a.y * 1.8446744e19f;   // 2^64
+                dd = __builtin_amdgcn_sqrtf(ax * ax + ay * ay) * 5.4210109e-20f;  // 2^-64
+            }
+            const float q = __builtin_amdgcn_rcpf(dd + 1.17549435e-38f);
+            const float2 Sk = make_float2(a.x * q * mgk, a.y * q * mgk);   // unit vector first: 0 * (mag / tiny) would be NaN
             if (owner) {
                 tprev_out[base + k] = reb;
                 if (spec_out) spec_out[base + k] = Sk;
@@ -672,21 +679,22 @@ __global__ __launch_bounds__(GLI_FRAMES * 64) void gl_iteration_kernel(const flo
             return Sk;
         };
 #pragma unroll
-        for (int r = 0; r < 8; ++r) S[r] = update_bin(j + 64 * r, pv[r], mg[r]);
+        for (int r = 0; r < 8; ++r) S[r] = update_bin(r, pv[r], mg[r]);
         S[8] = make_float2(0.f, 0.f);
-        if (j == 0) S[8] = update_bin(512, pv[8], mg[8]);
+        if (j == 0) S[8] = update_bin(8, pv[8], mg[8]);
         if (!do_inverse) continue;   // uniform: the last iteration only needs the spectrum
         // ---- inverse: S[k] and S[512-k] meet through this wave's LDS row (all reads of Z above are done)
         wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) buf[fpad(j + 64 * r)] = S[r];
+        for (int r = 0; r < 8; ++r) buf[a_fwd + 72 * r] = S[r];
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int k = j + 64 * r;
+            const bool dc = r == 0 && j == 0;
             float2 a = S[r];
-            float2 cj = k == 0 ? S[8] : buf[fpad((512 - k) & (FN - 1))];   // lane 0 holds the Nyquist bin itself
-            if (k == 0) { a.y = 0.f; cj.y = 0.f; }             // c2r ignores the imaginary parts of the DC and Nyquist bins
+            float2 cj = dc ? S[8] : buf[a_rev - 72 * r];       // lane 0 holds the Nyquist bin itself
+            if (dc) { a.y = 0.f; cj.y = 0.f; }                 // c2r ignores the imaginary parts of the DC and Nyquist bins
             cj.y = -cj.y;                                      // conj(S[512 - k])
             const float2 w = tw2[k];                           // e^{-2 pi i k/1024}; need e^{+...}
             const float2 d = csub(a, cj);

@@ -226,47 +226,17 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[mt][q] = 0.f;
 
-    // Streams the k-groups MAP(s), s in [S_BEGIN, S_END), of this wave through the MFMAs, DEPTH groups in flight.
-    // XLOAD(mt, kg) loads the x fragment of k-group kg.
-#define SK_STREAM(S_BEGIN, S_END, MAP, XLOAD)                                                            \
-    if ((S_BEGIN) < (S_END)) {                                                                            \
-        float4 wv[DEPTH], xv[MT][DEPTH];                                                                  \
-        const int s_last = (S_END) - 1;                                                                   \
-        _Pragma("unroll") for (int u = 0; u < DEPTH; ++u) SK_LOAD(u, (S_BEGIN) + u, MAP, XLOAD)           \
-        int base = (S_BEGIN);                                                                             \
-        /* steady state: every slot is valid and so is its refill -> branch-free body, counted waits */   \
-        for (; base + 2 * DEPTH <= (S_END); base += DEPTH) {                                              \
-            _Pragma("unroll") for (int u = 0; u < DEPTH; ++u) {                                           \
-                SK_MFMA(u)                                                                                \
-                SK_LOAD(u, base + u + DEPTH, MAP, XLOAD)                                                  \
-                /* keep the refill right behind the MFMAs that freed its registers: left alone, the   */  \
-                /* scheduler sinks all refills to the end of the pass and the wave drains to vmcnt(0) */  \
-                __builtin_amdgcn_sched_barrier(0);                                                        \
-            }                                                                                             \
-        }                                                                                                 \
-        /* drain.  The slots hold the next min(remaining, DEPTH) groups and remaining < 2*DEPTH.  Only */ \
-        /* when more than DEPTH groups are left is there anything to refill: that pass is branch free  */ \
-        /* (every slot valid, refills are clamped loads; the few surplus ones re-read the last group   */ \
-        /* and are never consumed).  The final pass issues no loads and only guards the MFMAs.         */ \
-        int rem = (S_END) - base;                                                                         \
-        if (rem > DEPTH) {                                                                                \
-            _Pragma("unroll") for (int u = 0; u < DEPTH; ++u) {                                           \
-                SK_MFMA(u)                                                                                \
-                SK_LOAD(u, base + u + DEPTH, MAP, XLOAD)                                                  \
-                __builtin_amdgcn_sched_barrier(0);                                                        \
-            }                                                                                             \
-            rem -= DEPTH;                                                                                 \
-        }                                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < DEPTH; ++u) {                                               \
-            if (u < rem) SK_MFMA(u)                                                                       \
-        }                                                                                                 \
-    }
-#define SK_LOAD(slot, ss, MAP, XLOAD)                                                             \
+    if (kg_begin < kg_end) {
+        float4 wv[DEPTH], xv[MT][DEPTH];
+        const int g_last = kg_end - 1;
+#define SK_LOAD(slot, gg)                                                                         \
         {                                                                                             \
-            const int s_ = min((ss), s_last);                                                         \
-            const int g_ = MAP(s_);                                                                   \
+            const int g_ = min((gg), g_last);                                                         \
             wv[slot] = wp[(long)g_ * 64];                                                            \
-            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xv[mt][slot] = XLOAD(mt, g_);           \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                       \
+                const float* base_ = g_ < g0 ? xb0[mt] : (g_ < g1 ? xb1[mt] : xb2[mt]);               \
+                xv[mt][slot] = *reinterpret_cast<const float4*>(base_ + (long)g_ * blk);              \
+            }                                                                                         \
         }
 #define SK_MFMA(slot)                                                                                  \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                               \
@@ -275,47 +245,41 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].z, xv[mt][slot].z, acc[mt], 0, 0, 0); \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].w, xv[mt][slot].w, acc[mt], 0, 0, 0); \
         }
-#define SK_X_PLAIN(mt, g) (*reinterpret_cast<const float4*>(((g) < g0 ? xb0[mt] : ((g) < g1 ? xb1[mt] : xb2[mt])) + (long)(g) * blk))
-#define SK_MAP_ID(s) (s)
-    if (!J.defer_seg) {
-        SK_STREAM(kg_begin, kg_end, SK_MAP_ID, SK_X_PLAIN)
-    } else {
-        // Deferred segment (teacher-forced decoder: x[1] is the attention context of the previous step, which the persistent
-        // attention kernel publishes while this launch is already streaming): every wave first takes its share of the
-        // k-groups of x[0] and x[2], then - once the context counter has reached its target - its share of x[1]'s.
-        const int nc = g1 - g0, nn = J.nkg - nc;
-        const int per_n = (nn + SK_WAVES - 1) / SK_WAVES, per_c = (nc + SK_WAVES - 1) / SK_WAVES;
-        const int n_begin = min(nn, wave * per_n), n_end = min(nn, n_begin + per_n);
-        const int c_begin = min(nc, wave * per_c), c_end = min(nc, c_begin + per_c);
-#define SK_MAP_N(s) ((s) < g0 ? (s) : (s) + nc)
-#define SK_MAP_C(s) ((s) + g0)
-        SK_STREAM(n_begin, n_end, SK_MAP_N, SK_X_PLAIN)
-        if (J.ctx_cnt) {
-            // every wave polls for itself (one request per wave) and reads the context with sc1 loads only: the bytes were
-            // stored write-through by another kernel, a plain load could be served from a stale L1 / L2 line
-            handoff_wait(J.ctx_cnt, J.ctx_target, J.tmo, 0x200u);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the compiler from moving the loads above the poll
-            const __amdgpu_buffer_rsrc_t rx = make_rsrc(J.x[1].p);
-            unsigned xo[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int b = mt * 32 + bl;
-                xo[mt] = (unsigned)((b < B ? b : 0) * 8 + 4 * h) * 4u;
+        for (int u = 0; u < DEPTH; ++u) SK_LOAD(u, kg_begin + u)
+        int base = kg_begin;
+        // steady state: every slot is valid and so is its refill -> branch-free body, counted waits
+        for (; base + 2 * DEPTH <= kg_end; base += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                SK_MFMA(u)
+                SK_LOAD(u, base + u + DEPTH)
+                // keep the refill right behind the MFMAs that freed its registers: left alone, the scheduler sinks
+                // all refills to the end of the pass and the wave drains to vmcnt(0) every DEPTH groups
+                __builtin_amdgcn_sched_barrier(0);
             }
-#define SK_X_SC1(mt, g) load_sc1(rx, xo[mt] + (unsigned)((g) - g0) * (unsigned)(blk * 4))
-            SK_STREAM(c_begin, c_end, SK_MAP_C, SK_X_SC1)
-#undef SK_X_SC1
-        } else {
-            SK_STREAM(c_begin, c_end, SK_MAP_C, SK_X_PLAIN)
         }
-#undef SK_MAP_N
-#undef SK_MAP_C
-    }
-#undef SK_MAP_ID
-#undef SK_X_PLAIN
+        // drain.  The slots hold the next min(remaining, DEPTH) groups and remaining < 2*DEPTH.  Only when more than
+        // DEPTH groups are left is there anything to refill: that pass is branch free (every slot valid, refills are
+        // clamped loads; the few surplus ones re-read the last group and are never consumed).  The final pass issues
+        // no loads and only guards the MFMAs (wave-uniform).
+        int rem = kg_end - base;
+        if (rem > DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                SK_MFMA(u)
+                SK_LOAD(u, base + u + DEPTH)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rem -= DEPTH;
+        }
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            if (u < rem) SK_MFMA(u)
+        }
 #undef SK_MFMA
 #undef SK_LOAD
-#undef SK_STREAM
+    }
 
     GVX_STAMP(0, 1);
 #ifdef GVX_STAMPS
@@ -405,7 +369,8 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         __syncthreads();
         const int a = J.att_dim;
         const float* wq = J.Wq_t + (long)tile * a * 8;
-        auto slab_value = [&](int b, int d) -> float {
+        for (int idx = tid; idx < B * a; idx += SK_THREADS) {
+            const int b = idx / a, d = idx - b * a;
             const float4 w0 = *reinterpret_cast<const float4*>(wq + d * 8);
             const float4 w1 = *reinterpret_cast<const float4*>(wq + d * 8 + 4);
             const float4 h0 = *reinterpret_cast<const float4*>(hs + b * 8);
@@ -413,28 +378,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             float v = w0.x * h0.x;
             v = fmaf(w0.y, h0.y, v); v = fmaf(w0.z, h0.z, v); v = fmaf(w0.w, h0.w, v);
             v = fmaf(w1.x, h1.x, v); v = fmaf(w1.y, h1.y, v); v = fmaf(w1.z, h1.z, v); v = fmaf(w1.w, h1.w, v);
-            return v;
-        };
-        if (J.q_cnt) {
-            // consumed by the persistent attention kernel while it runs: write-through 16-byte stores, drained, one add
-            const __amdgpu_buffer_rsrc_t rq = make_rsrc(J.q_slab);
-            const int a4 = a >> 2;
-            for (int idx = tid; idx < B * a4; idx += SK_THREADS) {
-                const int b = idx / a4, d = 4 * (idx - b * a4);
-                store_sc1(rq, (unsigned)(((long)tile * B + b) * a + d) * 4u,
-                          make_float4(slab_value(b, d), slab_value(b, d + 1), slab_value(b, d + 2), slab_value(b, d + 3)));
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                if (J.ready_cnt) handoff_wait(J.ready_cnt, J.ready_target, J.tmo, 0x300u);
-                __hip_atomic_fetch_add(J.q_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            for (int idx = tid; idx < B * a; idx += SK_THREADS) {
-                const int b = idx / a, d = idx - b * a;
-                J.q_slab[((long)tile * B + b) * a + d] = slab_value(b, d);
-            }
+            J.q_slab[((long)tile * B + b) * a + d] = v;
         }
     }
     GVX_STAMP(0, 4);

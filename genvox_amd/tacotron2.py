@@ -199,15 +199,12 @@ class Tacotron2(nn.Module):
         id outside the embedding table, which is what nn.Embedding does in the reference (models/tts/tacotron2.py:459).
         Not called by forward(): one check after a batch of calls is enough."""
         out = (C.c_int32 * 2)()
-        bad = stalled = False
+        bad = False
         for ws in [self._workspace] + self._lane_ws:
             if ws is None:
                 continue
             _lib.check(_lib.load().gvx_workspace_status(self._handle, ws.data_ptr(), ws.numel(), self._stream(), out))
             bad |= bool(out[0])
-            stalled |= bool(out[1])
-        if stalled:
-            raise RuntimeError("genvox_amd: an in-launch hand-off of the decoder loop timed out; the last outputs are invalid")
         if bad:
             raise IndexError("genvox_amd: token id outside [0, n_tokens)")
 
@@ -293,15 +290,9 @@ class Tacotron2(nn.Module):
         cur = torch.cuda.current_stream(dev)
         for lane in streams:
             lane.wait_stream(cur)
-        # one handle, two streams at once: the attention runs as a launch per step here (the resident attention kernel of
-        # the single-stream path owns the handle's side stream for a whole loop)
-        _lib.check(lib.gvx_model_set_persistent_attention(self._handle, 0))
-        try:
-            for ci, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
-                with torch.cuda.stream(streams[ci % 2]):
-                    run(lo, hi, wss[ci % 2])
-        finally:
-            _lib.check(lib.gvx_model_set_persistent_attention(self._handle, 1))
+        for ci, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
+            with torch.cuda.stream(streams[ci % 2]):
+                run(lo, hi, wss[ci % 2])
         for lane in streams:
             cur.wait_stream(lane)
         return out

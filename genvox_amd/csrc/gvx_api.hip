@@ -767,9 +767,10 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     if (rc != GVX_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(m->ev[2], s));
     // ---- T decoder steps.  Launch 1 of step t: attention-LSTM(t) together with decoder-LSTM(t-1), which is off
-    // the critical chain (only the next step's projection needs it).  Launches 2, 3: attention energies / context.
+    // the critical chain (only the next step's projection needs it).  Launch 2: the attention step (energies, softmax, context;
+    // GVX_ATTN_SPLIT=1: the round-1 energy + context pair).
     // The loop only touches workspace operands (alignments go to a time-major workspace buffer, the lengths are
-    // copied in), so its 3T+1 launches are captured once per (workspace, shape) into a hipGraph and replayed.
+    // copied in), so its 2T+1 launches are captured once per (workspace, weight blob, shape) into a hipGraph and replayed.
     const int32_t* len_ws = nullptr;
     if (lengths) {
         HIP_TRY(hipMemcpyAsync(db.len_copy, lengths, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));

@@ -30,9 +30,9 @@ from .weights import state_dict_spec
 
 MAX_CALL_BATCH = 64   # rows per C-ABI call of the recurrent entry points
 STREAM_ROWS = 32      # teacher-forced batches above this are cut into chunks of at most this many rows that run on two HIP
-                      # streams at once: a decoder step is one chip-wide weight-streaming launch followed by two small
-                      # latency-bound attention launches, so a second independent batch fills the attention gaps of the first
-                      # (measured: 64 rows as 2 x 32 concurrently 38 ms, as one 64-row call 43.5 ms)
+                      # streams at once: a decoder step is one chip-wide weight-streaming launch followed by a small
+                      # latency-bound attention launch, so a second independent batch fills the attention gaps of the first
+                      # (measured: 64 rows as 2 x 32 concurrently 40.6 ms, as one 64-row call 43.5 ms)
 
 _GAIN = {"linear": "linear", "sigmoid": "sigmoid", "tanh": "tanh", "relu": "relu"}
 

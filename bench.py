@@ -43,15 +43,16 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~63
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (same guide): v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
 
 
-def algorithmic_bytes_lstm_launch(mc, B, L):
+def algorithmic_bytes_lstm_launch(mc, B, L, persistent=False):
     """Bytes one decoder LSTM-step launch must move: both recurrent matrices and biases once, the
-    x rows, cell state read+write, new hidden states, attention-query partial slabs, and - since the launch also
-    produces the next attention step's location features - the two weight rows read and L*a features written per row."""
+    x rows, cell state read+write, new hidden states, attention-query partial slabs, and - when the launch also
+    produces the next attention step's location features - the two weight rows read and L*a features written per row.
+    persistent: the launch beside the persistent attention kernel (96 slabs, no location features)."""
     P, E, A, D, a = mc.prenet_dim, mc.encoder_embedding_dim, mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.attention_dim
     weights = 4 * A * (P + E + A) + 4 * D * (A + E + D) + 4 * A + 4 * D
     per_row = (P + E + A) + (A + E + D) + 2 * (A + D) + (A + D)
-    slabs = (A // 8) * a
-    loc = 2 * L + L * a
+    slabs = (96 if persistent else A // 8) * a
+    loc = 0 if persistent else 2 * L + L * a
     return 4 * (weights + B * (per_row + slabs + loc))
 
 
@@ -203,13 +204,16 @@ def main():
         torch.cuda.synchronize()
         kt = m.kernel_times_ms()
         m.enable_kernel_timing(False)
-        alg = algorithmic_bytes_lstm_launch(mc, b, L)
+        persistent = kt["attention_step"] == 0.0   # the attention ran as one kernel beside the loop (B <= 32, default sizes)
+        alg = algorithmic_bytes_lstm_launch(mc, b, L, persistent)
         sec = kt["decoder_lstm_step"] * 1e-3
         gbs, tfl = alg / sec / 1e9, flops_lstm_launch(mc, b) / sec / 1e12
-        return {"bound": "hbm", "kernel": f"decoder_lstm_step_kernel<{2 if b > 32 else 1}>", "achieved": round(gbs, 1),
+        return {"bound": "hbm", "kernel": "decoder_lstm_step_pa_kernel" if persistent else f"decoder_lstm_step_kernel<{2 if b > 32 else 1}>",
+                "achieved": round(gbs, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(kt["decoder_lstm_step"] * 1e3, 2),
-                "attention_launch_us": round(kt["attention_step"] * 1e3, 2),
+                "attention": "attn_persistent_kernel (one launch per decoder loop, 32 CUs)" if persistent else "attn_step_kernel per step",
+                "attention_launch_us": None if persistent else round(kt["attention_step"] * 1e3, 2),
                 "mfma_tflops": round(tfl, 1), "mfma_frac_of_157TF": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                 "decoder_step_us": round(loop_ms * 1e3 / T, 2),
                 "decoder_step_GBs_survey_8d": round(algorithmic_bytes_decoder_step(mc, b, L) * T / (loop_ms * 1e-3) / 1e9, 1)}

@@ -1,0 +1,313 @@
+// Location-sensitive attention of the teacher-forced decoder loop as ONE kernel that lives for the whole loop
+// (models/tts/tacotron2.py:243-262 Attention.forward, :317-348 Decoder.decode).
+//
+// Why: per step the attention reads, for one batch row, the encoder memory (L x E, 256 KB), the processed memory
+// (L x a, 64 KB), the location features (64 KB) and the query partial sums (64 KB).  All but the last are either constant
+// over the decode or produced by the attention itself, yet a per-step launch has to fetch them again through a fabric that
+// the LSTM weight stream saturates (measured: 7-8 us per launch on the step's critical chain, 11-14 us when run beside
+// the stream).  Here one workgroup per batch row keeps the row's memory (64 VGPRs x 1024 threads) and processed memory
+// (16 VGPRs) in registers and its location features in LDS for all T steps; per step it only receives the 64 KB of query
+// partial sums from the attention-LSTM tiles and publishes 2 KB of context.  It runs BESIDE the LSTM launches (on CUs of
+// its own, 32 of 256), so the chain  slabs(t) -> energies -> softmax -> context(t)  overlaps the next launch's streaming of
+// the weight columns that do not depend on the context; that launch waits for context(t) just before its context columns
+// (skinny.hip, deferred segment).
+//
+// Hand-offs between the two kernels follow cdna_hip_programming.md section 6 guideline 16 / MI355X_MICROARCH.md
+// "inter-workgroup visibility" (per-XCD L2s are not coherent):
+//   * payload (query slabs, context) is stored write-through (`sc1` 16-byte buffer stores), every storing wave drains
+//     (`s_waitcnt vmcnt(0)`), the workgroup meets at a barrier, ONE lane adds to an agent-scope counter;
+//   * the consumer polls that counter with `sc1` loads (one lane, bounded spin), meets at a barrier, and reads the payload
+//     with `sc1` 16-byte buffer loads only (never plain loads: L1 / L2 may hold last step's lines).
+// Every spin is bounded: on a timeout the waiter raises the workspace's hand-off status word and every later wait returns
+// at once, so both kernels drain (with wrong results, which gvx_workspace_status reports) instead of hanging the GPU.
+#include "gvx_kernels.h"
+
+namespace gvx {
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int PA_THREADS = 1024;
+constexpr int PA_A = 128;      // attention dim
+constexpr int PA_E = 512;      // encoder embedding dim
+constexpr int PA_L = 128;      // positions held per row
+constexpr int PA_FB_S = 36;    // LDS row stride of the conv output [l][32 filters] (+4: conflict-free float4 rows)
+constexpr int PA_KL_MAX = 31;
+constexpr int PA_SLABS = 96;   // workgroups of the attention LSTM in the launch's layout (skinny.hip): one query slab each
+constexpr int PA_WC_S = PA_L + 32;   // stride of the two halo-padded weight rows (prev, cum); taps are padded to 32
+
+// LDS layout (floats)
+constexpr int PA_OFF_LOC = 0;                                  // [128][128] location features, float4 groups swizzled by (l & 1)
+constexpr int PA_OFF_FB = PA_OFF_LOC + PA_L * PA_A;            // [128][36]
+constexpr int PA_OFF_CW = PA_OFF_FB + PA_L * PA_FB_S;          // [2][32][32] conv weights, taps zero-padded to 32
+constexpr int PA_OFF_WD = PA_OFF_CW + 2 * 32 * 32;             // [8][128][4] dense weights
+constexpr int PA_OFF_WC = PA_OFF_WD + 32 * PA_A;               // [2][PA_WC_S]
+constexpr int PA_OFF_QP = PA_OFF_WC + 2 * PA_WC_S;             // [32][128] query partial sums
+constexpr int PA_OFF_QS = PA_OFF_QP + 32 * PA_A;               // [128] query
+constexpr int PA_OFF_ES = PA_OFF_QS + PA_A;                    // [128] energies
+constexpr int PA_OFF_V = PA_OFF_ES + PA_L;                     // [128] v
+constexpr int PA_OFF_CP = PA_OFF_V + PA_A;                     // [8][512] context partial sums
+constexpr int PA_LDS_FLOATS = PA_OFF_CP + 8 * PA_E;
+static_assert(PA_LDS_FLOATS * 4 <= 160 * 1024, "persistent attention LDS");
+static_assert((PA_OFF_FB % 4) == 0 && (PA_OFF_CW % 4) == 0 && (PA_OFF_WD % 4) == 0 && (PA_OFF_QP % 4) == 0 && (PA_OFF_QS % 4) == 0 &&
+              (PA_OFF_V % 4) == 0 && (PA_OFF_CP % 4) == 0, "float4 alignment");
+
+__device__ __forceinline__ float fast_tanh(float x) {   // as attention.hip
+    const float e = __expf(2.f * x);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_get<0xB1>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = sum8(v);
+    v += dpp_get<0x140>(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_get<0xB1>(v));
+    v = fmaxf(v, dpp_get<0x4E>(v));
+    v = fmaxf(v, dpp_get<0x141>(v));
+    v = fmaxf(v, dpp_get<0x140>(v));
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersistParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* locf = smem + PA_OFF_LOC;
+    float* fb = smem + PA_OFF_FB;
+    float* cw = smem + PA_OFF_CW;
+    float* wdl = smem + PA_OFF_WD;
+    float* wc = smem + PA_OFF_WC;
+    float* qp = smem + PA_OFF_QP;
+    float* qs = smem + PA_OFF_QS;
+    float* es = smem + PA_OFF_ES;
+    float* vl = smem + PA_OFF_V;
+    float* cp = smem + PA_OFF_CP;
+
+    const int b = blockIdx.x, B = p.B, L = p.L, kl = p.kl, pad = (kl - 1) / 2;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int len = p.lengths ? p.lengths[b] : L;
+    unsigned* const cnt_q = p.sync + HANDOFF_CNT_Q;
+    unsigned* const cnt_ctx = p.sync + HANDOFF_CNT_CTX;
+    unsigned* const tmo = p.sync + HANDOFF_TIMEOUT;
+    if (tid == 0) __hip_atomic_fetch_add(p.sync + HANDOFF_READY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident
+
+    // ---- resident operands
+    // memory: thread (e4 = float4 column, lg = group of 16 positions) holds memory[b][16 lg + i][e4], i < 16
+    float4 mem[16];
+    {
+        const int e4 = tid & 127, lg = tid >> 7;
+        const float4* mb = reinterpret_cast<const float4*>(p.memory) + (long)b * L * (PA_E / 4);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mem[i] = mb[(long)min(16 * lg + i, L - 1) * (PA_E / 4) + e4];
+    }
+    // processed memory: thread (l = position, dg) holds the float4 groups dg + 8 j of pm[b][l]
+    float4 pmr[4];
+    {
+        const int el = tid >> 3, dg = tid & 7;
+        const float4* pb = reinterpret_cast<const float4*>(p.pm) + ((long)b * L + min(el, L - 1)) * (PA_A / 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pmr[j] = pb[dg + 8 * j];
+    }
+    for (int i = tid; i < 2 * 32 * 32; i += PA_THREADS) {   // conv weights [2][kl][32] -> [2][32][32], missing taps are zero
+        const int ch = i >> 10, k = (i >> 5) & 31, f = i & 31;
+        cw[i] = k < kl ? p.loc_conv_t[(ch * kl + k) * 32 + f] : 0.f;
+    }
+    for (int i = tid; i < 32 * PA_A / 4; i += PA_THREADS) reinterpret_cast<float4*>(wdl)[i] = reinterpret_cast<const float4*>(p.loc_dense_t)[i];
+    if (tid < PA_A) vl[tid] = p.v[tid];
+    for (int i = tid; i < 2 * PA_WC_S; i += PA_THREADS) wc[i] = 0.f;
+    __syncthreads();
+
+    // location features of the next step from the previous / cumulative weights in wc, on the MFMA units:
+    //   conv   C[f][l] = sum_kk Wc[f][kk] X[kk][l],  kk = 32 ch + k, X[kk][l] = wc[ch][l + k]   (4 position tiles, K = 64)
+    //   dense  D[d][l] = sum_f  Wd[d][f]  C[f][l]                                               (4 x 4 tiles, K = 32)
+    // v_mfma_f32_32x32x2_f32: A lane (i = lane & 31, kh = lane >> 5) gives A[i][kh], B lane (j, kh) gives B[kh][j], and lane
+    // (j, h) receives D[8 g + 4 h + r][j] in accumulator 4 g + r.  (As VALU loops this phase took 9.5 us per step.)
+    auto location_features = [&]() {
+        // (per-thread indices are recomputed from an opaque copy of the thread id in every phase of the step loop: hoisted out
+        // of the loop they would sit in registers the resident operands need)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lj = tq & 31, kh = (tq >> 5) & 1;
+        if (wave < 4) {   // conv: one position tile per wave
+            const int l0 = 32 * wave;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll 8
+            for (int s = 0; s < 32; ++s) {
+                const int kk = 2 * s + kh, ch = kk >> 5, k = kk & 31;
+                const float av = cw[(ch * 32 + k) * 32 + lj];
+                const float bv = wc[ch * PA_WC_S + l0 + lj + k];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(fb + (l0 + lj) * PA_FB_S + 8 * g + 4 * kh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+        __syncthreads();
+        {   // dense: wave -> (d tile = wave & 3, position tile = wave >> 2)
+            const int d0 = 32 * (wave & 3), l = 32 * (wave >> 2) + lj;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll 8
+            for (int s = 0; s < 16; ++s) {
+                const int f = 2 * s + kh;
+                const float av = wdl[((f >> 2) * PA_A + d0 + lj) * 4 + (f & 3)];
+                const float bv = fb[l * PA_FB_S + f];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int g4 = (d0 + 8 * g + 4 * kh) >> 2;
+                reinterpret_cast<float4*>(locf)[l * (PA_A / 4) + (g4 ^ ((l & 1) << 3))] =
+                    make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            }
+        }
+        __syncthreads();
+    };
+    location_features();   // step 0: zero weights
+
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q_slab);
+#ifdef GVX_STAMPS
+#define PA_STAMP(i) do { if (t == 20) GVX_STAMP(0, i); } while (0)
+#else
+#define PA_STAMP(i) do { } while (0)
+#endif
+    for (int t = 0; t < p.T; ++t) {
+        PA_STAMP(0);
+        // ---- query: the slabs of step t are plain stores of launch t; launch t + 1 (or the drain launch) adds 1 to the counter
+        // when it STARTS, i.e. after launch t has completed and its stores have been written back (count t + 2: launch 0
+        // adds too).  Then sum the partial slabs (fixed order)
+        if (tid == 0) handoff_wait(cnt_q, (unsigned)(t + 2), tmo, 0x100u + (unsigned)b);
+        __syncthreads();
+        PA_STAMP(1);
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lane = tq & 63, e4 = tq & 127, lg = tq >> 7, el = tq >> 3, dg = tq & 7;
+        {
+            const int d4 = tq & 31, sg = tq >> 5;   // slabs 3 sg .. 3 sg + 2 (96 workgroups of the attention LSTM, one slab each)
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 ql[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ql[i] = load_sc1(rq, (unsigned)(((3 * sg + i) * B + b) * PA_A + 4 * d4) * 4u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { s4.x += ql[i].x; s4.y += ql[i].y; s4.z += ql[i].z; s4.w += ql[i].w; }
+            reinterpret_cast<float4*>(qp)[sg * 32 + d4] = s4;
+        }
+        __syncthreads();
+        if (tq < PA_A) {
+            float acc = qp[tq];
+#pragma unroll 8
+            for (int g = 1; g < 32; ++g) acc += qp[g * PA_A + tq];
+            qs[tq] = acc;
+        }
+        __syncthreads();
+        PA_STAMP(2);
+        // ---- energies: e[l] = v . tanh(q + (loc[l] + pm[l]))   (8 lanes per position, DPP sum)
+        {
+            float pe = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g4 = dg + 8 * j;
+                const float4 qv = reinterpret_cast<const float4*>(qs)[g4];
+                const float4 vv = reinterpret_cast<const float4*>(vl)[g4];
+                const float4 lv = reinterpret_cast<const float4*>(locf)[el * (PA_A / 4) + (g4 ^ ((el & 1) << 3))];
+                pe = fmaf(vv.x, fast_tanh(qv.x + (lv.x + pmr[j].x)), pe);
+                pe = fmaf(vv.y, fast_tanh(qv.y + (lv.y + pmr[j].y)), pe);
+                pe = fmaf(vv.z, fast_tanh(qv.z + (lv.z + pmr[j].z)), pe);
+                pe = fmaf(vv.w, fast_tanh(qv.w + (lv.w + pmr[j].w)), pe);
+            }
+            pe = sum8(pe);
+            if (dg == 0) es[el] = el < len ? pe : -INFINITY;
+        }
+        __syncthreads();
+        PA_STAMP(3);
+        // ---- masked softmax (every wave computes the normaliser) and this thread's share of the context
+        float mx = -INFINITY;
+        for (int l = lane; l < L; l += 64) mx = fmaxf(mx, es[l]);
+        mx = wave_max_dpp(mx);
+        float sum = 0.f;
+        for (int l = lane; l < L; l += 64) sum += __expf(es[l] - mx);
+        sum = wave_sum_dpp(sum);
+        const float inv = 1.f / sum;
+        {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int l = 16 * lg + i;
+                const float w = l < L ? __expf(es[l] - mx) * inv : 0.f;   // exactly 0 past the row's length (exp(-inf))
+                acc.x = fmaf(w, mem[i].x, acc.x); acc.y = fmaf(w, mem[i].y, acc.y);
+                acc.z = fmaf(w, mem[i].z, acc.z); acc.w = fmaf(w, mem[i].w, acc.w);
+            }
+            reinterpret_cast<float4*>(cp)[lg * 128 + e4] = acc;
+        }
+        if (wave == 0) {   // alignment row out; previous / cumulative weights for the next location features
+            for (int l = lane; l < L; l += 64) {
+                const float w = __expf(es[l] - mx) * inv;
+                p.w_out[(long)t * p.w_out_ts + (long)b * p.w_out_bs + l] = w;
+                wc[pad + l] = w;
+                wc[PA_WC_S + pad + l] += w;
+            }
+        }
+        __syncthreads();
+        PA_STAMP(4);
+        if (tq < 128) {
+            float4 o = reinterpret_cast<const float4*>(cp)[tq];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) {
+                const float4 x = reinterpret_cast<const float4*>(cp)[g * 128 + tq];
+                o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w;
+            }
+            // blocked context vector [E/8][B][8] of step t, write-through
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.ctx_base + (long)t * p.ctx_ts);
+            store_sc1(rc, (unsigned)((tq >> 1) * B * 8 + b * 8 + 4 * (tq & 1)) * 4u, o);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt_ctx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PA_STAMP(5);
+        // ---- off the chain: location features of step t + 1
+        if (t + 1 < p.T) location_features();
+        PA_STAMP(6);
+    }
+}
+
+bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, int att_rnn_dim, int dec_rnn_dim) {
+    // default layer sizes only: the launch layout (skinny.hip) deals 128 + 128 tiles to 224 workgroups
+    return B >= 1 && B <= 32 && L >= 1 && L <= PA_L && a == PA_A && E == PA_E && F >= 1 && F <= 32 && kl >= 1 && kl <= PA_KL_MAX &&
+           (kl & 1) && att_rnn_dim == 1024 && dec_rnn_dim == 1024;
+}
+int attention_persistent_slabs() { return PA_SLABS; }
+
+hipError_t attention_persistent_init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PA_LDS_FLOATS * (int)sizeof(float));
+}
+
+#ifdef GVX_STAMPS
+hipError_t read_stamps_persist(unsigned long long* host96) {
+    return hipMemcpyFromSymbol(host96, HIP_SYMBOL(gvx_stamps), sizeof(unsigned long long) * 96);
+}
+#endif
+
+hipError_t launch_attention_persistent(const AttnPersistParams& p, hipStream_t s) {
+    if (!attention_persistent_supported(p.B, p.L, PA_A, 32, p.kl, PA_E, 1024, 1024) || p.n_slabs != PA_SLABS || p.T < 1) return hipErrorInvalidValue;
+    attn_persistent_kernel<<<dim3(p.B), dim3(PA_THREADS), PA_LDS_FLOATS * sizeof(float), s>>>(p);
+    return hipGetLastError();
+}
+
+}  // namespace gvx

@@ -29,11 +29,13 @@ namespace gvx {
 #ifdef GVX_STAMPS
 hipError_t read_stamps_skinny(unsigned long long* host96);
 hipError_t read_stamps_attention(unsigned long long* host96);
+hipError_t read_stamps_persist(unsigned long long* host96);
 hipError_t read_wg_spans(unsigned long long* host1024);
 #endif
 hipError_t skinny_init();
 hipError_t gemm_init();
 hipError_t attention_init();
+hipError_t attention_persistent_init();
 }  // namespace gvx
 
 using namespace gvx;
@@ -84,7 +86,7 @@ struct Blob {  // offsets in floats into the packed weight blob
 inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 8) * 64 * 4; }
 
 struct WsPlan {  // byte offsets into the caller's workspace
-    size_t xa, xb, xg, enc_h, enc_c, flags, memory;
+    size_t xa, xb, xg, enc_h, enc_c, flags, sync, memory;
     size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy, loc, ar_masks, p_slab, p_ctx;
     size_t att_part, dec_part;
     size_t ya, yb;
@@ -106,9 +108,10 @@ struct gvx_model {
     struct LoopKey {
         const void* ws; const void* memory; const void* blob; int B, L, T; bool has_len;
         float threshold = 0.f;   // autoregressive graphs only
+        int variant = 0;         // teacher-forced loop: 1 = with the persistent attention kernel
         bool operator==(const LoopKey& o) const {
             return ws == o.ws && memory == o.memory && blob == o.blob && B == o.B && L == o.L && T == o.T &&
-                   has_len == o.has_len && threshold == o.threshold;
+                   has_len == o.has_len && threshold == o.threshold && variant == o.variant;
         }
     };
     // One entry per key: the graphs of its chunks (one for the encoder / teacher-forced loop, one per 16-step chunk of the
@@ -126,6 +129,11 @@ struct gvx_model {
     uint64_t use_clock = 0;
     bool capture_first = false;   // GVX_GRAPH_FIRST=1: capture at the first sighting (tests of the replay path)
     bool attn_one_launch = true;  // GVX_ATTN_SPLIT=1: energy + context as two launches (the round-1 step, kept for A/B runs)
+    // teacher-forced loop: attention as one kernel that lives beside the LSTM launches (attn_persist.hip) when the shape
+    // allows it; GVX_ATTN_PERSISTENT=0 keeps the launch per step
+    bool attn_persistent = true;
+    hipStream_t pa_stream = nullptr;
+    hipEvent_t pa_fork = nullptr, pa_join = nullptr;
     void drop_graphs() {
         for (auto* c : {&ar_graphs, &loop_graphs, &enc_graphs}) {
             for (auto& gs : *c)
@@ -197,6 +205,7 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
     // status words first, at a shape-independent offset (gvx_workspace_status)
     w.flags = take(128);  // [0] token error, [1] AR rows done, [64..64+B) AR frame counts
+    w.sync = take(HANDOFF_WORDS);   // hand-off words of the persistent attention kernel (zeroed before every decoder loop)
     w.xa = take((size_t)B * (L + 2 * pe) * E);
     w.xb = take((size_t)B * (L + 2 * pe) * E);
     w.xg = take((size_t)B * L * 8 * H);
@@ -385,6 +394,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     if (const char* e = std::getenv("GVX_NO_GRAPH")) m->use_graph = !(e[0] == '1');
     if (const char* e = std::getenv("GVX_GRAPH_FIRST")) m->capture_first = e[0] == '1';
     if (const char* e = std::getenv("GVX_ATTN_SPLIT")) m->attn_one_launch = !(e[0] == '1');
+    if (const char* e = std::getenv("GVX_ATTN_PERSISTENT")) m->attn_persistent = !(e[0] == '0');
     *out = m;
     return GVX_OK;
 }
@@ -396,6 +406,9 @@ void gvx_model_destroy(gvx_model* m) {
     for (auto& e : m->kev) (void)hipEventDestroy(e);
     m->drop_graphs();
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    if (m->pa_stream) (void)hipStreamDestroy(m->pa_stream);
+    if (m->pa_fork) (void)hipEventDestroy(m->pa_fork);
+    if (m->pa_join) (void)hipEventDestroy(m->pa_join);
     delete m;
 }
 
@@ -521,6 +534,7 @@ int gvx_model_bind_blob(gvx_model* m, const void* device_blob) {
     HIP_TRY(gemm_init());
     HIP_TRY(skinny_init());
     HIP_TRY(attention_init());
+    HIP_TRY(attention_persistent_init());
     return GVX_OK;
 }
 
@@ -743,6 +757,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, D = d.dec_rnn_dim;
     const DecoderBuffers db = decoder_buffers(ws, wp);
+    HIP_TRY(zero_async(ws_ptr<unsigned>(ws, wp.sync), HANDOFF_WORDS * sizeof(unsigned), s));   // hand-off status of THIS call
     const bool timed = m->timing && m->ev_valid;
     // ---- Prenet over all T+1 frames at once (models/tts/tacotron2.py:370-373)
     HIP_TRY(zero_async(db.frames, (size_t)B * M * sizeof(float), s));  // go-frame
@@ -783,11 +798,55 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         if (rc != GVX_OK) return rc;
         m->n_lstm_ev = m->n_attn_ev = 0;
     }
+    // Persistent attention (attn_persist.hip): the loop is then T + 1 LSTM launches on `st` and ONE attention kernel on a
+    // forked stream; the LSTM tiles stream the k-groups of the context last and wait for it in the launch.
+    const bool pa = m->attn_persistent && m->attn_one_launch &&
+                    attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, E, d.att_rnn_dim, d.dec_rnn_dim);
+    unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
+    if (pa && !m->pa_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&m->pa_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m->pa_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->pa_join, hipEventDisableTiming));
+    }
+    auto defer = [&](SkinnyJob& J, int t_ctx, bool first) {   // t_ctx: the step whose context the job's x[1] is
+        if (!pa) return;      // (the deferred k order costs the launch ~0.9 us: only where the context arrives in-launch)
+        J.defer_seg = 1;
+        J.tmo = sync + HANDOFF_TIMEOUT;
+        if (t_ctx >= 0) { J.ctx_cnt = sync + HANDOFF_CNT_CTX; J.ctx_target = (unsigned)B * (unsigned)(t_ctx + 1); }
+        J.start_cnt = sync + HANDOFF_CNT_Q;   // every launch of the loop (and the drain launch) announces its start
+        if (first) { J.ready_cnt = sync + HANDOFF_READY; J.ready_target = (unsigned)B; }
+    };
+    // The resident kernel is launched eagerly on the handle's side stream, ordered behind everything already queued on `s`;
+    // only the LSTM chain is replayed from a graph (a graph that contains both may run its branches one after the other -
+    // observed: the attention node first, waiting for slabs of launches queued behind it until its spin limit)
+    auto pa_begin = [&](hipStream_t st) -> int {
+        HIP_TRY(hipEventRecord(m->pa_fork, st));
+        HIP_TRY(hipStreamWaitEvent(m->pa_stream, m->pa_fork, 0));
+        AttnPersistParams pp{};
+        pp.q_slab = db.q_slab; pp.n_slabs = attention_persistent_slabs();
+        pp.v = m->dev_blob + m->blob.v; pp.pm = db.pm; pp.memory = memory; pp.lengths = len_ws;
+        pp.loc_conv_t = m->dev_blob + m->blob.loc_conv; pp.loc_dense_t = m->dev_blob + m->blob.loc_dense;
+        pp.w_out = db.align_tm; pp.w_out_bs = (long)L; pp.w_out_ts = (long)B * L;
+        pp.ctx_base = db.hc + (size_t)B * (D + E) + (size_t)D * B; pp.ctx_ts = (long)B * (D + E);   // slot t + 1
+        pp.sync = sync; pp.B = B; pp.L = L; pp.T = T; pp.kl = d.att_loc_kernel;
+        HIP_TRY(launch_attention_persistent(pp, m->pa_stream));
+        HIP_TRY(hipEventRecord(m->pa_join, m->pa_stream));
+        return GVX_OK;
+    };
     auto enqueue_loop = [&](hipStream_t st) -> int {
         for (int t = 0; t < T; ++t) {
             SkinnyJob jobs[2];
             fill_att_job(m, jobs[0], db.prenet + (size_t)t * B * P, t, B, db);
-            if (t > 0) fill_dec_job(m, jobs[1], t - 1, B, db);
+            defer(jobs[0], t - 1, t == 0);
+            if (t > 0) {
+                fill_dec_job(m, jobs[1], t - 1, B, db);
+                defer(jobs[1], t - 1, false);
+            }
+            if (pa) {
+                HIP_TRY(launch_skinny_pa(jobs[0], t > 0 ? &jobs[1] : nullptr, st));
+                ++launches;
+                continue;
+            }
             LocJob lq;
             fill_loc(m, lq, t, B, L, db.align_tm, (long)L, (long)B * L, db);
             HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, SK_DECODER, st, &lq));
@@ -798,18 +857,27 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         }
         SkinnyJob job;
         fill_dec_job(m, job, T - 1, B, db);
+        defer(job, T - 1, false);
         HIP_TRY(launch_skinny(&job, 1, SK_DECODER, st));
         ++launches;
         return GVX_OK;
     };
+    if (pa) {
+        rc = pa_begin(s);   // (the hand-off words were zeroed at the top of this call)
+        if (rc != GVX_OK) return rc;
+    }
     if (m->use_graph && !kt) {
-        const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr};
+        const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr, 0.f, pa ? 1 : 0};
         rc = run_chunk(m, touch_graph_set(m, m->loop_graphs, key), 0, s, enqueue_loop);
         if (rc != GVX_OK) return rc;
-        launches = (m->attn_one_launch ? 2 : 3) * T + 1;
+        launches = pa ? T + 1 : (m->attn_one_launch ? 2 : 3) * T + 1;
     } else {
         rc = enqueue_loop(s);
         if (rc != GVX_OK) return rc;
+    }
+    if (pa) {
+        HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));
+        ++launches;
     }
     if (kt) {
         // Per-kernel duration for the roofline figure: the launch of a mid-sequence step replayed back to back between
@@ -820,18 +888,33 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         SkinnyJob jobs[2];
         fill_att_job(m, jobs[0], db.prenet + (size_t)tm * B * P, tm, B, db);
         if (tm > 0) fill_dec_job(m, jobs[1], tm - 1, B, db);
-        LocJob lq;
-        fill_loc(m, lq, tm, B, L, db.align_tm, (long)L, (long)B * L, db);
-        AttnParams ap;
-        fill_attn(m, ap, memory, len_ws, tm, B, L, db.align_tm, (long)L, (long)B * L, db);
-        ap.w_out = db.energies;  // do not disturb the real alignments / cumulative weights (db.loc is an INPUT of the
-        ap.w_cum = db.energies;  // one-launch step: it must not be scribbled on)
-        HIP_TRY(hipEventRecord(m->kev[0], s));
-        for (int i = 0; i < REPS; ++i) HIP_TRY(launch_skinny(jobs, tm > 0 ? 2 : 1, SK_DECODER, s, &lq));
-        HIP_TRY(hipEventRecord(m->kev[1], s));
-        for (int i = 0; i < REPS; ++i) HIP_TRY(launch_attn(m, ap, s));
-        HIP_TRY(hipEventRecord(m->kev[2], s));
-        m->n_lstm_ev = m->n_attn_ev = REPS;
+        if (pa) {
+            // the launch of the loop as it ran: deferred context columns read with sc1 loads; the context counter already
+            // stands at its final value, so no replay waits (the attention runs in its own kernel: nothing to time per step)
+            HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));
+            defer(jobs[0], tm - 1, false);
+            if (tm > 0) defer(jobs[1], tm - 1, false);
+            jobs[0].start_cnt = jobs[1].start_cnt = nullptr;
+            HIP_TRY(hipEventRecord(m->kev[0], s));
+            for (int i = 0; i < REPS; ++i) HIP_TRY(launch_skinny_pa(jobs[0], tm > 0 ? &jobs[1] : nullptr, s));
+            HIP_TRY(hipEventRecord(m->kev[1], s));
+            HIP_TRY(hipEventRecord(m->kev[2], s));
+            m->n_lstm_ev = REPS;
+            m->n_attn_ev = 0;
+        } else {
+            LocJob lq;
+            fill_loc(m, lq, tm, B, L, db.align_tm, (long)L, (long)B * L, db);
+            AttnParams ap;
+            fill_attn(m, ap, memory, len_ws, tm, B, L, db.align_tm, (long)L, (long)B * L, db);
+            ap.w_out = db.energies;  // do not disturb the real alignments / cumulative weights (db.loc is an INPUT of the
+            ap.w_cum = db.energies;  // one-launch step: it must not be scribbled on)
+            HIP_TRY(hipEventRecord(m->kev[0], s));
+            for (int i = 0; i < REPS; ++i) HIP_TRY(launch_skinny(jobs, tm > 0 ? 2 : 1, SK_DECODER, s, &lq));
+            HIP_TRY(hipEventRecord(m->kev[1], s));
+            for (int i = 0; i < REPS; ++i) HIP_TRY(launch_attn(m, ap, s));
+            HIP_TRY(hipEventRecord(m->kev[2], s));
+            m->n_lstm_ev = m->n_attn_ev = REPS;
+        }
     }
     // alignments: time-major workspace [T][B][L] -> caller's [B][T][L]
     HIP_TRY(launch_permute01(db.align_tm, align_out, T, B, L, s));
@@ -891,7 +974,7 @@ PostnetPlan make_postnet_plan(const gvx_model* m, int B, int T) {
     const int pp = (d.postnet_kernel - 1) / 2, cmax = d.postnet_dim > d.n_mels ? d.postnet_dim : d.n_mels;
     const size_t buf = align_up((size_t)B * (T + 2 * pp) * cmax * sizeof(float), 256);
     PostnetPlan p;
-    p.ya = align_up(128 * sizeof(float), 256);   // behind the status words of the full plan
+    p.ya = align_up((128 + HANDOFF_WORDS) * sizeof(float), 256);   // behind the status and hand-off words of the full plan
     p.yb = p.ya + buf;
     p.total = p.yb + buf;
     return p;
@@ -902,15 +985,24 @@ PostnetPlan make_postnet_plan(const gvx_model* m, int B, int T) {
 // =====================================================================================================
 extern "C" {
 
+int gvx_model_set_persistent_attention(gvx_model* m, int enable) {
+    if (!m) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    m->attn_persistent = enable != 0;
+    return GVX_OK;
+}
+
 int gvx_workspace_status(const gvx_model* m, const void* ws, size_t ws_bytes, void* stream, int32_t* host_out) {
     if (!m || !ws || !host_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
     const WsPlan wp = make_ws_plan(m, 1, 1, 1);   // the status words sit in front of every shape-dependent region
     if (ws_bytes < wp.flags + sizeof(int32_t)) return fail(GVX_ERR_WORKSPACE, "workspace too small");
-    int32_t h = 0;
+    int32_t h = 0, tmo = 0;
     HIP_TRY(hipMemcpyAsync(&h, reinterpret_cast<const char*>(ws) + wp.flags, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (ws_bytes >= wp.sync + HANDOFF_WORDS * sizeof(unsigned))   // (a Postnet-only workspace ends before the hand-off words)
+        HIP_TRY(hipMemcpyAsync(&tmo, reinterpret_cast<const char*>(ws) + wp.sync + HANDOFF_TIMEOUT * sizeof(unsigned), sizeof tmo,
+                               hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     host_out[0] = h;
-    host_out[1] = 0;
+    host_out[1] = tmo;
     return GVX_OK;
 }
 
@@ -1025,7 +1117,7 @@ int gvx_kernel_times_ms(gvx_model* m, float* lstm_avg_ms, float* attn_avg_ms, in
     HIP_TRY(hipEventElapsedTime(&a, m->kev[0], m->kev[1]));
     HIP_TRY(hipEventElapsedTime(&b, m->kev[1], m->kev[2]));
     *lstm_avg_ms = a / m->n_lstm_ev;
-    *attn_avg_ms = b / m->n_attn_ev;
+    *attn_avg_ms = m->n_attn_ev > 0 ? b / m->n_attn_ev : 0.f;   // 0: the attention ran as one kernel beside the loop
     if (n_steps) *n_steps = m->n_lstm_ev;
     return GVX_OK;
 }
@@ -1052,6 +1144,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim, T = max_steps;
     const WsPlan wp = make_ws_plan(m, B, L, T);
     const DecoderBuffers db = decoder_buffers(ws, wp);
+    HIP_TRY(zero_async(ws_ptr<unsigned>(ws, wp.sync), HANDOFF_WORDS * sizeof(unsigned), s));   // hand-off status of THIS call
     const int PSB = m->PSB();
     int32_t* flags = ws_ptr<int32_t>(ws, wp.flags);
     int32_t* n_done = flags + 1;
@@ -1191,6 +1284,11 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
 int gvx_debug_read_stamps_skinny(unsigned long long* host96) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(gvx::read_stamps_skinny(host96));
+    return GVX_OK;
+}
+int gvx_debug_read_stamps_persist(unsigned long long* host96) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(gvx::read_stamps_persist(host96));
     return GVX_OK;
 }
 int gvx_debug_read_wg_spans(unsigned long long* host1024) {

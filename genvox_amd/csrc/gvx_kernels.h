@@ -87,6 +87,13 @@ struct SkinnyJob {
     // attention query partial products: slab[tile][b][a] = sum_{j in tile} Wq[a][j] * h'[b][j]
     const float* Wq_t;      // [H/8][att_dim][8] (tile-major repack of query_layer.weight) or nullptr
     float* q_slab; int att_dim;
+    // teacher-forced decoder with the persistent attention kernel (attn_persist.hip); all 0 / nullptr otherwise
+    int defer_seg;                  // 1: every wave streams its share of x[1]'s k-groups (the context) after its share of the others
+    const unsigned* ctx_cnt; unsigned ctx_target;   // wait for *ctx_cnt >= ctx_target before x[1]; x[1] is then read with sc1 loads
+    unsigned* start_cnt;            // block 0 adds 1 here when the launch starts: everything the previous launch of the stream
+                                    // stored (its query slabs) has been written back by then
+    const unsigned* ready_cnt; unsigned ready_target;   // a tile does not end before *ready_cnt >= ready_target (first launch)
+    unsigned* tmo;                  // hand-off status word
     // --- linear epilogue
     float* y;               // blocked output [ceil(N/8)][B][8]
     const uint8_t* keep; long keep_stride;  // keep[b*stride + n]
@@ -107,6 +114,9 @@ struct LocJob {
 };
 enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_AR = 2 };  // kernel name only; same code
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc = nullptr);
+// teacher-forced step beside the persistent attention kernel: attention-LSTM (+ decoder-LSTM of the previous step) dealt to
+// 96 (224) workgroups of equal weight (skinny.hip); default layer sizes, B <= 32
+hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Location-sensitive attention, one decoder step, split over G workgroups per batch row:
@@ -135,6 +145,64 @@ hipError_t launch_attention_step(const AttnParams& p, hipStream_t s);
 int attention_slices(int B, int E);
 int attention_groups(int B, int L);                                // G for a batch / length
 bool attention_supported(int L, int a, int F, int kl, int E);
+
+// ---------------------------------------------------------------------------------------------
+// Persistent attention of the teacher-forced loop (attn_persist.hip): one workgroup per batch row lives for all T steps
+// beside the LSTM launches; hand-off words live in a 512-byte block of the workspace that is zeroed before every loop.
+// ---------------------------------------------------------------------------------------------
+// word indices: 4 KB apart, so that the pollers of one word do not queue in front of another word's traffic at the same channel
+constexpr int HANDOFF_CNT_Q = 0, HANDOFF_CNT_CTX = 1024, HANDOFF_READY = 2048, HANDOFF_TIMEOUT = 3072;
+constexpr int HANDOFF_WORDS = 4096;
+constexpr unsigned HANDOFF_SPIN_LIMIT = 200000u;   // polls with ~2 us of s_sleep between them (a few hundred ms), then the wait gives up
+struct AttnPersistParams {
+    const float* q_slab; int n_slabs;       // [n_slabs][B][a], rewritten (sc1) by the attention-LSTM tiles every step
+    const float* v; const float* pm; const float* memory; const int32_t* lengths;
+    const float* loc_conv_t; const float* loc_dense_t;
+    float* w_out; long w_out_bs, w_out_ts;  // alignment row of (step t, row b) at w_out + t*ts + b*bs
+    float* ctx_base; long ctx_ts;           // blocked context vector [E/8][B][8] of step t at ctx_base + t*ctx_ts
+    unsigned* sync;                         // HANDOFF_WORDS words
+    int B, L, T, kl;
+};
+bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, int att_rnn_dim, int dec_rnn_dim);
+int attention_persistent_slabs();
+hipError_t attention_persistent_init();
+hipError_t launch_attention_persistent(const AttnPersistParams& p, hipStream_t s);
+
+#if defined(__HIPCC__)
+// write-through / L1-bypassing 16-byte accesses of handed-off bytes (aux 16 = sc1)
+typedef __attribute__((ext_vector_type(4))) unsigned gvx_u32x4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 load_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const gvx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+    gvx_u32x4 u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)byte_off, 0, 16);
+}
+// One lane waits until *cnt >= target.  Bounded; a timeout (or one raised by anybody else) makes every wait return at once.
+__device__ __forceinline__ bool handoff_wait(const unsigned* cnt, unsigned target, unsigned* tmo, unsigned code) {
+    // Normally the word is there at the first look.  A waiter that is early backs off (up to ~2 us between polls): a launch has
+    // ~1 800 waves that may wait on the same word, and their polls queue in front of the producer's own traffic.
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        ++spins;
+        if ((spins & 7u) == 1u) {   // (after a timeout every wait gives up at its first look)
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > HANDOFF_SPIN_LIMIT) {
+                __hip_atomic_store(tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        if (spins < 8u) __builtin_amdgcn_s_sleep(8);
+        else __builtin_amdgcn_s_sleep(64);
+    }
+    return true;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Small data-movement kernels.

@@ -50,6 +50,7 @@ struct SkinnyJobs {
     int tiles1;   // tiles of job 1
     int tiles;    // tiles of all jobs; blocks >= tiles are location-feature workgroups
     LocJob loc;
+    int pa_layout;   // teacher-forced step beside the persistent attention kernel: 224 (96) workgroups, see skinny_body
 };
 
 constexpr int LOC_LC = 32;   // positions per pass
@@ -158,19 +159,41 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 // resident in the 256-MiB Infinity Cache; non-temporal loads bypass it and were measured 16 % slower (round 1: 20.2 us vs
 // 17.4 us per decoder step).
 
-template <int MT, int DEPTH>
+// XH: the workgroup may carry an extra HALF tile (16 of another tile's 32 packed rows) through the same pass over x.
+// Layout of the teacher-forced launch beside the persistent attention kernel, which holds 32 CUs: a CU streams ~25 KB/us
+// whatever shares it, so the launch must have one workgroup per remaining CU and equal bytes per workgroup (measured with
+// tools/micro/partition_bench.hip: 256 tiles on 224 CUs 26 us, this deal 18.0 us, 256 tiles on 256 CUs 17.5 us):
+//   blocks [0, 64):   attention-LSTM tile + half of a neighbour  (48 packed rows, 336 KB of weights, one pass over x)
+//   blocks [64, 96):  attention-LSTM tiles 96 .. 127             (224 KB)
+//   blocks [96, 224): decoder-LSTM tiles                         (320 KB)
+// block 2m carries tile 3m and rows 0..15 of tile 3m + 1, block 2m + 1 tile 3m + 2 and rows 16..31 of tile 3m + 1.
+template <int MT, int DEPTH, bool XH = false>
 __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                                   // [SK_WAVES][MT][16][64]
     float* hs = smem + SK_WAVES * MT * 16 * 64;          // [MT*32][8] h' of this tile (LSTM + q slabs)
+    float* red2 = hs + MT * 32 * 8;                      // XH: [SK_WAVES][16][64] of the extra half tile, then its h' [32][4]
 
     int jsel = 0, tile = (int)blockIdx.x;
-    if (jobs.njobs > 1 && tile >= jobs.tiles0) {
+    int xt = -1, xhalf = 0;    // extra half tile: packed rows 16 xhalf .. 16 xhalf + 15 of tile xt
+    if (XH && jobs.pa_layout) {
+        const int bid = (int)blockIdx.x;
+        if (bid < 64) { const int m = bid >> 1, odd = bid & 1; tile = 3 * m + 2 * odd; xt = 3 * m + 1; xhalf = odd; }
+        else if (bid < 96) tile = 96 + (bid - 64);
+        else { jsel = 1; tile = bid - 96; }
+    } else if (jobs.njobs > 1 && tile >= jobs.tiles0) {
         jsel = 1; tile -= jobs.tiles0;
         if (jobs.njobs > 2 && tile >= jobs.tiles1) { jsel = 2; tile -= jobs.tiles1; }
     }
+    const bool has_x = XH && xt >= 0;   // workgroup-uniform
     const SkinnyJob& J = jobs.job[jsel];
-    GVX_STAMP(0, 0);
+    if (J.start_cnt && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_fetch_add(J.start_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (J.ctx_cnt) {   // workgroup-local "context has arrived" word (see the deferred segment below)
+        if (threadIdx.x == 0) reinterpret_cast<volatile int*>(hs)[MT * 32 * 8 - 1] = 0;
+        __syncthreads();
+    }
+    if (jobs.njobs >= 2) GVX_STAMP(0, 0);   // (stamps build: the single-job drain launch must not overwrite a step's stamps)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, counted waits
     const int bl = lane & 31, h = lane >> 5;
@@ -190,6 +213,14 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b_ * J.add_bs + tile * 32 + 8 * g_ + 4 * h);
             bias_pref.x += ad.x; bias_pref.y += ad.y; bias_pref.z += ad.z; bias_pref.w += ad.w;
         }
+    }
+
+    if (XH && has_x && J.mode == 0 && (wave == 4 || wave == 5)) {
+        // extra half tile: lane (j = lane & 15, g = lane >> 4) finishes hidden unit 4 xhalf + g of tile xt for batch row
+        // j (wave 4) or 16 + j (wave 5)
+        const int b_ = (lane & 15) + 16 * (wave - 4), jl_ = 4 * xhalf + (lane >> 4);
+        if (b_ < B) c_pref = J.c[(long)b_ * (J.N >> 2) + xt * 8 + jl_];
+        if (J.bias) bias_pref = *reinterpret_cast<const float4*>(J.bias + xt * 32 + 4 * jl_);
     }
 
     // ---- main loop: this wave's K slice, software pipelined DEPTH k-groups deep.
@@ -219,24 +250,62 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     // of the recurrent matrices: see the autoregressive step in gvx_api.hip)
     const int nkg_w = J.nkg_w > 0 ? J.nkg_w : J.nkg;
     const float4* wp = reinterpret_cast<const float4*>(J.Wp) + ((long)tile * nkg_w + J.kg0) * 64 + lane;
+    // extra half tile: the lanes of the other half read their partner's address (same bytes, no extra traffic): the copies
+    // feed the second batch-row block of the 16x16x1 MFMAs below
+    const bool x_mine = ((lane >> 4) & 1) == xhalf;
+    const float4* wp2 = reinterpret_cast<const float4*>(J.Wp) + ((long)(has_x ? xt : tile) * nkg_w + J.kg0) * 64 + (x_mine ? lane : (lane ^ 16));
 
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[mt][q] = 0.f;
+    f32x16 acc2;   // XH only
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2[q] = 0.f;
 
-    if (kg_begin < kg_end) {
-        float4 wv[DEPTH], xv[MT][DEPTH];
-        const int g_last = kg_end - 1;
-#define SK_LOAD(slot, gg)                                                                         \
+    // Streams the k-groups MAP(s), s in [S_BEGIN, S_END), of this wave through the MFMAs, DEPTH groups in flight.
+    // XLOAD(mt, kg) loads the x fragment of k-group kg.
+#define SK_STREAM(S_BEGIN, S_END, MAP, XLOAD)                                                            \
+    if ((S_BEGIN) < (S_END)) {                                                                            \
+        float4 wv[DEPTH], xv[MT][DEPTH], wv2[XH ? DEPTH : 1];                                             \
+        const int s_last = (S_END) - 1;                                                                   \
+        _Pragma("unroll") for (int u = 0; u < DEPTH; ++u) SK_LOAD(u, (S_BEGIN) + u, MAP, XLOAD)           \
+        int base = (S_BEGIN);                                                                             \
+        /* steady state: every slot is valid and so is its refill -> branch-free body, counted waits */   \
+        for (; base + 2 * DEPTH <= (S_END); base += DEPTH) {                                              \
+            _Pragma("unroll") for (int u = 0; u < DEPTH; ++u) {                                           \
+                SK_MFMA(u)                                                                                \
+                SK_LOAD(u, base + u + DEPTH, MAP, XLOAD)                                                  \
+                /* keep the refill right behind the MFMAs that freed its registers: left alone, the   */  \
+                /* scheduler sinks all refills to the end of the pass and the wave drains to vmcnt(0) */  \
+                __builtin_amdgcn_sched_barrier(0);                                                        \
+            }                                                                                             \
+        }                                                                                                 \
+        /* drain.  The slots hold the next min(remaining, DEPTH) groups and remaining < 2*DEPTH.  Only */ \
+        /* when more than DEPTH groups are left is there anything to refill: that pass is branch free  */ \
+        /* (every slot valid, refills are clamped loads; the few surplus ones re-read the last group   */ \
+        /* and are never consumed).  The final pass issues no loads and only guards the MFMAs.         */ \
+        int rem = (S_END) - base;                                                                         \
+        if (rem > DEPTH) {                                                                                \
+            _Pragma("unroll") for (int u = 0; u < DEPTH; ++u) {                                           \
+                SK_MFMA(u)                                                                                \
+                SK_LOAD(u, base + u + DEPTH, MAP, XLOAD)                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                        \
+            }                                                                                             \
+            rem -= DEPTH;                                                                                 \
+        }                                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < DEPTH; ++u) {                                               \
+            if (u < rem) SK_MFMA(u)                                                                       \
+        }                                                                                                 \
+    }
+#define SK_LOAD(slot, ss, MAP, XLOAD)                                                             \
         {                                                                                             \
-            const int g_ = min((gg), g_last);                                                         \
+            const int s_ = min((ss), s_last);                                                         \
+            const int g_ = MAP(s_);                                                                   \
             wv[slot] = wp[(long)g_ * 64];                                                            \
-            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                       \
-                const float* base_ = g_ < g0 ? xb0[mt] : (g_ < g1 ? xb1[mt] : xb2[mt]);               \
-                xv[mt][slot] = *reinterpret_cast<const float4*>(base_ + (long)g_ * blk);              \
-            }                                                                                         \
+            if (XH && has_x) wv2[slot] = wp2[(long)g_ * 64];                                         \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xv[mt][slot] = XLOAD(mt, g_);           \
         }
 #define SK_MFMA(slot)                                                                                  \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                               \
@@ -244,44 +313,70 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].y, xv[mt][slot].y, acc[mt], 0, 0, 0); \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].z, xv[mt][slot].z, acc[mt], 0, 0, 0); \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].w, xv[mt][slot].w, acc[mt], 0, 0, 0); \
+        }                                                                                                 \
+        if (XH && has_x) {                                                                                \
+            /* extra half tile on v_mfma_f32_16x16x1_4b_f32: four independent 16 x 16 blocks, block = lane >> 4.  With */ \
+            /* the packed fragment in the half's lanes AND copied into their partners (lane ^ 16), block 0 is         */ \
+            /* (rows 0-15 of the half) x (batch rows 0-15) at k = c, block 1 the same rows x batch rows 16-31,        */ \
+            /* blocks 2 / 3 the same at k = 4 + c: no lane is wasted (the 32x32x2 form with half its rows zeroed      */ \
+            /* made these workgroups MFMA bound: 26-28 us per launch)                                                 */ \
+            const float4 w2_ = wv2[slot];                                                                 \
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(w2_.x, xv[0][slot].x, acc2, 0, 0, 0);             \
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(w2_.y, xv[0][slot].y, acc2, 0, 0, 0);             \
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(w2_.z, xv[0][slot].z, acc2, 0, 0, 0);             \
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(w2_.w, xv[0][slot].w, acc2, 0, 0, 0);             \
         }
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) SK_LOAD(u, kg_begin + u)
-        int base = kg_begin;
-        // steady state: every slot is valid and so is its refill -> branch-free body, counted waits
-        for (; base + 2 * DEPTH <= kg_end; base += DEPTH) {
-#pragma unroll
-            for (int u = 0; u < DEPTH; ++u) {
-                SK_MFMA(u)
-                SK_LOAD(u, base + u + DEPTH)
-                // keep the refill right behind the MFMAs that freed its registers: left alone, the scheduler sinks
-                // all refills to the end of the pass and the wave drains to vmcnt(0) every DEPTH groups
-                __builtin_amdgcn_sched_barrier(0);
+#define SK_X_PLAIN(mt, g) (*reinterpret_cast<const float4*>(((g) < g0 ? xb0[mt] : ((g) < g1 ? xb1[mt] : xb2[mt])) + (long)(g) * blk))
+#define SK_MAP_ID(s) (s)
+    if (!J.defer_seg) {
+        SK_STREAM(kg_begin, kg_end, SK_MAP_ID, SK_X_PLAIN)
+    } else {
+        // Deferred segment (teacher-forced decoder: x[1] is the attention context of the previous step, which the persistent
+        // attention kernel publishes while this launch is already streaming): every wave first takes its share of the
+        // k-groups of x[0] and x[2], then - once the context counter has reached its target - its share of x[1]'s.
+        const int nc = g1 - g0, nn = J.nkg - nc;
+        const int per_n = (nn + SK_WAVES - 1) / SK_WAVES, per_c = (nc + SK_WAVES - 1) / SK_WAVES;
+        const int n_begin = min(nn, wave * per_n), n_end = min(nn, n_begin + per_n);
+        const int c_begin = min(nc, wave * per_c), c_end = min(nc, c_begin + per_c);
+#define SK_MAP_N(s) ((s) < g0 ? (s) : (s) + nc)
+#define SK_MAP_C(s) ((s) + g0)
+        SK_STREAM(n_begin, n_end, SK_MAP_N, SK_X_PLAIN)
+        if (J.ctx_cnt) {
+            // ONE wave per workgroup polls the counter (1 800 waves polling one word queue in front of the producer's own
+            // add to it); the others watch a word in LDS that the polling wave sets.  The context is then read with sc1
+            // loads only: the bytes were stored write-through by another kernel, a plain load could hit a stale L1 / L2 line
+            volatile int* seen = reinterpret_cast<volatile int*>(hs) + MT * 32 * 8 - 1;   // last word of hs (free until the epilogue)
+            if (wave == 0) {
+                handoff_wait(J.ctx_cnt, J.ctx_target, J.tmo, 0x200u);
+                *seen = 1;
+            } else {
+                unsigned spins = 0;
+                while (*seen == 0 && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
             }
-        }
-        // drain.  The slots hold the next min(remaining, DEPTH) groups and remaining < 2*DEPTH.  Only when more than
-        // DEPTH groups are left is there anything to refill: that pass is branch free (every slot valid, refills are
-        // clamped loads; the few surplus ones re-read the last group and are never consumed).  The final pass issues
-        // no loads and only guards the MFMAs (wave-uniform).
-        int rem = kg_end - base;
-        if (rem > DEPTH) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the compiler from moving the loads above the poll
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(J.x[1].p);
+            unsigned xo[MT];
 #pragma unroll
-            for (int u = 0; u < DEPTH; ++u) {
-                SK_MFMA(u)
-                SK_LOAD(u, base + u + DEPTH)
-                __builtin_amdgcn_sched_barrier(0);
+            for (int mt = 0; mt < MT; ++mt) {
+                const int b = mt * 32 + bl;
+                xo[mt] = (unsigned)((b < B ? b : 0) * 8 + 4 * h) * 4u;
             }
-            rem -= DEPTH;
+#define SK_X_SC1(mt, g) load_sc1(rx, xo[mt] + (unsigned)((g) - g0) * (unsigned)(blk * 4))
+            SK_STREAM(c_begin, c_end, SK_MAP_C, SK_X_SC1)
+#undef SK_X_SC1
+        } else {
+            SK_STREAM(c_begin, c_end, SK_MAP_C, SK_X_PLAIN)
         }
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-            if (u < rem) SK_MFMA(u)
-        }
+#undef SK_MAP_N
+#undef SK_MAP_C
+    }
+#undef SK_MAP_ID
+#undef SK_X_PLAIN
 #undef SK_MFMA
 #undef SK_LOAD
-    }
+#undef SK_STREAM
 
-    GVX_STAMP(0, 1);
+    if (jobs.njobs >= 2) GVX_STAMP(0, 1);   // (stamps build: the single-job drain launch must not overwrite a step's stamps)
 #ifdef GVX_STAMPS
     // per-wave end-of-main-loop times of one attention-LSTM tile (block 0) and one decoder-LSTM tile (block tiles0)
     if (lane == 0 && (blockIdx.x == 0 || (int)blockIdx.x == jobs.tiles0))
@@ -293,8 +388,36 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) red[((wave * MT + mt) * 16 + q) * 64 + lane] = acc[mt][q];
+    if (XH && has_x) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red2[(wave * 16 + q) * 64 + lane] = acc2[q];
+    }
     __syncthreads();
-    GVX_STAMP(0, 2);
+    if (jobs.njobs >= 2) GVX_STAMP(0, 2);   // (stamps build: the single-job drain launch must not overwrite a step's stamps)
+    float* hs2 = red2 + SK_WAVES * 16 * 64;   // [32][4] h' of the extra half tile's 4 hidden units
+    if (XH && has_x && J.mode == 0 && (wave == 4 || wave == 5)) {
+        // LSTM cell of the extra half tile's units (decoder semantics only: no packed sequences, no addend).  Accumulator
+        // 4 blk + r of lane (j, g) is gate r of unit g for batch row j (blocks 0, 2: k halves) or 16 + j (blocks 1, 3)
+        const int rb = wave - 4;
+        float s2[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; ++w) t += red2[(w * 16 + 4 * rb + qq) * 64 + lane] + red2[(w * 16 + 8 + 4 * rb + qq) * 64 + lane];
+            s2[qq] = t;
+        }
+        const int b2 = (lane & 15) + 16 * rb, g2 = lane >> 4;
+        const int jloc = 4 * xhalf + g2, j = xt * 8 + jloc, H = J.N >> 2;
+        float hval = 0.f;
+        if (b2 < B) {
+            const float c_new = sigmoidf_(s2[1] + bias_pref.y) * c_pref + sigmoidf_(s2[0] + bias_pref.x) * tanhf_(s2[2] + bias_pref.z);
+            hval = sigmoidf_(s2[3] + bias_pref.w) * tanhf_(c_new);
+            J.c[(long)b2 * H + j] = c_new;
+            J.h_out[(long)xt * blk + b2 * 8 + jloc] = hval;
+        }
+        hs2[b2 * 4 + g2] = hval;
+    }
 
     // unit u = (mt, g): register group g (4 registers) of batch tile mt; one unit per wave
     for (int u = wave; u < 4 * MT; u += SK_WAVES) {
@@ -363,25 +486,47 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         }
     }
 
-    GVX_STAMP(0, 3);
-    // ---- attention query partial products for this tile's 8 hidden units
+    if (jobs.njobs >= 2) GVX_STAMP(0, 3);   // (stamps build: the single-job drain launch must not overwrite a step's stamps)
+    // ---- attention query partial products for this workgroup's 8 (12) hidden units
     if (J.mode == 0 && J.q_slab) {
         __syncthreads();
         const int a = J.att_dim;
         const float* wq = J.Wq_t + (long)tile * a * 8;
+        const float* wq2 = J.Wq_t + (long)(has_x ? xt : tile) * a * 8 + 4 * xhalf;
+        const int slab = (XH && jobs.pa_layout) ? (int)blockIdx.x : tile;   // one slab per workgroup
+        // a thread keeps its attention dim d over the passes when the thread count is a multiple of a: the weights are loaded
+        // once (they were re-loaded per value, one dependent round trip each: 3 us in the 12-unit workgroups)
+        const bool fixed_d = (SK_THREADS % a) == 0;
+        const int d_f = tid % a;
+        float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0;
+        if (fixed_d) {
+            w0 = *reinterpret_cast<const float4*>(wq + d_f * 8);
+            w1 = *reinterpret_cast<const float4*>(wq + d_f * 8 + 4);
+            if (XH && has_x) w2 = *reinterpret_cast<const float4*>(wq2 + d_f * 8);
+        }
         for (int idx = tid; idx < B * a; idx += SK_THREADS) {
             const int b = idx / a, d = idx - b * a;
-            const float4 w0 = *reinterpret_cast<const float4*>(wq + d * 8);
-            const float4 w1 = *reinterpret_cast<const float4*>(wq + d * 8 + 4);
+            if (!fixed_d) {
+                w0 = *reinterpret_cast<const float4*>(wq + d * 8);
+                w1 = *reinterpret_cast<const float4*>(wq + d * 8 + 4);
+                if (XH && has_x) w2 = *reinterpret_cast<const float4*>(wq2 + d * 8);
+            }
             const float4 h0 = *reinterpret_cast<const float4*>(hs + b * 8);
             const float4 h1 = *reinterpret_cast<const float4*>(hs + b * 8 + 4);
             float v = w0.x * h0.x;
             v = fmaf(w0.y, h0.y, v); v = fmaf(w0.z, h0.z, v); v = fmaf(w0.w, h0.w, v);
             v = fmaf(w1.x, h1.x, v); v = fmaf(w1.y, h1.y, v); v = fmaf(w1.z, h1.z, v); v = fmaf(w1.w, h1.w, v);
-            J.q_slab[((long)tile * B + b) * a + d] = v;
+            if (XH && has_x) {   // the slab of this workgroup covers its 12 hidden units
+                const float4 h2 = *reinterpret_cast<const float4*>(hs2 + b * 4);
+                v = fmaf(w2.x, h2.x, v); v = fmaf(w2.y, h2.y, v); v = fmaf(w2.z, h2.z, v); v = fmaf(w2.w, h2.w, v);
+            }
+            J.q_slab[((long)slab * B + b) * a + d] = v;
         }
+        // first launch beside the persistent attention kernel: do not end before that kernel is resident (afterwards this
+        // launch's successors would fill every CU)
+        if (J.ready_cnt && tid == 0) handoff_wait(J.ready_cnt, J.ready_target, J.tmo, 0x300u);
     }
-    GVX_STAMP(0, 4);
+    if (jobs.njobs >= 2) GVX_STAMP(0, 4);   // (stamps build: the single-job drain launch must not overwrite a step's stamps)
 }
 
 // Same body under three kernel names so that profiles separate the teacher-forced decoder step (the dominant kernel of
@@ -401,6 +546,12 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_ste
     skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
     GVX_WG_END();
 }
+// teacher-forced step beside the persistent attention kernel (224 / 96 workgroups, no location workgroups)
+__global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_pa_kernel(SkinnyJobs jobs) {
+    GVX_WG_BEGIN();
+    skinny_body<1, SK_DEPTH1, true>(jobs);
+    GVX_WG_END();
+}
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_kernel(SkinnyJobs jobs) {   // autoregressive launches A / C
     if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }
     skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
@@ -408,6 +559,7 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_ker
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs); }
 
 static size_t skinny_lds(int MT) { return (size_t)(SK_WAVES * MT * 16 * 64 + MT * 32 * 8) * sizeof(float); }
+static size_t skinny_pa_lds() { return skinny_lds(1) + (size_t)(SK_WAVES * 16 * 64 + 32 * 4) * sizeof(float); }
 
 template <typename K>
 static hipError_t set_lds(K kern, int MT) {
@@ -420,14 +572,30 @@ hipError_t skinny_init() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_lstm_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_lstm_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
     return set_lds(encoder_lstm_step_kernel<2>, 2);
+}
+
+hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s) {
+    // the layout is built for the default layer sizes: 128 tiles per cell, batch rows in one MFMA tile
+    if (att.N != 4096 || att.B < 1 || att.B > 32 || att.mode != 0 || !att.q_slab || (dec && (dec->N != 4096 || dec->B != att.B || dec->mode != 0)))
+        return hipErrorInvalidValue;
+    SkinnyJobs js;
+    js.njobs = dec ? 2 : 1;
+    js.job[0] = att; js.job[1] = dec ? *dec : att; js.job[2] = js.job[1];
+    js.tiles0 = 128; js.tiles1 = dec ? 128 : 0; js.tiles = js.tiles0 + js.tiles1;
+    js.loc = LocJob{};
+    js.pa_layout = 1;
+    decoder_lstm_step_pa_kernel<<<dim3(dec ? 224 : 96), dim3(SK_THREADS), skinny_pa_lds(), s>>>(js);
+    return hipGetLastError();
 }
 
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc) {
     if (njobs < 1 || njobs > 3) return hipErrorInvalidValue;
     SkinnyJobs js;
     js.njobs = njobs;
+    js.pa_layout = 0;
     for (int i = 0; i < 3; ++i) js.job[i] = jobs[i < njobs ? i : njobs - 1];
     js.tiles0 = (jobs[0].N + 31) / 32;
     js.tiles1 = njobs > 1 ? (jobs[1].N + 31) / 32 : 0;

@@ -188,23 +188,34 @@ class Tacotron2(nn.Module):
     def _get_workspace(self, B: int, L: int, T: int) -> torch.Tensor:
         need = _lib.load().gvx_workspace_bytes(self._handle, B, L, T)
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != self._device():
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=self._device())
+            self._workspace = self._new_workspace(need, self._device())
         return self._workspace
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self._device()).cuda_stream
+
+    @staticmethod
+    def _new_workspace(nbytes: int, dev) -> torch.Tensor:
+        """Scratch for the C-ABI calls.  The status words at its front (gvx_workspace_status) are only ever written by the
+        kernels that raise them, so they start out cleared; the rest needs no initialisation."""
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws[:32768].zero_()
+        return ws
 
     def check_status(self) -> None:
         """Read the device-side status word of the last calls (synchronises the stream): raises IndexError for a token
         id outside the embedding table, which is what nn.Embedding does in the reference (models/tts/tacotron2.py:459).
         Not called by forward(): one check after a batch of calls is enough."""
         out = (C.c_int32 * 2)()
-        bad = False
+        bad = stalled = False
         for ws in [self._workspace] + self._lane_ws:
             if ws is None:
                 continue
             _lib.check(_lib.load().gvx_workspace_status(self._handle, ws.data_ptr(), ws.numel(), self._stream(), out))
             bad |= bool(out[0])
+            stalled |= bool(out[1])
+        if stalled:
+            raise RuntimeError("genvox_amd: an in-launch hand-off of the decoder loop timed out; the last outputs are invalid")
         if bad:
             raise IndexError("genvox_amd: token id outside [0, n_tokens)")
 
@@ -214,7 +225,7 @@ class Tacotron2(nn.Module):
             self._lane_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         for i in range(2):
             if self._lane_ws[i] is None or self._lane_ws[i].numel() < need_bytes or self._lane_ws[i].device != dev:
-                self._lane_ws[i] = torch.empty(need_bytes, dtype=torch.uint8, device=dev)
+                self._lane_ws[i] = self._new_workspace(need_bytes, dev)
         return self._lane_streams, self._lane_ws
 
     def enable_stage_timing(self, enable: bool = True) -> None:
@@ -290,9 +301,15 @@ class Tacotron2(nn.Module):
         cur = torch.cuda.current_stream(dev)
         for lane in streams:
             lane.wait_stream(cur)
-        for ci, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
-            with torch.cuda.stream(streams[ci % 2]):
-                run(lo, hi, wss[ci % 2])
+        # one handle, two streams at once: the attention runs as a launch per step here (the resident attention kernel of
+        # the single-stream path owns the handle's side stream for a whole loop)
+        _lib.check(lib.gvx_model_set_persistent_attention(self._handle, 0))
+        try:
+            for ci, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
+                with torch.cuda.stream(streams[ci % 2]):
+                    run(lo, hi, wss[ci % 2])
+        finally:
+            _lib.check(lib.gvx_model_set_persistent_attention(self._handle, 1))
         for lane in streams:
             cur.wait_stream(lane)
         return out
@@ -394,7 +411,7 @@ class Tacotron2(nn.Module):
         # every row is post-processed as a sequence of its own length (what a batch-1 run of the reference sees)
         need = lib.gvx_postnet_workspace_bytes(self._handle, B, Tn)
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._workspace = self._new_workspace(need, dev)
         ws = self._workspace
         _lib.check(lib.gvx_postnet_forward(self._handle, mel_out.data_ptr(), n_frames.data_ptr() if B > 1 else None, B, Tn,
                                            mel_post.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
@@ -427,7 +444,7 @@ class Tacotron2(nn.Module):
         lib = _lib.load()
         need = lib.gvx_postnet_workspace_bytes(self._handle, B, T)
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._workspace = self._new_workspace(need, dev)
         ws = self._workspace
         out = torch.empty_like(mel)
         _lib.check(lib.gvx_postnet_forward(self._handle, mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T,

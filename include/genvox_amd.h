@@ -94,9 +94,18 @@ size_t gvx_workspace_bytes(const gvx_model* model, int B, int L, int T);
  *   [0] != 0: a token id was outside [0, n_tokens) (the reference's nn.Embedding raises IndexError there,
  *             models/tts/tacotron2.py:459; the row is embedded as zeros here) - set by the last
  *             gvx_encoder_forward / gvx_tacotron2_forward on this workspace;
- *   [1]: reserved (0).
+ *   [1] != 0: a bounded in-launch wait of the last teacher-forced decoder loop gave up (the attention kernel that runs
+ *             beside the LSTM launches and those launches hand the query / context over through counters in the
+ *             workspace; a wait that is not served within a few hundred ms raises this word and every kernel drains):
+ *             the outputs of that call are invalid.  Never observed; it exists so that a scheduling failure cannot hang.
  * Costs a stream synchronisation: meant for tests and for one check after a batch of calls, not for every call. */
 int gvx_workspace_status(const gvx_model* model, const void* workspace, size_t workspace_bytes, void* stream, int32_t* host_out);
+
+/* Teacher-forced decoder loop: run the attention as ONE kernel that lives beside the step launches (default, used when the
+ * shape allows it: B <= 32, L <= 128, default layer sizes) or as a launch per step (enable = 0).  Callers that drive one
+ * handle from two streams at once (the host mirror does that for batches above 32 rows) must switch it off: the
+ * resident kernel owns the handle's side stream for the whole loop.  Results are identical either way. */
+int gvx_model_set_persistent_attention(gvx_model* model, int enable);
 
 /* ---- Encoder: embedding + conv/BN/relu stack + BiLSTM with packed-sequence semantics.
  * Replaces nn.Embedding + Encoder.forward / Encoder.inference (models/tts/tacotron2.py:459,

@@ -221,3 +221,40 @@ def test_autoregressive_batch_over_32_rows():
         want = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(tok[b:b + 1]), masks[:, :, b], 1.0, steps)
         for k in KEYS:
             assert max_abs_diff(out[k][b:b + 1], want[k]) <= TOL, (b, k)
+
+
+def test_persistent_attention_equals_per_step_attention():
+    """The teacher-forced loop runs its attention as ONE kernel beside the LSTM launches when the shape allows it (default
+    layer sizes, B <= 32, L <= 128: attn_persist.hip, 224-workgroup launch layout in skinny.hip) and as a launch per step
+    otherwise; both must give the reference's numbers (models/tts/tacotron2.py:243-262, :317-348).  Ragged lengths, fixed
+    dropout masks; the hand-off status word must stay clear; two runs must agree bit for bit (fixed reduction orders, no
+    data-dependent scheduling in the results), also when the second one replays the hipGraph of the LSTM chain."""
+    from genvox_amd import _lib
+
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
+    sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+    m = Tacotron2(mc, ac, tc)
+    m.load_state_dict(sd)
+    m = m.to("cuda:0")
+    B, L, T, P = 7, 100, 33, mc.prenet_dim
+    tl = np.array([100, 97, 64, 50, 33, 2, 1])
+    ml = np.array([33, 30, 33, 7, 20, 1, 33])
+    inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=9, token_lengths=tl, mel_lengths=ml)
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    masks = torch.from_numpy(gw.prenet_keep_masks((T + 1) * B, P, seed=2)).reshape(2, T + 1, B, P)
+    batch["prenet_keep_masks"] = masks
+    lib = _lib.load()
+    handle = m._ensure_handle()
+    outs = {}
+    for tag, on in (("persistent", 1), ("persistent_again", 1), ("persistent_graph", 1), ("per_step", 0)):
+        _lib.check(lib.gvx_model_set_persistent_attention(handle, on))
+        outs[tag] = {k: v.clone() for k, v in m.forward(batch).items()}
+        m.check_status()   # raises if an in-launch wait gave up
+    _lib.check(lib.gvx_model_set_persistent_attention(handle, 1))
+    for k in KEYS:
+        assert torch.equal(outs["persistent"][k], outs["persistent_again"][k]), k
+        assert torch.equal(outs["persistent"][k], outs["persistent_graph"][k]), k
+        assert max_abs_diff(outs["persistent"][k], outs["per_step"][k]) <= 2e-5, k
+    want = tacotron2_ref.tacotron2_forward(sd, batch, masks.reshape(2, -1, P), mask_padding=True)
+    for k in KEYS:
+        assert max_abs_diff(outs["persistent"][k], want[k]) <= TOL, k

@@ -99,7 +99,9 @@ def test_c_abi_rejects_bad_arguments_loudly():
     whole = m.forward({**big, "prenet_keep_masks": masks})
     part = m.forward({**{k: v[64:] for k, v in big.items()}, "prenet_keep_masks": masks[:, :, 64:].contiguous()})
     assert whole["mel_outputs"].shape == (B, 80, T)
-    assert torch.equal(whole["mel_outputs_postnet"][64:], part["mel_outputs_postnet"])
+    # (rows 64.. run as a chunk of a two-stream batch in `whole` and as a batch of their own in `part`: the latter takes the
+    # persistent-attention loop, whose fp32 sums are ordered differently - equal to rounding, not bit for bit)
+    assert (whole["mel_outputs_postnet"][64:] - part["mel_outputs_postnet"]).abs().max() <= 1e-5
 
 
 @pytest.mark.parametrize("name", ["tf_small", "tf_full"])

@@ -167,7 +167,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 //   blocks [64, 96):  attention-LSTM tiles 96 .. 127             (224 KB)
 //   blocks [96, 224): decoder-LSTM tiles                         (320 KB)
 // block 2m carries tile 3m and rows 0..15 of tile 3m + 1, block 2m + 1 tile 3m + 2 and rows 16..31 of tile 3m + 1.
-template <int MT, int DEPTH, bool XH = false>
+template <int MT, int DEPTH, bool XH = false, bool DEFER = false>
 __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                                   // [SK_WAVES][MT][16][64]
@@ -187,9 +187,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     }
     const bool has_x = XH && xt >= 0;   // workgroup-uniform
     const SkinnyJob& J = jobs.job[jsel];
-    if (J.start_cnt && blockIdx.x == 0 && threadIdx.x == 0)
+    if (DEFER && J.start_cnt && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_fetch_add(J.start_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (J.ctx_cnt) {   // workgroup-local "context has arrived" word (see the deferred segment below)
+    if (DEFER && J.ctx_cnt) {   // workgroup-local "context has arrived" word (see the deferred segment below)
         if (threadIdx.x == 0) reinterpret_cast<volatile int*>(hs)[MT * 32 * 8 - 1] = 0;
         __syncthreads();
     }
@@ -328,7 +328,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         }
 #define SK_X_PLAIN(mt, g) (*reinterpret_cast<const float4*>(((g) < g0 ? xb0[mt] : ((g) < g1 ? xb1[mt] : xb2[mt])) + (long)(g) * blk))
 #define SK_MAP_ID(s) (s)
-    if (!J.defer_seg) {
+    if (!DEFER || !J.defer_seg) {   // (DEFER is a template parameter so that the ordinary kernels do not carry the code below)
         SK_STREAM(kg_begin, kg_end, SK_MAP_ID, SK_X_PLAIN)
     } else {
         // Deferred segment (teacher-forced decoder: x[1] is the attention context of the previous step, which the persistent
@@ -549,9 +549,11 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_ste
 // teacher-forced step beside the persistent attention kernel (224 / 96 workgroups, no location workgroups)
 __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_pa_kernel(SkinnyJobs jobs) {
     GVX_WG_BEGIN();
-    skinny_body<1, SK_DEPTH1, true>(jobs);
+    skinny_body<1, SK_DEPTH1, true, true>(jobs);
     GVX_WG_END();
 }
+// the launch that drains the loop (decoder-LSTM of the last step): ordinary layout, context handed over in-launch
+__global__ __launch_bounds__(SK_THREADS) void decoder_lstm_drain_pa_kernel(SkinnyJobs jobs) { skinny_body<1, SK_DEPTH1, false, true>(jobs); }
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_kernel(SkinnyJobs jobs) {   // autoregressive launches A / C
     if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }
     skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
@@ -573,6 +575,7 @@ hipError_t skinny_init() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_lstm_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_lstm_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
+    if ((e = set_lds(decoder_lstm_drain_pa_kernel, 1)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
     return set_lds(encoder_lstm_step_kernel<2>, 2);
 }
@@ -626,7 +629,10 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
         else if (kind == SK_ENCODER) encoder_lstm_step_kernel<2><<<grid, block, lds, s>>>(js);
         else ar_lstm_step_kernel<2><<<grid, block, lds, s>>>(js);
     } else {
-        if (kind == SK_DECODER) decoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
+        if (kind == SK_DECODER && jobs[0].defer_seg) {
+            if (B > 32 || extra) return hipErrorInvalidValue;
+            decoder_lstm_drain_pa_kernel<<<grid, block, lds, s>>>(js);
+        } else if (kind == SK_DECODER) decoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
         else if (kind == SK_ENCODER) encoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
         else ar_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
     }

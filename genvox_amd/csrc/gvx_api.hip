@@ -804,7 +804,13 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
                     attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, E, d.att_rnn_dim, d.dec_rnn_dim);
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
     if (pa && !m->pa_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&m->pa_stream, hipStreamNonBlocking));
+        // Highest priority: HIP keeps separate hardware queues per priority, so this stream can never be dealt the queue of
+        // the (normal-priority) stream the LSTM chain runs on.  Two ordinary streams may share one of the few hardware queues
+        // (round-robin in order of first use); the attention kernel would then sit in front of the launches it waits for
+        // until its spin limit - observed in a process that had created a dozen streams before.
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&m->pa_stream, hipStreamNonBlocking, greatest));
         HIP_TRY(hipEventCreateWithFlags(&m->pa_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m->pa_join, hipEventDisableTiming));
     }

@@ -172,7 +172,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* red = smem;                                   // [SK_WAVES][MT][16][64]
     float* hs = smem + SK_WAVES * MT * 16 * 64;          // [MT*32][8] h' of this tile (LSTM + q slabs)
-    float* red2 = hs + MT * 32 * 8;                      // XH: [SK_WAVES][16][64] of the extra half tile, then its h' [32][4]
+    float* red2 = hs + MT * 32 * 8;                      // XH: [SK_WAVES][8][64] of the extra half tile, then its h' [32][4]
 
     int jsel = 0, tile = (int)blockIdx.x;
     int xt = -1, xhalf = 0;    // extra half tile: packed rows 16 xhalf .. 16 xhalf + 15 of tile xt
@@ -388,13 +388,13 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) red[((wave * MT + mt) * 16 + q) * 64 + lane] = acc[mt][q];
-    if (XH && has_x) {
+    if (XH && has_x) {   // the two k-half blocks of a batch-row block are added here, before the cross-wave sum
 #pragma unroll
-        for (int q = 0; q < 16; ++q) red2[(wave * 16 + q) * 64 + lane] = acc2[q];
+        for (int q = 0; q < 8; ++q) red2[(wave * 8 + q) * 64 + lane] = acc2[q] + acc2[8 + q];
     }
     __syncthreads();
     if (jobs.njobs >= 2) GVX_STAMP(0, 2);   // (stamps build: the single-job drain launch must not overwrite a step's stamps)
-    float* hs2 = red2 + SK_WAVES * 16 * 64;   // [32][4] h' of the extra half tile's 4 hidden units
+    float* hs2 = red2 + SK_WAVES * 8 * 64;    // [32][4] h' of the extra half tile's 4 hidden units
     if (XH && has_x && J.mode == 0 && (wave == 4 || wave == 5)) {
         // LSTM cell of the extra half tile's units (decoder semantics only: no packed sequences, no addend).  Accumulator
         // 4 blk + r of lane (j, g) is gate r of unit g for batch row j (blocks 0, 2: k halves) or 16 + j (blocks 1, 3)
@@ -404,7 +404,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         for (int qq = 0; qq < 4; ++qq) {
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < SK_WAVES; ++w) t += red2[(w * 16 + 4 * rb + qq) * 64 + lane] + red2[(w * 16 + 8 + 4 * rb + qq) * 64 + lane];
+            for (int w = 0; w < SK_WAVES; ++w) t += red2[(w * 8 + 4 * rb + qq) * 64 + lane];
             s2[qq] = t;
         }
         const int b2 = (lane & 15) + 16 * rb, g2 = lane >> 4;
@@ -504,13 +504,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             w1 = *reinterpret_cast<const float4*>(wq + d_f * 8 + 4);
             if (XH && has_x) w2 = *reinterpret_cast<const float4*>(wq2 + d_f * 8);
         }
-        for (int idx = tid; idx < B * a; idx += SK_THREADS) {
-            const int b = idx / a, d = idx - b * a;
-            if (!fixed_d) {
-                w0 = *reinterpret_cast<const float4*>(wq + d * 8);
-                w1 = *reinterpret_cast<const float4*>(wq + d * 8 + 4);
-                if (XH && has_x) w2 = *reinterpret_cast<const float4*>(wq2 + d * 8);
-            }
+        auto slab_row = [&](int b, int d) {
             const float4 h0 = *reinterpret_cast<const float4*>(hs + b * 8);
             const float4 h1 = *reinterpret_cast<const float4*>(hs + b * 8 + 4);
             float v = w0.x * h0.x;
@@ -521,6 +515,24 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                 v = fmaf(w2.x, h2.x, v); v = fmaf(w2.y, h2.y, v); v = fmaf(w2.z, h2.z, v); v = fmaf(w2.w, h2.w, v);
             }
             J.q_slab[((long)slab * B + b) * a + d] = v;
+        };
+        if (fixed_d) {
+            // batch rows tid / a + (SK_THREADS / a) i: unrolled by 8 so that the passes' LDS reads and dependent FMA chains
+            // interleave (rolled, each pass waited for its own: 2 us at the end of the launch's slowest workgroups)
+            const int rstep = SK_THREADS / a, b_first = tid / a;
+            for (int b0 = b_first; b0 < B; b0 += 8 * rstep) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (b0 + i * rstep < B) slab_row(b0 + i * rstep, d_f);
+            }
+        } else {
+            for (int idx = tid; idx < B * a; idx += SK_THREADS) {
+                const int b = idx / a, d = idx - b * a;
+                w0 = *reinterpret_cast<const float4*>(wq + d * 8);
+                w1 = *reinterpret_cast<const float4*>(wq + d * 8 + 4);
+                if (XH && has_x) w2 = *reinterpret_cast<const float4*>(wq2 + d * 8);
+                slab_row(b, d);
+            }
         }
         // first launch beside the persistent attention kernel: do not end before that kernel is resident (afterwards this
         // launch's successors would fill every CU)
@@ -561,7 +573,7 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_ker
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs); }
 
 static size_t skinny_lds(int MT) { return (size_t)(SK_WAVES * MT * 16 * 64 + MT * 32 * 8) * sizeof(float); }
-static size_t skinny_pa_lds() { return skinny_lds(1) + (size_t)(SK_WAVES * 16 * 64 + 32 * 4) * sizeof(float); }
+static size_t skinny_pa_lds() { return skinny_lds(1) + (size_t)(SK_WAVES * 8 * 64 + 32 * 4) * sizeof(float); }
 
 template <typename K>
 static hipError_t set_lds(K kern, int MT) {

@@ -76,7 +76,7 @@ struct Blob {  // offsets in floats into the packed weight blob
     size_t enc_w[MAX_CONV], enc_b[MAX_CONV];
     size_t enc_wih, enc_bih, enc_whh_frag[2];
     size_t pre_w0, pre_w1, pre_w0_t, pre_w1_t;
-    size_t att_frag, att_bias, wq_t, wmem, v, loc_conv, loc_dense;
+    size_t att_frag, att_bias, att_wpre, wq_t, wmem, v, loc_conv, loc_dense;
     size_t dec_frag, dec_bias;
     size_t proj_w, proj_b, proj_frag, proj_hd_t, proj_ctx_frag;   // last two: autoregressive split of the projection (see gvx_decoder_autoregressive)
     size_t post_w[MAX_CONV], post_b[MAX_CONV];
@@ -88,7 +88,7 @@ inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 
 struct WsPlan {  // byte offsets into the caller's workspace
     size_t xa, xb, xg, enc_h, enc_c, flags, sync, memory;
     size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy, loc, ar_masks, p_slab, p_ctx;
-    size_t att_part, dec_part;
+    size_t att_part, dec_part, pre_gate;
     size_t ya, yb;
     size_t total;
 };
@@ -178,6 +178,8 @@ Blob make_blob_layout(const gvx_dims& d) {
     b.pre_w0_t = take((size_t)M * P);   // both Prenet matrices transposed ([in][out]) for the autoregressive step tail
     b.pre_w1_t = take((size_t)P * P);   // (ar_project_kernel)
     b.att_frag = take(frag_floats(4 * A, P + E + A)); b.att_bias = take((size_t)4 * A);
+    b.att_wpre = take((size_t)4 * A * P);   // the Prenet columns of the attention LSTM again, plain [4A packed rows][P]: one GEMM per
+                                            // teacher-forced loop applies them to all steps at once (persistent-attention path)
     b.wq_t = take((size_t)A * d.att_dim);
     b.wmem = take((size_t)d.att_dim * E); b.v = take(d.att_dim);
     b.loc_conv = take((size_t)2 * d.att_loc_kernel * 32);   // transposed [2][kl][32]
@@ -231,6 +233,8 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.p_ctx = take((size_t)B * m->PSB());            //   and of the context columns (blocked vector)
     w.att_part = take((size_t)B * 4 * A);            // autoregressive mode: partial gate pre-activations [B][4A] / [B][4D] of the
     w.dec_part = take((size_t)B * 4 * D);            //   column slices that are known one launch early
+    // teacher-forced loop beside the persistent attention kernel: Prenet contribution to the attention LSTM's gates, all steps
+    w.pre_gate = take(B <= 32 ? (size_t)T * B * 4 * A : 0);
     w.ar_masks = take(((size_t)2 * T * B * P + 3) / 4);  // autoregressive mode: keep masks copied next to the graphs' operands (bytes)
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
@@ -466,6 +470,7 @@ int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, vo
                        "decoder.attention_rnn.bias_hh", A, P + E, &wcat, out + bl.att_bias);
         if (rc != GVX_OK) return rc;
         pack_frag(wcat, 4 * A, P + E + A, out + bl.att_frag);
+        for (int n = 0; n < 4 * A; ++n) std::memcpy(out + bl.att_wpre + (size_t)n * P, &wcat[(size_t)n * (P + E + A)], sizeof(float) * P);
     }
     {   // attention layer
         const std::string att = "decoder.attention_layer.";
@@ -652,7 +657,7 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
 
 struct DecoderBuffers {
     float *pm, *frames, *pre1, *prenet, *h_a, *c_a, *c_d, *hc, *w_cum, *q_slab, *proj, *energies, *align_tm, *loc, *p_slab, *p_ctx;
-    float *att_part, *dec_part;
+    float *att_part, *dec_part, *pre_gate;
     int32_t* len_copy;
 };
 
@@ -666,6 +671,7 @@ DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
     b.loc = ws_ptr<float>(ws, wp.loc);
     b.p_slab = ws_ptr<float>(ws, wp.p_slab); b.p_ctx = ws_ptr<float>(ws, wp.p_ctx);
     b.att_part = ws_ptr<float>(ws, wp.att_part); b.dec_part = ws_ptr<float>(ws, wp.dec_part);
+    b.pre_gate = ws_ptr<float>(ws, wp.pre_gate);
     return b;
 }
 
@@ -803,6 +809,14 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     const bool pa = m->attn_persistent && m->attn_one_launch &&
                     attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, E, d.att_rnn_dim, d.dec_rnn_dim);
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
+    if (pa) {   // pre_gate[t][b][:] = W_ih[:, :P] prenet(t)[b]  for all T steps: 4A x P weights read once instead of T times
+        GemmParams g{};
+        g.A = db.prenet; g.amap = RowMap{B, (long)B * P, 8}; g.a_kblk = (long)B * 8;   // step t: blocked [P/8][B][8]
+        g.W = m->dev_blob + m->blob.att_wpre; g.ldw = P;
+        g.C = db.pre_gate; g.cmap = RowMap{T * B, 0, (long)4 * d.att_rnn_dim};
+        g.M = T * B; g.N = 4 * d.att_rnn_dim; g.K = P; g.act = ACT_NONE;
+        HIP_TRY(launch_gemm(g, s));
+    }
     if (pa && !m->pa_stream) {
         // Highest priority: HIP keeps separate hardware queues per priority, so this stream can never be dealt the queue of
         // the (normal-priority) stream the LSTM chain runs on.  Two ordinary streams may share one of the few hardware queues
@@ -817,6 +831,14 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     auto defer = [&](SkinnyJob& J, int t_ctx, bool first) {   // t_ctx: the step whose context the job's x[1] is
         if (!pa) return;      // (the deferred k order costs the launch ~0.9 us: only where the context arrives in-launch)
         J.defer_seg = 1;
+        if (J.q_slab) {
+            // attention LSTM: its Prenet columns were applied to all steps by one GEMM before the loop (pre_gate); the job
+            // streams the k-groups of [context ; h_a] only and takes the rest as an addend (step t_ctx + 1)
+            const int A = d.att_rnn_dim;
+            J.x[0] = XSeg{J.x[1].p, 0};
+            J.kg0 = P / 8; J.nkg_w = (P + E + A) / 8; J.nkg = (E + A) / 8;
+            J.addend = db.pre_gate + (size_t)(t_ctx + 1) * B * 4 * A; J.add_bs = 4 * A;
+        }
         J.tmo = sync + HANDOFF_TIMEOUT;
         if (t_ctx >= 0) { J.ctx_cnt = sync + HANDOFF_CNT_CTX; J.ctx_target = (unsigned)B * (unsigned)(t_ctx + 1); }
         J.start_cnt = sync + HANDOFF_CNT_Q;   // every launch of the loop (and the drain launch) announces its start

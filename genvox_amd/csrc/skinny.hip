@@ -221,6 +221,10 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         const int b_ = (lane & 15) + 16 * (wave - 4), jl_ = 4 * xhalf + (lane >> 4);
         if (b_ < B) c_pref = J.c[(long)b_ * (J.N >> 2) + xt * 8 + jl_];
         if (J.bias) bias_pref = *reinterpret_cast<const float4*>(J.bias + xt * 32 + 4 * jl_);
+        if (J.addend && b_ < B) {
+            const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b_ * J.add_bs + xt * 32 + 4 * jl_);
+            bias_pref.x += ad.x; bias_pref.y += ad.y; bias_pref.z += ad.z; bias_pref.w += ad.w;
+        }
     }
 
     // ---- main loop: this wave's K slice, software pipelined DEPTH k-groups deep.

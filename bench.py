@@ -53,6 +53,9 @@ def algorithmic_bytes_lstm_launch(mc, B, L, persistent=False):
     per_row = (P + E + A) + (A + E + D) + 2 * (A + D) + (A + D)
     slabs = (96 if persistent else A // 8) * a
     loc = 0 if persistent else 2 * L + L * a
+    if persistent:   # the Prenet columns of the attention LSTM are applied by one GEMM before the loop: the launch reads their
+        weights -= 4 * A * P          # product (4A floats per row) instead of the 4A x P weights and the P inputs per row
+        per_row += 4 * A - P
     return 4 * (weights + B * (per_row + slabs + loc))
 
 

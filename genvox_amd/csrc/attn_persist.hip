@@ -6,18 +6,23 @@
 // over the decode or produced by the attention itself, yet a per-step launch has to fetch them again through a fabric that
 // the LSTM weight stream saturates (measured: 7-8 us per launch on the step's critical chain, 11-14 us when run beside
 // the stream).  Here one workgroup per batch row keeps the row's memory (64 VGPRs x 1024 threads) and processed memory
-// (16 VGPRs) in registers and its location features in LDS for all T steps; per step it only receives the 64 KB of query
-// partial sums from the attention-LSTM tiles and publishes 2 KB of context.  It runs BESIDE the LSTM launches (on CUs of
-// its own, 32 of 256), so the chain  slabs(t) -> energies -> softmax -> context(t)  overlaps the next launch's streaming of
-// the weight columns that do not depend on the context; that launch waits for context(t) just before its context columns
-// (skinny.hip, deferred segment).
+// (16 VGPRs) in registers and its location features in LDS for all T steps (conv + dense on the MFMA units); per step it
+// only receives the 48 KB of query partial sums from the 96 attention-LSTM workgroups and publishes 2 KB of context.  It
+// runs BESIDE the LSTM launches (on CUs of its own, 32 of 256 - a kernel that shares a CU with a weight-streaming tile gets
+// half its issue slots and a full memory queue: measured 12.8 instead of 5.8 us for this chain), so the chain
+// slabs(t) -> energies -> softmax -> context(t)  overlaps the next launch's streaming of the weight columns that do not
+// depend on the context; that launch waits for context(t) just before its context columns (skinny.hip, deferred segment)
+// and is dealt to 224 workgroups of equal weight, because a CU streams ~25 KB/us whatever shares it.
 //
 // Hand-offs between the two kernels follow cdna_hip_programming.md section 6 guideline 16 / MI355X_MICROARCH.md
 // "inter-workgroup visibility" (per-XCD L2s are not coherent):
-//   * payload (query slabs, context) is stored write-through (`sc1` 16-byte buffer stores), every storing wave drains
-//     (`s_waitcnt vmcnt(0)`), the workgroup meets at a barrier, ONE lane adds to an agent-scope counter;
-//   * the consumer polls that counter with `sc1` loads (one lane, bounded spin), meets at a barrier, and reads the payload
-//     with `sc1` 16-byte buffer loads only (never plain loads: L1 / L2 may hold last step's lines).
+//   * the context is stored write-through (`sc1` 16-byte buffer stores), the storing waves drain (`s_waitcnt vmcnt(0)`), the
+//     workgroup meets at a barrier, ONE lane adds to an agent-scope counter; the LSTM waves poll that counter with `sc1`
+//     loads (one wave per workgroup, bounded spin with back-off) and read the context with `sc1` buffer loads only;
+//   * the query slabs need no in-kernel publication: they are plain stores of launch t, and block 0 of launch t + 1 adds 1 to
+//     a second counter when it STARTS - by then launch t has completed and its stores have been written back (a
+//     write-through store + drain at the end of every attention-LSTM workgroup cost the launch 6 us).  They are read with
+//     `sc1` buffer loads (never plain loads: L1 / L2 may hold last step's lines).
 // Every spin is bounded: on a timeout the waiter raises the workspace's hand-off status word and every later wait returns
 // at once, so both kernels drain (with wrong results, which gvx_workspace_status reports) instead of hanging the GPU.
 #include "gvx_kernels.h"

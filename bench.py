@@ -219,7 +219,10 @@ def main():
                 "attention_launch_us": None if persistent else round(kt["attention_step"] * 1e3, 2),
                 "mfma_tflops": round(tfl, 1), "mfma_frac_of_157TF": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                 "decoder_step_us": round(loop_ms * 1e3 / T, 2),
-                "decoder_step_GBs_survey_8d": round(algorithmic_bytes_decoder_step(mc, b, L) * T / (loop_ms * 1e-3) / 1e9, 1)}
+                "decoder_step_GBs_survey_8d": round(algorithmic_bytes_decoder_step(mc, b, L) * T / (loop_ms * 1e-3) / 1e9, 1),
+                # the whole step against the HBM peak (SURVEY 8d bytes per step / measured step time): with the persistent
+                # attention kernel the launch above IS the step, so this is the figure to compare across rounds
+                "decoder_step_frac": round(algorithmic_bytes_decoder_step(mc, b, L) * T / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     roofline, stages = None, None
     if rank == 0:

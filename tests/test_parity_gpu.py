@@ -258,3 +258,35 @@ def test_persistent_attention_equals_per_step_attention():
     want = tacotron2_ref.tacotron2_forward(sd, batch, masks.reshape(2, -1, P), mask_padding=True)
     for k in KEYS:
         assert max_abs_diff(outs["persistent"][k], want[k]) <= TOL, k
+
+
+@pytest.mark.parametrize("B,L,T", [(1, 1, 1), (1, 128, 3), (32, 5, 2), (17, 127, 9), (2, 64, 1), (31, 128, 17), (32, 128, 1)])
+def test_persistent_attention_edge_shapes(B, L, T):
+    """Edge shapes of the persistent-attention loop (single row / token / step, maximum rows and tokens, ragged lengths):
+    same numbers as the launch-per-step loop (which test_shapes_against_oracle pins to the oracle), repeatable bit for bit,
+    finite, no hand-off time-out."""
+    from genvox_amd import _lib
+
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
+    m = Tacotron2(mc, ac, tc)
+    m.load_state_dict(gw.generate_state_dict(mc, ac, tc, seed=0))
+    m = m.to("cuda:0")
+    rng = np.random.default_rng(B * 1000 + L * 10 + T)
+    tl = np.sort(rng.integers(1, L + 1, B))[::-1].copy()
+    tl[0] = L
+    ml = rng.integers(1, T + 1, B)
+    ml[0] = T
+    inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=7, token_lengths=tl, mel_lengths=ml)
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    batch["prenet_keep_masks"] = torch.from_numpy(gw.prenet_keep_masks((T + 1) * B, mc.prenet_dim, seed=2)).reshape(2, T + 1, B, mc.prenet_dim)
+    lib, handle = _lib.load(), m._ensure_handle()
+    outs = []
+    for on in (1, 1, 0):
+        _lib.check(lib.gvx_model_set_persistent_attention(handle, on))
+        outs.append({k: v.clone() for k, v in m.forward(batch).items()})
+        m.check_status()
+    _lib.check(lib.gvx_model_set_persistent_attention(handle, 1))
+    for k in KEYS:
+        assert torch.isfinite(outs[0][k]).all(), k
+        assert torch.equal(outs[0][k], outs[1][k]), k
+        assert max_abs_diff(outs[0][k], outs[2][k]) <= 2e-5, k

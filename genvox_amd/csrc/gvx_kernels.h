@@ -184,20 +184,23 @@ __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, unsigned byt
     __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)byte_off, 0, 16);
 }
 // One lane waits until *cnt >= target.  Bounded; a timeout (or one raised by anybody else) makes every wait return at once.
+template <bool FEW_WAITERS = false>
 __device__ __forceinline__ bool handoff_wait(const unsigned* cnt, unsigned target, unsigned* tmo, unsigned code) {
     // Normally the word is there at the first look.  A waiter that is early backs off (up to ~2 us between polls): a launch has
-    // ~1 800 waves that may wait on the same word, and their polls queue in front of the producer's own traffic.
+    // ~220 waves that may wait on the same word, and their polls queue in front of the producer's own traffic.  FEW_WAITERS
+    // (the 32 workgroups of the persistent attention kernel, which wait every step): poll every ~0.1 us instead - what they
+    // wait for starts the step's critical chain.
     unsigned spins = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         ++spins;
-        if ((spins & 7u) == 1u) {   // (after a timeout every wait gives up at its first look)
+        if ((spins & (FEW_WAITERS ? 127u : 7u)) == 1u) {   // (after a timeout every wait gives up at its first look)
             if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (spins > HANDOFF_SPIN_LIMIT) {
+            if (spins > (FEW_WAITERS ? 16u : 1u) * HANDOFF_SPIN_LIMIT) {
                 __hip_atomic_store(tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
         }
-        if (spins < 8u) __builtin_amdgcn_s_sleep(8);
+        if (FEW_WAITERS || spins < 8u) __builtin_amdgcn_s_sleep(FEW_WAITERS ? 2 : 8);
         else __builtin_amdgcn_s_sleep(64);
     }
     return true;

@@ -89,12 +89,34 @@ def cpu_threads():
     return max(1, min(int(os.environ.get("GVX_CPU_THREADS", "16")), os.cpu_count() or 1, len(os.sched_getaffinity(0))))
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT loading the HIP runtime (the parent of the self-launch must never touch it: on
+    this pool a process that initialised HIP must not start another program).  Counts the KFD topology nodes that have SIMDs
+    (CPU nodes have none), capped by the first *_VISIBLE_DEVICES list that is set."""
+    import glob
+
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(prop) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+            break
+    return n
+
+
 def self_launch(args):
     """--gpus N without a launcher: start torch.distributed.run as a CHILD (this process has not touched the GPU and never
     will: on this pool a process that initialised HIP must not exec another program) and relay its exit code."""
-    import torch
-
-    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    have = visible_gpu_count()
     if have < (1 if args.rehearse_one_gpu else args.gpus):
         raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible on this node")
     s = socket.socket()
@@ -184,12 +206,21 @@ def main():
 
     log(f"rank {rank}: weights bound, inputs resident; warmup {args.warmup}")
     model.enable_stage_timing(True)   # 6 HIP event records per forward, on the launch stream, inside the timed region
+    # Reference run for the validation of the timed region's outputs: the Prenet masks of a forward are drawn on the device
+    # from a seed taken from torch's CPU generator, so the same manual_seed in front of the LAST timed forward must give
+    # the same outputs bit for bit (fixed reduction orders everywhere); the oracle pins this path in tests/, not here.
+    VALID_SEED = 1234567 + rank
+    torch.manual_seed(VALID_SEED)
+    ref = {k: v.clone() for k, v in model.forward(batch).items()}
+    model.check_status()
     for _ in range(max(args.warmup, 0)):
         model.forward(batch)
     sync_all()
     log("timed region")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            torch.manual_seed(VALID_SEED)
         out = model.forward(batch)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -197,8 +228,13 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the slowest rank defines the job's time
         elapsed = float(t.item())
+    model.check_status()   # raises if a hand-off of the resident-attention loop timed out (outputs would be NaN) or a token id was bad
     assert torch.isfinite(out["mel_outputs_postnet"]).all()
-    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
+    validated = all(torch.equal(out[k], ref[k]) for k in ref)
+    if not validated:
+        raise SystemExit("bench.py: the last timed forward does not reproduce the un-timed reference run bit for bit")
+    del ref
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps; outputs of the last timed forward validated")
 
     def lstm_roofline(m, b, batch_b, loop_ms):
         """HBM and MFMA fractions of the decoder LSTM step launch at batch b (instrumented pass, see module docstring)."""
@@ -262,25 +298,74 @@ def main():
                "sample": f"oracle teacher-forced forward, batch {B} x {Tc} frames x {L} tokens (first {Tc} of {T} frames), "
                          f"{cpu_s:.1f} s, torch {torch.__version__} CPU"}
 
-    # ---- the other BASELINE configurations (rank 0, N = 1 only)
+    audio_s_per_frame = ac.hop_length / ac.sampling_rate
+
+    def ar_leg(bb, reps=3):
+        """Autoregressive decode of bb rows x max_decoder_steps (the gate never fires): seconds per batch."""
+        mc.gate_threshold = 1.0   # never fires: exactly max_decoder_steps frames (BASELINE configs[2])
+        tok = torch.from_numpy(gw.synthetic_inputs(bb, L, 8, tc.n_tokens, ac.n_mels, seed=3 + rank)["token_padded"]).to(dev)
+        with contextlib.redirect_stdout(sys.stderr):   # "Warning! Reached max decoder steps" must not land next to the JSON line
+            dt = timed(torch, lambda: model.inference({"tokens": tok}), 2, reps)
+        mc.gate_threshold = 0.5
+        model.check_status()
+        return dt, tok
+
+    def ar_entry(dt, bb, n_streams):
+        S = mc.max_decoder_steps
+        return {"us_per_step": round(dt / S * 1e6, 2), "ms_per_utterance_batch": round(dt * 1e3, 2),
+                "rtf_per_stream": round(dt / (S * audio_s_per_frame), 6), "rtf_aggregate": round(dt / (S * audio_s_per_frame * n_streams), 7),
+                "mel_frames_per_s": round(n_streams * S / dt, 1), "includes": "encoder + 1000 decoder steps + Postnet, host stop polling"}
+
+    # ---- N > 1: the second line SURVEY.md section 8d asks of the sharded configuration - autoregressive decode, 64 rows per
+    # rank, all ranks at once (barrier on both sides, slowest rank defines the time)
     extra = None
+    if world > 1 and not args.no_extra:
+        sync_all()
+        dt, _ = ar_leg(64)
+        sync_all()
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            extra = {"ar_b64_1000_per_rank": {**ar_entry(float(t.item()), 64, 64 * world), "ranks": world,
+                                              "note": "64 rows per rank decoded concurrently on every rank; rtf_aggregate / mel_frames_per_s are whole-job figures"}}
+
+    # ---- the other BASELINE configurations (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_extra:
-        want = set(filter(None, args.only_extra.split(","))) or {"tf_b64x800", "ar_b64_1000", "ar_b1_1000", "postnet_b256x800",
+        want = set(filter(None, args.only_extra.split(","))) or {"c1_b1x568", "tf_b64x800", "ar_b64_1000", "ar_b1_1000", "postnet_b256x800",
                                                                   "gl_60it_b256x800"}
         with_cpu = not args.no_cpu_baseline
         extra = {"host_cpu": cpu_model, "cpu_threads": n_thr}
-        audio_s_per_frame = ac.hop_length / ac.sampling_rate
         if with_cpu:
             from oracle import audio_ref, tacotron2_ref
             if sd_cpu is None:
                 sd_cpu = gw.generate_state_dict(mc, ac, tc, seed=0)
             torch.set_num_threads(n_thr)
+        if "c1_b1x568" in want:   # BASELINE configs[0]: one LJSpeech-sized utterance, teacher-forced (SURVEY.md section 8d C1)
+            log("extra: teacher-forced single utterance, 1 x 568 frames, 100 tokens")
+            L1, T1 = 100, 568
+            c1 = {k: torch.from_numpy(v).to(dev) for k, v in gw.synthetic_inputs(1, L1, T1, tc.n_tokens, ac.n_mels, seed=3).items()}
+            dt = timed(torch, lambda: model.forward(c1), 2, args.steps)
+            model.check_status()
+            e = {"ms_per_utterance": round(dt * 1e3, 3), "mel_frames_per_s": round(T1 / dt, 1),
+                 "rtf": round(dt / (T1 * audio_s_per_frame), 6), "steps": args.steps,
+                 "workload": f"Tacotron2.forward, batch 1 x {T1} frames, {L1} tokens (BASELINE configs[0], an average LJSpeech clip)"}
+            if with_cpu:
+                cb = {k: v.cpu() for k, v in c1.items()}
+                masks = torch.from_numpy(gw.prenet_keep_masks(T1 + 1, mc.prenet_dim))
+                c0 = time.perf_counter()
+                tacotron2_ref.tacotron2_forward(sd_cpu, cb, masks, mask_padding=True)
+                cs = time.perf_counter() - c0
+                e["cpu_baseline"] = {"ms_per_utterance": round(cs * 1e3, 1), "mel_frames_per_s": round(T1 / cs, 1), "cores": n_thr, "kind": "port",
+                                     "sample": f"oracle teacher-forced forward of the whole utterance (1 x {T1} frames), torch {torch.__version__} CPU"}
+            extra["c1_b1x568"] = e
+            del c1
         if "tf_b64x800" in want:   # the north_star's target batch
             log("extra: teacher-forced batch 64 x 800")
             b64 = {k: torch.from_numpy(v).to(dev) for k, v in gw.synthetic_inputs(64, L, T, tc.n_tokens, ac.n_mels, seed=3).items()}
             model.enable_stage_timing(True)
             dt = timed(torch, lambda: model.forward(b64), 2, args.steps)
-            st64, _ = model.stage_times_ms()
+            model.check_status()
+            st64, _ = model.stage_times_ms(lane=0)
             model.enable_stage_timing(False)
             # 64 rows run as two 32-row chunks on two HIP streams at once (genvox_amd/tacotron2.py STREAM_ROWS): the kernel that
             # runs is the 32-row launch, measured above; what changes is how many launches the chip overlaps
@@ -294,15 +379,8 @@ def main():
             if key not in want:
                 continue
             log(f"extra: autoregressive batch {bb} x {mc.max_decoder_steps} steps")
-            mc.gate_threshold = 1.0   # never fires: exactly max_decoder_steps frames (BASELINE configs[2])
-            tok = torch.from_numpy(gw.synthetic_inputs(bb, L, 8, tc.n_tokens, ac.n_mels, seed=3)["token_padded"]).to(dev)
-            with contextlib.redirect_stdout(sys.stderr):   # "Warning! Reached max decoder steps" must not land next to the JSON line
-                dt = timed(torch, lambda: model.inference({"tokens": tok}), 2, 3)
-            mc.gate_threshold = 0.5
-            S = mc.max_decoder_steps
-            e = {"us_per_step": round(dt / S * 1e6, 2), "ms_per_utterance_batch": round(dt * 1e3, 2),
-                 "rtf_per_stream": round(dt / (S * audio_s_per_frame), 6), "rtf_aggregate": round(dt / (S * audio_s_per_frame * bb), 7),
-                 "mel_frames_per_s": round(bb * S / dt, 1), "includes": "encoder + 1000 decoder steps + Postnet, host stop polling"}
+            dt, tok = ar_leg(bb)
+            e = ar_entry(dt, bb, bb)
             if with_cpu and bb == 1:
                 steps_c = 40
                 masks = torch.from_numpy(gw.prenet_keep_masks(steps_c, mc.prenet_dim, seed=11)).reshape(2, steps_c, mc.prenet_dim)
@@ -317,6 +395,7 @@ def main():
             log("extra: Postnet batch 256 x 800 (one call)")
             mel = torch.randn(256, ac.n_mels, T, device=dev)
             dt = timed(torch, lambda: model.postnet_residual(mel), 1, 3)
+            model.check_status()
             flops = 8.68e6 * 256 * T   # 8.68 MFLOP per frame
             e = {"ms": round(dt * 1e3, 3), "tflops": round(flops / dt / 1e12, 1), "mfma_frac_of_157TF": round(flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                  "frames_per_s": round(256 * T / dt, 1), "note": "whole call incl. the two layout transposes and the residual"}
@@ -363,7 +442,9 @@ def main():
             "config": {"workload": f"Tacotron2 teacher-forced forward, batch {B} x {T} mel frames x 80 bins, {L} tokens, per GPU "
                                    f"(BASELINE configs[1]); random-init default dims, seed 0",
                        "global_batch": world * B, "frames": T, "tokens": L, "parallelism": f"dp{world} (independent batches, one RCCL weight broadcast)"},
-            "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages, "extra": extra,
+            "roofline": roofline, "cpu_baseline": cpu, "stage_ms": stages,
+            "validated": "status words clear after the timed region; last timed forward bit-equal to an un-timed run with the same mask seed",
+            "extra": extra,
         }
         if args.rehearse_one_gpu:
             line["rehearsal"] = f"{world} ranks sharing ONE GPU over gloo: flow check only, not a scaling measurement"

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         // ---- query: the slabs of step t are plain stores of launch t; launch t + 1 (or the drain launch) adds 1 to the counter
         // when it STARTS, i.e. after launch t has completed and its stores have been written back (count t + 2: launch 0
         // adds too).  Then sum the partial slabs (fixed order)
-        if (tid == 0) handoff_wait<true>(cnt_q, (unsigned)(t + 2), tmo, 0x100u + (unsigned)b);
+        if (tid == 0) handoff_wait<true>(cnt_q, (unsigned)(t + 2), tmo, 0x100u + (unsigned)b, p.spin_limit);
         __syncthreads();
         PA_STAMP(1);
         int tq = tid;

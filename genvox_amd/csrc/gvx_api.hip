@@ -132,6 +132,10 @@ struct gvx_model {
     // teacher-forced loop: attention as one kernel that lives beside the LSTM launches (attn_persist.hip) when the shape
     // allows it; GVX_ATTN_PERSISTENT=0 keeps the launch per step
     bool attn_persistent = true;
+    int pa_depth = 4;                  // GVX_PA_DEPTH=6: prefetch depth of the launch beside the resident kernel (tests, A/B runs)
+    unsigned spin_limit = 0;           // GVX_HANDOFF_SPIN_LIMIT: polls before an in-launch wait gives up (0 = the built-in limit)
+    bool debug_skip_resident = false;  // GVX_DEBUG_SKIP_RESIDENT=1: never launch the resident attention kernel, so that every
+                                       // wait of the loop runs into its limit (test of the time-out reporting only)
     hipStream_t pa_stream = nullptr;
     hipEvent_t pa_fork = nullptr, pa_join = nullptr;
     void drop_graphs() {
@@ -198,7 +202,17 @@ Blob make_blob_layout(const gvx_dims& d) {
     return b;
 }
 
-WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
+bool persistent_path(const gvx_model* m, int B, int L);
+
+enum WsMode : int { WS_TEACHER_FORCED = 0, WS_AUTOREGRESSIVE = 1 };
+
+// status words at the front of every workspace (int32 indices into `flags`)
+constexpr int FLAG_TOKEN = 0;      // sticky: a token id was outside the embedding table
+constexpr int FLAG_AR_DONE = 1;    // autoregressive loop: rows finished
+constexpr int FLAG_TIMEOUT = 2;    // sticky: a teacher-forced call ended with its hand-off time-out word set
+constexpr int FLAG_AR_FRAMES = 64; // autoregressive loop: frame counts [B <= 64]
+
+WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T, int mode = WS_TEACHER_FORCED) {
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, H = E / 2, M = d.n_mels, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim;
     const int pe = (d.enc_kernel - 1) / 2, pp = (d.postnet_kernel - 1) / 2;
@@ -206,7 +220,7 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     size_t off = 0;
     auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
     // status words first, at a shape-independent offset (gvx_workspace_status)
-    w.flags = take(128);  // [0] token error, [1] AR rows done, [64..64+B) AR frame counts
+    w.flags = take(128);  // FLAG_* words; the sticky ones are only cleared by gvx_workspace_status
     w.sync = take(HANDOFF_WORDS);   // hand-off words of the persistent attention kernel (zeroed before every decoder loop)
     w.xa = take((size_t)B * (L + 2 * pe) * E);
     w.xb = take((size_t)B * (L + 2 * pe) * E);
@@ -234,7 +248,8 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T) {
     w.att_part = take((size_t)B * 4 * A);            // autoregressive mode: partial gate pre-activations [B][4A] / [B][4D] of the
     w.dec_part = take((size_t)B * 4 * D);            //   column slices that are known one launch early
     // teacher-forced loop beside the persistent attention kernel: Prenet contribution to the attention LSTM's gates, all steps
-    w.pre_gate = take(B <= 32 ? (size_t)T * B * 4 * A : 0);
+    // (only where that loop can run: 0.5 GB at B = 32, T = 1000 that the autoregressive / launch-per-step paths never touch)
+    w.pre_gate = take(mode == WS_TEACHER_FORCED && persistent_path(m, B, L) ? (size_t)T * B * 4 * A : 0);
     w.ar_masks = take(((size_t)2 * T * B * P + 3) / 4);  // autoregressive mode: keep masks copied next to the graphs' operands (bytes)
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
@@ -399,6 +414,14 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     if (const char* e = std::getenv("GVX_GRAPH_FIRST")) m->capture_first = e[0] == '1';
     if (const char* e = std::getenv("GVX_ATTN_SPLIT")) m->attn_one_launch = !(e[0] == '1');
     if (const char* e = std::getenv("GVX_ATTN_PERSISTENT")) m->attn_persistent = !(e[0] == '0');
+    // the resident attention kernel and the launches it feeds must run at the same time: under kernel serialisation every
+    // hand-off would run into its limit
+    for (const char* name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"})
+        if (const char* e = std::getenv(name))
+            if (e[0] != '\0' && e[0] != '0') m->attn_persistent = false;
+    if (const char* e = std::getenv("GVX_PA_DEPTH")) m->pa_depth = std::atoi(e) == 6 ? 6 : 4;
+    if (const char* e = std::getenv("GVX_HANDOFF_SPIN_LIMIT")) m->spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("GVX_DEBUG_SKIP_RESIDENT")) m->debug_skip_resident = e[0] == '1';
     *out = m;
     return GVX_OK;
 }
@@ -548,19 +571,24 @@ size_t gvx_workspace_bytes(const gvx_model* m, int B, int L, int T) {
     return make_ws_plan(m, B, L, T).total;
 }
 
+size_t gvx_workspace_bytes_autoregressive(const gvx_model* m, int B, int L, int max_steps) {
+    if (!m || B < 1 || L < 1 || max_steps < 1) return 0;
+    return make_ws_plan(m, B, L, max_steps, WS_AUTOREGRESSIVE).total;
+}
+
 }  // extern "C"
 
 // =====================================================================================================
 namespace {
 
-int check_common(const gvx_model* m, int B, int L, int T, void* ws, size_t ws_bytes) {
+int check_common(const gvx_model* m, int B, int L, int T, void* ws, size_t ws_bytes, int mode = WS_TEACHER_FORCED) {
     if (!m) return fail(GVX_ERR_INVALID_ARG, "null model");
     if (!m->dev_blob) return fail(GVX_ERR_STATE, "weights not bound (call gvx_model_bind_blob)");
     if (B < 1 || B > 64) return fail(GVX_ERR_UNSUPPORTED, "batch %d not in [1, 64] (shard larger batches across calls / GPUs)", B);
     if (L < 1 || T < 1) return fail(GVX_ERR_INVALID_ARG, "L and T must be >= 1");
     if (!ws) return fail(GVX_ERR_WORKSPACE, "null workspace");
     if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(GVX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
-    const size_t need = make_ws_plan(m, B, L, T).total;
+    const size_t need = make_ws_plan(m, B, L, T, mode).total;
     if (ws_bytes < need) return fail(GVX_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
     if (!attention_supported(L, m->d.att_dim, m->d.att_loc_filters, m->d.att_loc_kernel, m->d.embed_dim))
         return fail(GVX_ERR_UNSUPPORTED, "L = %d is too long for the attention kernels' LDS budget", L);
@@ -594,8 +622,9 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
     const size_t xbytes = (size_t)B * (L + 2 * pe) * E * sizeof(float);
     HIP_TRY(zero_async(xa, xbytes, s));
     HIP_TRY(zero_async(xb, xbytes, s));
-    HIP_TRY(zero_async(flags, sizeof(int), s));
-    HIP_TRY(launch_embed(tokens, m->dev_blob + m->blob.emb, d.n_tokens, xa, B, L, E, pe, flags, s));
+    // (the token-error word is sticky: raised here, cleared only by gvx_workspace_status - a later chunk on the same
+    // workspace must not wipe an earlier chunk's error)
+    HIP_TRY(launch_embed(tokens, m->dev_blob + m->blob.emb, d.n_tokens, xa, B, L, E, pe, flags + FLAG_TOKEN, s));
     float* cur = xa;
     float* nxt = xb;
     for (int i = 0; i < d.enc_n_conv; ++i) {
@@ -866,6 +895,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
             J.addend = db.pre_gate + (size_t)(t_ctx + 1) * B * 4 * A; J.add_bs = 4 * A;
         }
         J.tmo = sync + HANDOFF_TIMEOUT;
+        J.spin_limit = m->spin_limit;
         if (t_ctx >= 0) { J.ctx_cnt = sync + HANDOFF_CNT_CTX; J.ctx_target = (unsigned)B * (unsigned)(t_ctx + 1); }
         J.start_cnt = sync + HANDOFF_CNT_Q;   // every launch of the loop (and the drain launch) announces its start
         if (first) { J.ready_cnt = sync + HANDOFF_READY; J.ready_target = (unsigned)B; }
@@ -883,7 +913,8 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         pp.w_out = db.align_tm; pp.w_out_bs = (long)L; pp.w_out_ts = (long)B * L;
         pp.ctx_base = db.hc + (size_t)B * (D + E) + (size_t)D * B; pp.ctx_ts = (long)B * (D + E);   // slot t + 1
         pp.sync = sync; pp.B = B; pp.L = L; pp.T = T; pp.kl = d.att_loc_kernel;
-        HIP_TRY(launch_attention_persistent(pp, m->pa_stream));
+        pp.spin_limit = m->spin_limit;
+        if (!m->debug_skip_resident) HIP_TRY(launch_attention_persistent(pp, m->pa_stream));
         HIP_TRY(hipEventRecord(m->pa_join, m->pa_stream));
         return GVX_OK;
     };
@@ -897,7 +928,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
                 defer(jobs[1], t - 1, false);
             }
             if (pa) {
-                HIP_TRY(launch_skinny_pa(jobs[0], t > 0 ? &jobs[1] : nullptr, st));
+                HIP_TRY(launch_skinny_pa(jobs[0], t > 0 ? &jobs[1] : nullptr, st, m->pa_depth));
                 ++launches;
                 continue;
             }
@@ -921,7 +952,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         if (rc != GVX_OK) return rc;
     }
     if (m->use_graph && !kt) {
-        const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr, 0.f, pa ? 1 : 0};
+        const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr, 0.f, pa ? m->pa_depth : 0};
         rc = run_chunk(m, touch_graph_set(m, m->loop_graphs, key), 0, s, enqueue_loop);
         if (rc != GVX_OK) return rc;
         launches = pa ? T + 1 : (m->attn_one_launch ? 2 : 3) * T + 1;
@@ -950,7 +981,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
             if (tm > 0) defer(jobs[1], tm - 1, false);
             jobs[0].start_cnt = jobs[1].start_cnt = nullptr;
             HIP_TRY(hipEventRecord(m->kev[0], s));
-            for (int i = 0; i < REPS; ++i) HIP_TRY(launch_skinny_pa(jobs[0], tm > 0 ? &jobs[1] : nullptr, s));
+            for (int i = 0; i < REPS; ++i) HIP_TRY(launch_skinny_pa(jobs[0], tm > 0 ? &jobs[1] : nullptr, s, m->pa_depth));
             HIP_TRY(hipEventRecord(m->kev[1], s));
             HIP_TRY(hipEventRecord(m->kev[2], s));
             m->n_lstm_ev = REPS;
@@ -1022,6 +1053,16 @@ int postnet_impl(gvx_model* m, const float* mel_in, const int32_t* mel_lengths, 
     return GVX_OK;
 }
 
+// A hand-off time-out of the resident-attention loop must not return numbers that look like results: the call's last
+// launch writes NaN over every output and raises the workspace's sticky status word when the time-out word is set
+// (no host synchronisation; a no-op of one word read per workgroup otherwise).  gvx_workspace_status reports it.
+int poison_if_timed_out(const gvx_model* m, int B, int L, void* ws, const WsPlan& wp, float* const* outs, const size_t* counts, int n,
+                        hipStream_t s) {
+    if (!persistent_path(m, B, L)) return GVX_OK;   // no in-launch hand-off on the other paths
+    HIP_TRY(launch_poison_on_timeout(ws_ptr<unsigned>(ws, wp.sync) + HANDOFF_TIMEOUT, ws_ptr<int>(ws, wp.flags) + FLAG_TIMEOUT, outs, counts, n, s));
+    return GVX_OK;
+}
+
 struct PostnetPlan { size_t ya, yb, total; };
 PostnetPlan make_postnet_plan(const gvx_model* m, int B, int T) {
     const gvx_dims& d = m->d;
@@ -1045,27 +1086,34 @@ int gvx_model_set_persistent_attention(gvx_model* m, int enable) {
     return GVX_OK;
 }
 
-int gvx_workspace_status(const gvx_model* m, const void* ws, size_t ws_bytes, void* stream, int32_t* host_out) {
+int gvx_workspace_status(const gvx_model* m, void* ws, size_t ws_bytes, void* stream, int32_t* host_out) {
     if (!m || !ws || !host_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
-    const WsPlan wp = make_ws_plan(m, 1, 1, 1);   // the status words sit in front of every shape-dependent region
-    if (ws_bytes < wp.flags + sizeof(int32_t)) return fail(GVX_ERR_WORKSPACE, "workspace too small");
-    int32_t h = 0, tmo = 0;
-    HIP_TRY(hipMemcpyAsync(&h, reinterpret_cast<const char*>(ws) + wp.flags, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    const WsPlan wp = make_ws_plan(m, 1, 1, 1, WS_AUTOREGRESSIVE);   // the status words sit in front of every shape-dependent region
+    if (ws_bytes < wp.flags + 4 * sizeof(int32_t)) return fail(GVX_ERR_WORKSPACE, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t h[4] = {0, 0, 0, 0}, tmo = 0;
+    int32_t* flags = ws_ptr<int32_t>(ws, wp.flags);
+    HIP_TRY(hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, s));
     if (ws_bytes >= wp.sync + HANDOFF_WORDS * sizeof(unsigned))   // (a Postnet-only workspace ends before the hand-off words)
         HIP_TRY(hipMemcpyAsync(&tmo, reinterpret_cast<const char*>(ws) + wp.sync + HANDOFF_TIMEOUT * sizeof(unsigned), sizeof tmo,
-                               hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    host_out[0] = h;
-    host_out[1] = tmo;
+                               hipMemcpyDeviceToHost, s));
+    // the sticky words accumulate over every call since the last look: reading them clears them
+    HIP_TRY(zero_async(flags + FLAG_TOKEN, sizeof(int32_t), s));
+    HIP_TRY(zero_async(flags + FLAG_TIMEOUT, sizeof(int32_t), s));
+    if (ws_bytes >= wp.sync + HANDOFF_WORDS * sizeof(unsigned))
+        HIP_TRY(zero_async(ws_ptr<unsigned>(ws, wp.sync) + HANDOFF_TIMEOUT, sizeof(unsigned), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    host_out[0] = h[FLAG_TOKEN];
+    host_out[1] = h[FLAG_TIMEOUT] ? h[FLAG_TIMEOUT] : tmo;
     return GVX_OK;
 }
 
 int gvx_encoder_forward(gvx_model* m, const int64_t* tokens, const int32_t* lengths, int B, int L, float* memory_out,
                         void* ws, size_t ws_bytes, void* stream) {
-    int rc = check_common(m, B, L, 1, ws, ws_bytes);
+    int rc = check_common(m, B, L, 1, ws, ws_bytes, WS_AUTOREGRESSIVE);   // (the encoder's buffers precede every mode-dependent one)
     if (rc != GVX_OK) return rc;
     if (!tokens || !memory_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
-    return encoder_impl(m, tokens, lengths, B, L, memory_out, ws, make_ws_plan(m, B, L, 1), (hipStream_t)stream);
+    return encoder_impl(m, tokens, lengths, B, L, memory_out, ws, make_ws_plan(m, B, L, 1, WS_AUTOREGRESSIVE), (hipStream_t)stream);
 }
 
 int gvx_decoder_teacher_forced(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
@@ -1074,8 +1122,12 @@ int gvx_decoder_teacher_forced(gvx_model* m, const float* memory, const int32_t*
     int rc = check_common(m, B, L, T, ws, ws_bytes);
     if (rc != GVX_OK) return rc;
     if (!memory || !mel_in || !keep_masks || !mel_out || !gate_out || !align_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
-    return decoder_tf_impl(m, memory, lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws,
-                           make_ws_plan(m, B, L, T), (hipStream_t)stream);
+    const WsPlan wp = make_ws_plan(m, B, L, T);
+    rc = decoder_tf_impl(m, memory, lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws, wp, (hipStream_t)stream);
+    if (rc != GVX_OK) return rc;
+    float* outs[3] = {mel_out, gate_out, align_out};
+    const size_t counts[3] = {(size_t)B * m->d.n_mels * T, (size_t)B * T, (size_t)B * T * L};
+    return poison_if_timed_out(m, B, L, ws, wp, outs, counts, 3, (hipStream_t)stream);
 }
 
 size_t gvx_postnet_workspace_bytes(const gvx_model* m, int B, int T) {
@@ -1142,6 +1194,11 @@ int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* to
     rc = postnet_impl(m, mel_out, nullptr, B, T, mel_post_out, ws_ptr<float>(ws, wp.ya), ws_ptr<float>(ws, wp.yb), s);
     if (rc != GVX_OK) return rc;
     if (mel_lengths) HIP_TRY(launch_mask_padding(mel_out, mel_post_out, gate_out, mel_lengths, B, m->d.n_mels, T, s));
+    float* outs[4] = {mel_out, mel_post_out, gate_out, align_out};
+    const size_t nm = (size_t)B * m->d.n_mels * T;
+    const size_t counts[4] = {nm, nm, (size_t)B * T, (size_t)B * T * L};
+    rc = poison_if_timed_out(m, B, L, ws, wp, outs, counts, 4, s);
+    if (rc != GVX_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(m->ev[5], s));
     return GVX_OK;
 }
@@ -1207,20 +1264,20 @@ int gvx_stage_times_ms(gvx_model* m, float* t5, int* launches) {
 int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, int max_steps,
                                float gate_threshold, const uint8_t* keep_masks, float* mel_out, float* gate_out, float* align_out,
                                int32_t* n_frames_out, int* steps_run_out, void* ws, size_t ws_bytes, void* stream) {
-    int rc = check_common(m, B, L, max_steps, ws, ws_bytes);
+    int rc = check_common(m, B, L, max_steps, ws, ws_bytes, WS_AUTOREGRESSIVE);
     if (rc != GVX_OK) return rc;
     if (!memory || !keep_masks || !mel_out || !gate_out || !align_out || !n_frames_out)
         return fail(GVX_ERR_INVALID_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim, T = max_steps;
-    const WsPlan wp = make_ws_plan(m, B, L, T);
+    const WsPlan wp = make_ws_plan(m, B, L, T, WS_AUTOREGRESSIVE);
     const DecoderBuffers db = decoder_buffers(ws, wp);
     HIP_TRY(zero_async(ws_ptr<unsigned>(ws, wp.sync), HANDOFF_WORDS * sizeof(unsigned), s));   // hand-off status of THIS call
     const int PSB = m->PSB();
     int32_t* flags = ws_ptr<int32_t>(ws, wp.flags);
-    int32_t* n_done = flags + 1;
-    int32_t* n_frames_ws = flags + 64;
+    int32_t* n_done = flags + FLAG_AR_DONE;
+    int32_t* n_frames_ws = flags + FLAG_AR_FRAMES;
     // Everything a step touches is moved next to the workspace so that the step launches only bake workspace addresses:
     // encoder output, token lengths and keep masks are copied in; alignments / per-step projections stay in workspace
     // buffers and are scattered to the caller's tensors once, after the loop.
@@ -1238,7 +1295,8 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     if (rc != GVX_OK) return rc;
     HIP_TRY(zero_async(db.prenet, (size_t)B * P * sizeof(float), s));       // Prenet of the go-frame: no biases, relu(W 0) = 0
     HIP_TRY(zero_async(db.att_part, (size_t)B * 4 * A * sizeof(float), s)); // ctx(-1) = h_a(-1) = 0
-    HIP_TRY(zero_async(flags + 1, (size_t)127 * sizeof(int32_t), s));       // n_done + frame counts
+    HIP_TRY(zero_async(n_done, sizeof(int32_t), s));                         // (the sticky status words in between stay)
+    HIP_TRY(zero_async(n_frames_ws, (size_t)64 * sizeof(int32_t), s));
 
     // One step = 5 launches.  In autoregressive mode BOTH cells are on the critical chain (the frame feeds back), and a cell
     // alone is only 128 tiles - half the chip.  But most of a cell's input is known one launch early: the attention LSTM's

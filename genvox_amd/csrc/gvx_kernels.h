@@ -94,6 +94,7 @@ struct SkinnyJob {
                                     // stored (its query slabs) has been written back by then
     const unsigned* ready_cnt; unsigned ready_target;   // a tile does not end before *ready_cnt >= ready_target (first launch)
     unsigned* tmo;                  // hand-off status word
+    unsigned spin_limit;            // polls before a wait gives up (0 = HANDOFF_SPIN_LIMIT)
     // --- linear epilogue
     float* y;               // blocked output [ceil(N/8)][B][8]
     const uint8_t* keep; long keep_stride;  // keep[b*stride + n]
@@ -116,7 +117,7 @@ enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_AR = 2 };  // kernel 
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc = nullptr);
 // teacher-forced step beside the persistent attention kernel: attention-LSTM (+ decoder-LSTM of the previous step) dealt to
 // 96 (224) workgroups of equal weight (skinny.hip); default layer sizes, B <= 32
-hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s);
+hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s, int depth = 4);
 
 // ---------------------------------------------------------------------------------------------
 // Location-sensitive attention, one decoder step, split over G workgroups per batch row:
@@ -148,7 +149,7 @@ bool attention_supported(int L, int a, int F, int kl, int E);
 
 // ---------------------------------------------------------------------------------------------
 // Persistent attention of the teacher-forced loop (attn_persist.hip): one workgroup per batch row lives for all T steps
-// beside the LSTM launches; hand-off words live in a 512-byte block of the workspace that is zeroed before every loop.
+// beside the LSTM launches; hand-off words live in a 16-KB block of the workspace (HANDOFF_WORDS words) that is zeroed before every loop.
 // ---------------------------------------------------------------------------------------------
 // word indices: 4 KB apart, so that the pollers of one word do not queue in front of another word's traffic at the same channel
 constexpr int HANDOFF_CNT_Q = 0, HANDOFF_CNT_CTX = 1024, HANDOFF_READY = 2048, HANDOFF_TIMEOUT = 3072;
@@ -162,6 +163,7 @@ struct AttnPersistParams {
     float* ctx_base; long ctx_ts;           // blocked context vector [E/8][B][8] of step t at ctx_base + t*ctx_ts
     unsigned* sync;                         // HANDOFF_WORDS words
     int B, L, T, kl;
+    unsigned spin_limit;                    // polls before a wait gives up (0 = HANDOFF_SPIN_LIMIT)
 };
 bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, int att_rnn_dim, int dec_rnn_dim);
 int attention_persistent_slabs();
@@ -185,7 +187,8 @@ __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, unsigned byt
 }
 // One lane waits until *cnt >= target.  Bounded; a timeout (or one raised by anybody else) makes every wait return at once.
 template <bool FEW_WAITERS = false>
-__device__ __forceinline__ bool handoff_wait(const unsigned* cnt, unsigned target, unsigned* tmo, unsigned code) {
+__device__ __forceinline__ bool handoff_wait(const unsigned* cnt, unsigned target, unsigned* tmo, unsigned code, unsigned limit = 0u) {
+    if (limit == 0u) limit = HANDOFF_SPIN_LIMIT;
     // Normally the word is there at the first look.  A waiter that is early backs off (up to ~2 us between polls): a launch has
     // ~220 waves that may wait on the same word, and their polls queue in front of the producer's own traffic.  FEW_WAITERS
     // (the 32 workgroups of the persistent attention kernel, which wait every step): poll every ~0.1 us instead - what they
@@ -195,7 +198,7 @@ __device__ __forceinline__ bool handoff_wait(const unsigned* cnt, unsigned targe
         ++spins;
         if ((spins & (FEW_WAITERS ? 127u : 7u)) == 1u) {   // (after a timeout every wait gives up at its first look)
             if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (spins > (FEW_WAITERS ? 16u : 1u) * HANDOFF_SPIN_LIMIT) {
+            if (spins > (FEW_WAITERS ? 16u : 1u) * limit) {
                 __hip_atomic_store(tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
@@ -226,6 +229,8 @@ hipError_t launch_residual_to_channels_first(const float* mel, const float* y, f
 hipError_t launch_zero_halo(float* buf, int B, int T, int halo, int C, hipStream_t s);
 hipError_t launch_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths, int B, int M, int T,
                                hipStream_t s);
+// if *tmo != 0 (a bounded in-launch wait of this call gave up): NaN over the n_arrays (<= 4) output arrays and *sticky = *tmo
+hipError_t launch_poison_on_timeout(const unsigned* tmo, int* sticky, float* const* ptrs, const size_t* counts, int n_arrays, hipStream_t s);
 // dst[b][t][:] = src[t][b][:]  (rows of n floats, n % 4 == 0 not required)
 hipError_t launch_permute01(const float* src, float* dst, int T, int B, int n, hipStream_t s);
 // Tacotron2Loss: out3 = {loss, mel_loss, gate_loss}; scratch = loss_scratch_bytes() of device memory (8-byte aligned)

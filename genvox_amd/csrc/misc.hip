@@ -177,6 +177,26 @@ hipError_t launch_mask_padding(float* mel, float* mel_post, float* gate, const i
     return hipGetLastError();
 }
 
+// ---- hand-off time-out made loud: NaN over every output of the call + a sticky status word -------------
+// Last launch of a teacher-forced call: when the call's hand-off time-out word (zeroed at the start of the call, raised by
+// a bounded in-launch wait that gave up) is set, the loop drained with wrong results - they must not look like results.
+struct PoisonArgs { float* p[4]; size_t n[4]; };
+__global__ void poison_on_timeout_kernel(const unsigned* tmo, int* sticky, PoisonArgs a) {
+    const unsigned code = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (code == 0u) return;   // the normal case: one word read per workgroup
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sticky = (int)code;
+    const float nan = __int_as_float(0x7fc00000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.n[i]; k += (size_t)gridDim.x * blockDim.x) a.p[i][k] = nan;
+}
+hipError_t launch_poison_on_timeout(const unsigned* tmo, int* sticky, float* const* ptrs, const size_t* counts, int n_arrays, hipStream_t s) {
+    PoisonArgs a{};
+    for (int i = 0; i < 4; ++i) { a.p[i] = i < n_arrays ? ptrs[i] : nullptr; a.n[i] = i < n_arrays && ptrs[i] ? counts[i] : 0; }
+    hipLaunchKernelGGL(poison_on_timeout_kernel, dim3(64), dim3(256), 0, s, tmo, sticky, a);
+    return hipGetLastError();
+}
+
 // ---- Prenet keep masks: Bernoulli(0.5) bytes from a splitmix64 counter hash --------------------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;

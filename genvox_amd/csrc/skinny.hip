@@ -227,6 +227,17 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         }
     }
 
+    // Query-slab weights of this wave's 32 attention dims (MFMA form of the slab phase, one batch tile only): fetched now
+    // as well - loaded after the cells they were a dependent global round trip at the end of the launch's slowest workgroups
+    const bool slab_mfma = MT == 1 && J.mode == 0 && J.q_slab && (J.att_dim & 31) == 0 && (J.att_dim >> 5) <= SK_WAVES;
+    float4 wq_a = make_float4(0.f, 0.f, 0.f, 0.f), wq_b = wq_a, wq_c = wq_a;
+    if (slab_mfma && wave < (J.att_dim >> 5)) {
+        const float* wq_l = J.Wq_t + ((long)tile * J.att_dim + 32 * wave + bl) * 8;
+        wq_a = *reinterpret_cast<const float4*>(wq_l);
+        wq_b = *reinterpret_cast<const float4*>(wq_l + 4);
+        if (XH && has_x) wq_c = *reinterpret_cast<const float4*>(J.Wq_t + ((long)xt * J.att_dim + 32 * wave + bl) * 8 + 4 * xhalf);
+    }
+
     // ---- main loop: this wave's K slice, software pipelined DEPTH k-groups deep.
     // Per k-group a wave issues one 1-KiB weight load (HBM / Infinity Cache) and MT 1-KiB x-loads (L2); with DEPTH
     // groups in flight per wave and 8 waves per CU about DEPTH*8 KiB of weights are outstanding per CU, which is
@@ -311,7 +322,11 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             if (XH && has_x) wv2[slot] = wp2[(long)g_ * 64];                                         \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xv[mt][slot] = XLOAD(mt, g_);           \
         }
-#define SK_MFMA(slot)                                                                                  \
+/* ONE statement (braces): the drain pass guards it with `if (u < rem)`.  As two statements the guard covered only the    */
+/* 32x32 loop and the half tile's MFMAs ran on stale slots whenever rem < DEPTH - never at depth 4 with the K slices of */
+/* the default layer sizes (16 and 8 k-groups per wave), always at depth 5 / 6: round 2's "depth 5 / 6 gives wrong      */
+/* results in the 48-row workgroups" (tests/test_parity_gpu.py::test_persistent_attention_depth6)   */
+#define SK_MFMA(slot) {                                                                                \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                               \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].x, xv[mt][slot].x, acc[mt], 0, 0, 0); \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].y, xv[mt][slot].y, acc[mt], 0, 0, 0); \
@@ -329,7 +344,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(w2_.y, xv[0][slot].y, acc2, 0, 0, 0);             \
             acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(w2_.z, xv[0][slot].z, acc2, 0, 0, 0);             \
             acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(w2_.w, xv[0][slot].w, acc2, 0, 0, 0);             \
-        }
+        } }
 #define SK_X_PLAIN(mt, g) (*reinterpret_cast<const float4*>(((g) < g0 ? xb0[mt] : ((g) < g1 ? xb1[mt] : xb2[mt])) + (long)(g) * blk))
 #define SK_MAP_ID(s) (s)
     if (!DEFER || !J.defer_seg) {   // (DEFER is a template parameter so that the ordinary kernels do not carry the code below)
@@ -351,11 +366,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             // loads only: the bytes were stored write-through by another kernel, a plain load could hit a stale L1 / L2 line
             volatile int* seen = reinterpret_cast<volatile int*>(hs) + MT * 32 * 8 - 1;   // last word of hs (free until the epilogue)
             if (wave == 0) {
-                handoff_wait(J.ctx_cnt, J.ctx_target, J.tmo, 0x200u);
+                handoff_wait(J.ctx_cnt, J.ctx_target, J.tmo, 0x200u, J.spin_limit);
                 *seen = 1;
             } else {
-                unsigned spins = 0;
-                while (*seen == 0 && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
+                // no bound of its own: wave 0 sets the word after ITS bounded wait in every case (with a bound here a wave
+                // could give up before wave 0 does and read a context that has not arrived, unreported)
+                while (*seen == 0) __builtin_amdgcn_s_sleep(4);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the compiler from moving the loads above the poll
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(J.x[1].p);
@@ -498,6 +514,39 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         const float* wq = J.Wq_t + (long)tile * a * 8;
         const float* wq2 = J.Wq_t + (long)(has_x ? xt : tile) * a * 8 + 4 * xhalf;
         const int slab = (XH && jobs.pa_layout) ? (int)blockIdx.x : tile;   // one slab per workgroup
+        if (slab_mfma) {
+            // slab[b][d] = sum_j h'[b][j] Wq[d][j] over the workgroup's 8 (12) hidden units on the matrix pipe: wave w takes
+            // the attention dims 32 w .. 32 w + 31.  v_mfma_f32_32x32x2_f32 with A = h' (lane (b, kh): h'[b][2 s + kh]) and
+            // B = Wq^T (lane (d, kh): Wq[d][2 s + kh]); lane (d, hh) receives D[b = 8 g + 4 hh + r][d] in register 4 g + r,
+            // so every store instruction writes two rows of 32 consecutive floats.  The sum runs over j in index order,
+            // the chain the VALU form used (which took ~2 us of dependent FMAs and LDS reads here).
+            if (wave < (a >> 5)) {
+                f32x16 qa;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) qa[q] = 0.f;
+                const float* hrow = hs + bl * 8 + h;
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[0], h ? wq_a.y : wq_a.x, qa, 0, 0, 0);
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[2], h ? wq_a.w : wq_a.z, qa, 0, 0, 0);
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[4], h ? wq_b.y : wq_b.x, qa, 0, 0, 0);
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[6], h ? wq_b.w : wq_b.z, qa, 0, 0, 0);
+                if (XH && has_x) {
+                    const float* hrow2 = hs2 + bl * 4 + h;
+                    qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow2[0], h ? wq_c.y : wq_c.x, qa, 0, 0, 0);
+                    qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow2[2], h ? wq_c.w : wq_c.z, qa, 0, 0, 0);
+                }
+                float* qout = J.q_slab + (long)slab * B * a + 32 * wave + bl;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int b = 8 * g + 4 * h + r;
+                        if (b < B) qout[(long)b * a] = qa[4 * g + r];
+                    }
+            }
+            if (J.ready_cnt && tid == 0) handoff_wait(J.ready_cnt, J.ready_target, J.tmo, 0x300u, J.spin_limit);
+            if (jobs.njobs >= 2) GVX_STAMP(0, 4);
+            return;
+        }
         // a thread keeps its attention dim d over the passes when the thread count is a multiple of a: the weights are loaded
         // once (they were re-loaded per value, one dependent round trip each: 3 us in the 12-unit workgroups)
         const bool fixed_d = (SK_THREADS % a) == 0;
@@ -540,7 +589,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         }
         // first launch beside the persistent attention kernel: do not end before that kernel is resident (afterwards this
         // launch's successors would fill every CU)
-        if (J.ready_cnt && tid == 0) handoff_wait(J.ready_cnt, J.ready_target, J.tmo, 0x300u);
+        if (J.ready_cnt && tid == 0) handoff_wait(J.ready_cnt, J.ready_target, J.tmo, 0x300u, J.spin_limit);
     }
     if (jobs.njobs >= 2) GVX_STAMP(0, 4);   // (stamps build: the single-job drain launch must not overwrite a step's stamps)
 }
@@ -563,9 +612,11 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_ste
     GVX_WG_END();
 }
 // teacher-forced step beside the persistent attention kernel (224 / 96 workgroups, no location workgroups)
-__global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_pa_kernel(SkinnyJobs jobs) {
+// DEPTH: k-groups in flight per wave.  4 ships; 6 is kept selectable (GVX_PA_DEPTH=6) because it is the configuration that
+// exposed the drain-pass bug of the half tiles (see SK_MFMA) and the parity suite runs it.
+template <int DEPTH> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_pa_kernel(SkinnyJobs jobs) {
     GVX_WG_BEGIN();
-    skinny_body<1, SK_DEPTH1, true, true>(jobs);
+    skinny_body<1, DEPTH, true, true>(jobs);
     GVX_WG_END();
 }
 // the launch that drains the loop (decoder-LSTM of the last step): ordinary layout, context handed over in-launch
@@ -590,13 +641,14 @@ hipError_t skinny_init() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_lstm_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_lstm_step_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel<SK_DEPTH1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
     if ((e = set_lds(decoder_lstm_drain_pa_kernel, 1)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
     return set_lds(encoder_lstm_step_kernel<2>, 2);
 }
 
-hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s) {
+hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s, int depth) {
     // the layout is built for the default layer sizes: 128 tiles per cell, batch rows in one MFMA tile
     if (att.N != 4096 || att.B < 1 || att.B > 32 || att.mode != 0 || !att.q_slab || (dec && (dec->N != 4096 || dec->B != att.B || dec->mode != 0)))
         return hipErrorInvalidValue;
@@ -606,7 +658,8 @@ hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStrea
     js.tiles0 = 128; js.tiles1 = dec ? 128 : 0; js.tiles = js.tiles0 + js.tiles1;
     js.loc = LocJob{};
     js.pa_layout = 1;
-    decoder_lstm_step_pa_kernel<<<dim3(dec ? 224 : 96), dim3(SK_THREADS), skinny_pa_lds(), s>>>(js);
+    if (depth == 6) decoder_lstm_step_pa_kernel<6><<<dim3(dec ? 224 : 96), dim3(SK_THREADS), skinny_pa_lds(), s>>>(js);
+    else decoder_lstm_step_pa_kernel<SK_DEPTH1><<<dim3(dec ? 224 : 96), dim3(SK_THREADS), skinny_pa_lds(), s>>>(js);
     return hipGetLastError();
 }
 

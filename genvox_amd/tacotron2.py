@@ -85,6 +85,7 @@ class Tacotron2(nn.Module):
                     t.zero_()
                 node.register_parameter(leaf, nn.Parameter(t, requires_grad=False))
         self._handle: Optional[int] = None
+        self._key_tensors = None
         self._blob: Optional[torch.Tensor] = None
         self._packed_key = None
         self._workspace: Optional[torch.Tensor] = None
@@ -127,8 +128,17 @@ class Tacotron2(nn.Module):
         return dev
 
     def _weights_key(self):
-        sd = self.state_dict()
-        return (str(self._device()),) + tuple((v.data_ptr(), v._version) for v in sd.values())
+        """Identity + version of every weight tensor.  Walks a cached list of the parameter / buffer objects (forward()
+        calls this: building a state_dict per call cost ~0.3 ms of host time inside the timed region)."""
+        ts = self._key_tensors
+        if ts is None:
+            ts = self._key_tensors = [v for v in self.state_dict(keep_vars=True).values()]
+        return (str(self._device()),) + tuple((v.data_ptr(), v._version) for v in ts)
+
+    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda(): parameter objects may be replaced
+        out = super()._apply(fn, *args, **kwargs)
+        self._key_tensors = None
+        return out
 
     def _ensure_handle(self) -> int:
         if self._handle is None:
@@ -212,9 +222,11 @@ class Tacotron2(nn.Module):
         return ws
 
     def check_status(self) -> None:
-        """Read the device-side status word of the last calls (synchronises the stream): raises IndexError for a token
-        id outside the embedding table, which is what nn.Embedding does in the reference (models/tts/tacotron2.py:459).
-        Not called by forward(): one check after a batch of calls is enough."""
+        """Read and clear the sticky device-side status words of every call since the last check (synchronises the stream):
+        raises IndexError for a token id outside the embedding table, which is what nn.Embedding does in the reference
+        (models/tts/tacotron2.py:459), RuntimeError when an in-launch hand-off of a teacher-forced loop timed out (that
+        call's outputs are all NaN, so they cannot be mistaken for results even without this check).
+        Not called by forward() - it costs a synchronisation; one check after a batch of calls is enough."""
         out = (C.c_int32 * 2)()
         bad = stalled = False
         for ws in [self._workspace] + self._lane_ws:
@@ -228,6 +240,22 @@ class Tacotron2(nn.Module):
         if bad:
             raise IndexError("genvox_amd: token id outside [0, n_tokens)")
 
+    def _ensure_lane_handles(self) -> None:
+        """One C-ABI handle per chunk lane, bound to the same weight blob (a handle is not re-entrant: the lanes run
+        concurrently, the autoregressive ones on host threads).  The resident attention kernel stays off on them - two
+        of them would hold 64 CUs beside launches that need one CU per tile - and is never touched on the main handle."""
+        lib = _lib.load()
+        for i in range(2):
+            if self._lane_handles[i] is None:
+                h = C.c_void_p()
+                dims = dims_from_configs(self.model_config, self.audio_config, self.text_config)
+                _lib.check(lib.gvx_model_create(C.byref(dims), C.byref(h)))
+                _lib.check(lib.gvx_model_set_persistent_attention(h.value, 0))
+                _lib.check(lib.gvx_model_bind_blob(h.value, self._blob.data_ptr()))
+                if self._timing:
+                    _lib.check(lib.gvx_stage_timing_enable(h.value, 1))
+                self._lane_handles[i] = h.value
+
     def _lanes(self, dev, need_bytes: int):
         """Two side streams with a workspace each (chunks of a large batch run on them concurrently)."""
         if self._lane_streams is None:
@@ -239,13 +267,15 @@ class Tacotron2(nn.Module):
 
     def enable_stage_timing(self, enable: bool = True) -> None:
         self._timing = enable
-        if self._handle is not None:
-            _lib.check(_lib.load().gvx_stage_timing_enable(self._handle, int(enable)))
+        for h in [self._handle] + self._lane_handles:
+            if h is not None:
+                _lib.check(_lib.load().gvx_stage_timing_enable(h, int(enable)))
 
-    def stage_times_ms(self):
+    def stage_times_ms(self, lane: Optional[int] = None):
+        """Stage times of the last whole-forward call on the main handle, or on chunk lane `lane` (batches above 32 rows)."""
         t = (C.c_float * 5)()
         n = C.c_int()
-        _lib.check(_lib.load().gvx_stage_times_ms(self._handle, t, C.byref(n)))
+        _lib.check(_lib.load().gvx_stage_times_ms(self._handle if lane is None else self._lane_handles[lane], t, C.byref(n)))
         names = ("encoder", "prenet", "decoder_loop", "projection", "postnet")
         return dict(zip(names, list(t))), n.value
 
@@ -288,37 +318,32 @@ class Tacotron2(nn.Module):
                "gate_outputs": torch.empty(B, T, device=dev), "alignments": torch.empty(B, T, L, device=dev)}
         lib = _lib.load()
 
-        def run(lo: int, hi: int, ws: torch.Tensor) -> None:
+        def run(lo: int, hi: int, ws: torch.Tensor, handle: int) -> None:
             n = hi - lo
             masks = self._keep_masks(given[:, :, lo:hi].contiguous() if given is not None else None, 2 * (T + 1) * n * P, dev)
             _lib.check(lib.gvx_tacotron2_forward(
-                self._handle, tokens[lo:hi].data_ptr(), tok_len[lo:hi].data_ptr(), n, L, mel_in[lo:hi].data_ptr(),
+                handle, tokens[lo:hi].data_ptr(), tok_len[lo:hi].data_ptr(), n, L, mel_in[lo:hi].data_ptr(),
                 mel_len[lo:hi].data_ptr() if self.model_config.mask_padding else None, T, masks.data_ptr(),
                 out["mel_outputs"][lo:hi].data_ptr(), out["mel_outputs_postnet"][lo:hi].data_ptr(),
                 out["gate_outputs"][lo:hi].data_ptr(), out["alignments"][lo:hi].data_ptr(),
                 ws.data_ptr(), ws.numel(), self._stream()))
 
         if B <= STREAM_ROWS:
-            run(0, B, self._get_workspace(B, L, T))
+            run(0, B, self._get_workspace(B, L, T), self._handle)
             return out
         # chunks of near-equal size, alternating over two streams (rows never interact, so the split is invisible in the
         # results); the caller's stream waits for both lanes before anything downstream may touch the outputs
         n_chunks = -(-B // STREAM_ROWS)
         bounds = [(B * i) // n_chunks for i in range(n_chunks + 1)]
-        need = lib.gvx_workspace_bytes(self._handle, max(hi - lo for lo, hi in zip(bounds, bounds[1:])), L, T)
+        self._ensure_lane_handles()   # a handle per lane, attention as a launch per step (see _ensure_lane_handles)
+        need = lib.gvx_workspace_bytes(self._lane_handles[0], max(hi - lo for lo, hi in zip(bounds, bounds[1:])), L, T)
         streams, wss = self._lanes(dev, need)
         cur = torch.cuda.current_stream(dev)
         for lane in streams:
             lane.wait_stream(cur)
-        # one handle, two streams at once: the attention runs as a launch per step here (the resident attention kernel of
-        # the single-stream path owns the handle's side stream for a whole loop)
-        _lib.check(lib.gvx_model_set_persistent_attention(self._handle, 0))
-        try:
-            for ci, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
-                with torch.cuda.stream(streams[ci % 2]):
-                    run(lo, hi, wss[ci % 2])
-        finally:
-            _lib.check(lib.gvx_model_set_persistent_attention(self._handle, 1))
+        for ci, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
+            with torch.cuda.stream(streams[ci % 2]):
+                run(lo, hi, wss[ci % 2], self._lane_handles[ci % 2])
         for lane in streams:
             cur.wait_stream(lane)
         return out
@@ -373,21 +398,18 @@ class Tacotron2(nn.Module):
         n_chunks = -(-B // STREAM_ROWS)
         seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(n_chunks)]  # CPU generator: manual_seed repeats runs
         if n_chunks == 1:
-            run(0, B, self._handle, self._get_workspace(B, L, S), seeds[0])
+            need = lib.gvx_workspace_bytes_autoregressive(self._handle, B, L, S)
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+                self._workspace = self._new_workspace(need, dev)
+            run(0, B, self._handle, self._workspace, seeds[0])
         else:
             import threading
 
             bounds = [(B * i) // n_chunks for i in range(n_chunks + 1)]
             chunks = list(zip(bounds, bounds[1:]))
-            need = lib.gvx_workspace_bytes(self._handle, max(hi - lo for lo, hi in chunks), L, S)
+            need = lib.gvx_workspace_bytes_autoregressive(self._handle, max(hi - lo for lo, hi in chunks), L, S)
             streams, wss = self._lanes(dev, need)
-            for i in range(2):   # the C-ABI handle is not re-entrant: one per lane, bound to the same weight blob
-                if self._lane_handles[i] is None:
-                    h = C.c_void_p()
-                    dims = dims_from_configs(self.model_config, self.audio_config, self.text_config)
-                    _lib.check(lib.gvx_model_create(C.byref(dims), C.byref(h)))
-                    _lib.check(lib.gvx_model_bind_blob(h.value, self._blob.data_ptr()))
-                    self._lane_handles[i] = h.value
+            self._ensure_lane_handles()
             cur = torch.cuda.current_stream(dev)
             errors = []
 
@@ -480,6 +502,7 @@ class Tacotron2(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         out = super().load_state_dict(state_dict, strict=strict, assign=assign)
         self._packed_key = None
+        self._key_tensors = None
         return out
 
     @staticmethod

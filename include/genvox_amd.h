@@ -87,19 +87,26 @@ size_t gvx_model_blob_bytes(const gvx_model* model);
 int gvx_model_pack_weights(gvx_model* model, const gvx_weight_desc* table, int n, void* host_blob);
 int gvx_model_bind_blob(gvx_model* model, const void* device_blob);
 
-/* Bytes of scratch the calls below need for batch B, L tokens and up to T frames. */
+/* Bytes of scratch the calls below need for batch B, L tokens and up to T frames.  gvx_workspace_bytes covers every call;
+ * gvx_workspace_bytes_autoregressive is the (smaller) amount gvx_encoder_forward + gvx_decoder_autoregressive +
+ * gvx_postnet_forward need for max_steps frames (it leaves out the per-step buffers only the teacher-forced loop uses). */
 size_t gvx_workspace_bytes(const gvx_model* model, int B, int L, int T);
+size_t gvx_workspace_bytes_autoregressive(const gvx_model* model, int B, int L, int max_steps);
 
-/* Device-side status words the kernels raise in the workspace, copied to host_out[2] after synchronising `stream`:
+/* Device-side status words the kernels raise in the workspace, copied to host_out[2] after synchronising `stream`.  Both
+ * are STICKY: they accumulate over every call made with this workspace since the last gvx_workspace_status, which clears them.
  *   [0] != 0: a token id was outside [0, n_tokens) (the reference's nn.Embedding raises IndexError there,
- *             models/tts/tacotron2.py:459; the row is embedded as zeros here) - set by the last
- *             gvx_encoder_forward / gvx_tacotron2_forward on this workspace;
- *   [1] != 0: a bounded in-launch wait of the last teacher-forced decoder loop gave up (the attention kernel that runs
+ *             models/tts/tacotron2.py:459; the row is embedded as zeros here) in some gvx_encoder_forward /
+ *             gvx_tacotron2_forward call;
+ *   [1] != 0: a bounded in-launch wait of a teacher-forced decoder loop gave up (the attention kernel that runs
  *             beside the LSTM launches and those launches hand the query / context over through counters in the
- *             workspace; a wait that is not served within a few hundred ms raises this word and every kernel drains):
- *             the outputs of that call are invalid.  Never observed; it exists so that a scheduling failure cannot hang.
+ *             workspace; a wait that is not served within a few hundred ms raises the call's time-out word and every
+ *             kernel drains).  The outputs of such a call are NOT results and do not look like results: the call's
+ *             last launch overwrites all of them (mel, mel_post, gate, alignments) with NaN.  It cannot happen while
+ *             the two kernels run concurrently; the library switches the resident kernel off when the process runs
+ *             under AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING.
  * Costs a stream synchronisation: meant for tests and for one check after a batch of calls, not for every call. */
-int gvx_workspace_status(const gvx_model* model, const void* workspace, size_t workspace_bytes, void* stream, int32_t* host_out);
+int gvx_workspace_status(const gvx_model* model, void* workspace, size_t workspace_bytes, void* stream, int32_t* host_out);
 
 /* Teacher-forced decoder loop: run the attention as ONE kernel that lives beside the step launches (default, used when the
  * shape allows it: B <= 32, L <= 128, default layer sizes) or as a launch per step (enable = 0).  Callers that drive one

@@ -274,3 +274,74 @@ def test_config4_griffin_lim_800_frames_60_iterations():
     assert torch.equal(wavB[17], wav60[0])
     _, w200 = ap.griffin_lim(magB[200:201], n_iter=60, want_phase=False)
     assert torch.equal(wavB[200], w200[0])
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def test_config1_single_utterance_b1_l100_t568():
+    """BASELINE configs[0]: one LJSpeech-sized utterance, B = 1, L = 100 tokens, T = 568 frames,
+    teacher-forced (models/tts/tacotron2.py:450-481) - the whole utterance against the oracle, all four outputs."""
+    mc, ac, tc = full_configs()
+    sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+    m = Tacotron2(mc, ac, tc)
+    m.load_state_dict(sd)
+    m = m.to("cuda:0")
+    B, L, T, P = 1, 100, 568, mc.prenet_dim
+    inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=3)
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    masks = torch.from_numpy(gw.prenet_keep_masks((T + 1) * B, P, seed=11))
+    got = m.forward({**batch, "prenet_keep_masks": masks})
+    m.check_status()
+    again = m.forward({**batch, "prenet_keep_masks": masks})
+    want = tacotron2_ref.tacotron2_forward(sd, batch, masks, mask_padding=True)
+    for k in KEYS:
+        assert got[k].shape == want[k].shape
+        assert torch.equal(got[k], again[k]), k
+        d = max_abs_diff(got[k], want[k])
+        assert d <= TOL, f"{k}: {d}"
+    assert float((got["alignments"].sum(dim=2) - 1).abs().max()) <= 1e-5
+
+
+def test_north_star_batch_64x800_two_lanes():
+    """north_star's target batch (64 x 800 frames, 128 tokens) through Tacotron2.forward, which runs it as two 32-row chunks
+    on two HIP streams with a C-ABI handle each: deterministic, softmax rows sum to one, rows independent of their chunk
+    (rows 0 / 32 / 63 run alone reproduce themselves), and the first 100 steps of rows 0 / 32 / 63 equal what the oracle
+    gives on a 100-frame run (the teacher-forced decoder is causal; the Postnet prefix is compared where its receptive
+    field - 5 layers x 2 frames - lies inside the prefix)."""
+    mc, ac, tc = full_configs()
+    sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+    m = Tacotron2(mc, ac, tc)
+    m.load_state_dict(sd)
+    m = m.to("cuda:0")
+    B, L, T, P = 64, 128, 800, mc.prenet_dim
+    tl = np.sort(128 - (np.arange(B) * 5) % 60)[::-1].copy()
+    ml = 800 - (np.arange(B) * 29) % 350
+    ml[0] = 800
+    inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=5, token_lengths=tl, mel_lengths=ml)
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    masks = torch.from_numpy(gw.prenet_keep_masks((T + 1) * B, P, seed=13)).reshape(2, T + 1, B, P)
+    out = m.forward({**batch, "prenet_keep_masks": masks})
+    m.check_status()
+    out2 = m.forward({**batch, "prenet_keep_masks": masks})
+    for k in KEYS:
+        assert torch.isfinite(out[k]).all(), k
+        assert torch.equal(out[k], out2[k]), k
+    a = out["alignments"]
+    assert float((a.sum(dim=2) - 1).abs().max()) <= 1e-5
+    for b in range(B):
+        assert torch.all(a[b, :, int(tl[b]):] == 0)
+        assert torch.all(out["mel_outputs"][b, :, int(ml[b]):] == 0) and torch.all(out["gate_outputs"][b, int(ml[b]):] == 1e3)
+    rows = [0, 32, 63]
+    sub = {k: v[rows] for k, v in batch.items()}
+    alone = m.forward({**sub, "prenet_keep_masks": masks[:, :, rows].contiguous()})
+    for k in KEYS:
+        assert max_abs_diff(alone[k], out[k][rows]) <= 1e-4, k
+    n = 100
+    pre = {"token_padded": sub["token_padded"], "token_lengths": sub["token_lengths"], "mel_padded": sub["mel_padded"][:, :, :n].contiguous(),
+           "gate_padded": sub["gate_padded"][:, :n].contiguous(), "mel_lengths": torch.full((3,), n, dtype=sub["mel_lengths"].dtype)}
+    want = tacotron2_ref.tacotron2_forward(sd, pre, masks[:, :n + 1, rows].reshape(2, -1, P), mask_padding=False)
+    assert int(ml[rows].min()) >= n   # the prefix lies inside every sampled row's unmasked part
+    for k in ("mel_outputs", "gate_outputs", "alignments"):
+        got = out[k][rows][..., :n] if k != "alignments" else out[k][rows][:, :n]
+        d = max_abs_diff(got, want[k])
+        assert d <= TOL, f"{k}: {d}"
+    assert max_abs_diff(out["mel_outputs_postnet"][rows][..., :n - 10], want["mel_outputs_postnet"][..., :n - 10]) <= TOL

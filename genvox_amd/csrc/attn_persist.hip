@@ -38,7 +38,8 @@ constexpr int PA_E = 512;      // encoder embedding dim
 constexpr int PA_L = 128;      // positions held per row
 constexpr int PA_FB_S = 36;    // LDS row stride of the conv output [l][32 filters] (+4: conflict-free float4 rows)
 constexpr int PA_KL_MAX = 31;
-constexpr int PA_SLABS = 96;   // workgroups of the attention LSTM in the launch's layout (skinny.hip): one query slab each
+constexpr int PA_SLABS = 96;   // workgroups of the attention LSTM in the teacher-forced launch's layout (skinny.hip): one query slab each
+constexpr int PA_SLABS_AR = 128;   // autoregressive launches: one slab per attention-LSTM tile
 constexpr int PA_WC_S = PA_L + 32;   // stride of the two halo-padded weight rows (prev, cum); taps are padded to 32
 
 // LDS layout (floats)
@@ -52,7 +53,8 @@ constexpr int PA_OFF_QS = PA_OFF_QP + 32 * PA_A;               // [128] query
 constexpr int PA_OFF_ES = PA_OFF_QS + PA_A;                    // [128] energies
 constexpr int PA_OFF_V = PA_OFF_ES + PA_L;                     // [128] v
 constexpr int PA_OFF_CP = PA_OFF_V + PA_A;                     // [8][512] context partial sums
-constexpr int PA_LDS_FLOATS = PA_OFF_CP + 8 * PA_E;
+constexpr int PA_OFF_FLAG = PA_OFF_CP + 8 * PA_E;              // [4] "leave the loop" word of the step's wait
+constexpr int PA_LDS_FLOATS = PA_OFF_FLAG + 4;
 static_assert(PA_LDS_FLOATS * 4 <= 160 * 1024, "persistent attention LDS");
 static_assert((PA_OFF_FB % 4) == 0 && (PA_OFF_CW % 4) == 0 && (PA_OFF_WD % 4) == 0 && (PA_OFF_QP % 4) == 0 && (PA_OFF_QS % 4) == 0 &&
               (PA_OFF_V % 4) == 0 && (PA_OFF_CP % 4) == 0, "float4 alignment");
@@ -87,6 +89,9 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 
 }  // namespace
 
+// SPG: query slabs per group of 32 threads (32 groups): 3 = the 96 slabs of the teacher-forced launch, 4 = the 128 of the
+// autoregressive launches
+template <int SPG>
 __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersistParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* locf = smem + PA_OFF_LOC;
@@ -99,6 +104,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     float* es = smem + PA_OFF_ES;
     float* vl = smem + PA_OFF_V;
     float* cp = smem + PA_OFF_CP;
+    volatile int* leave = reinterpret_cast<volatile int*>(smem + PA_OFF_FLAG);
 
     const int b = blockIdx.x, B = p.B, L = p.L, kl = p.kl, pad = (kl - 1) / 2;
     const int tid = threadIdx.x;
@@ -107,6 +113,8 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     unsigned* const cnt_q = p.sync + HANDOFF_CNT_Q;
     unsigned* const cnt_ctx = p.sync + HANDOFF_CNT_CTX;
     unsigned* const tmo = p.sync + HANDOFF_TIMEOUT;
+    const unsigned* const stop = p.sync + HANDOFF_STOP;
+    if (tid == 0) *leave = 0;
     if (tid == 0) __hip_atomic_fetch_add(p.sync + HANDOFF_READY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident
 
     // ---- resident operands
@@ -197,20 +205,23 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         // ---- query: the slabs of step t are plain stores of launch t; launch t + 1 (or the drain launch) adds 1 to the counter
         // when it STARTS, i.e. after launch t has completed and its stores have been written back (count t + 2: launch 0
         // adds too).  Then sum the partial slabs (fixed order)
-        if (tid == 0) handoff_wait<true>(cnt_q, (unsigned)(t + 2), tmo, 0x100u + (unsigned)b, p.spin_limit);
+        // A wait that returns without its word (the host has ended the loop early - autoregressive decode, every row has
+        // stopped - or some wait has timed out) ends the kernel: nothing it could still compute would be used
+        if (tid == 0 && !handoff_wait<true>(cnt_q, (unsigned)t + p.q_first, tmo, 0x100u + (unsigned)b, p.spin_limit, stop)) *leave = 1;
         __syncthreads();
+        if (*leave) break;
         PA_STAMP(1);
         int tq = tid;
         asm volatile("" : "+v"(tq));
         const int lane = tq & 63, e4 = tq & 127, lg = tq >> 7, el = tq >> 3, dg = tq & 7;
         {
-            const int d4 = tq & 31, sg = tq >> 5;   // slabs 3 sg .. 3 sg + 2 (96 workgroups of the attention LSTM, one slab each)
+            const int d4 = tq & 31, sg = tq >> 5;   // slabs SPG sg .. SPG sg + SPG - 1 (one slab per workgroup / tile of the attention LSTM)
             float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 ql[3];
+            float4 ql[SPG];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) ql[i] = load_sc1(rq, (unsigned)(((3 * sg + i) * B + b) * PA_A + 4 * d4) * 4u);
+            for (int i = 0; i < SPG; ++i) ql[i] = load_sc1(rq, (unsigned)(((SPG * sg + i) * B + b) * PA_A + 4 * d4) * 4u);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { s4.x += ql[i].x; s4.y += ql[i].y; s4.z += ql[i].z; s4.w += ql[i].w; }
+            for (int i = 0; i < SPG; ++i) { s4.x += ql[i].x; s4.y += ql[i].y; s4.z += ql[i].z; s4.w += ql[i].w; }
             reinterpret_cast<float4*>(qp)[sg * 32 + d4] = s4;
         }
         __syncthreads();
@@ -299,8 +310,17 @@ bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, i
 int attention_persistent_slabs() { return PA_SLABS; }
 
 hipError_t attention_persistent_init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_persistent_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       PA_LDS_FLOATS * (int)sizeof(float));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_persistent_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                PA_LDS_FLOATS * (int)sizeof(float));
+}
+
+__global__ void handoff_set_kernel(unsigned* word) { __hip_atomic_store(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+hipError_t launch_handoff_set(unsigned* word, hipStream_t s) {
+    handoff_set_kernel<<<dim3(1), dim3(1), 0, s>>>(word);
+    return hipGetLastError();
 }
 
 #ifdef GVX_STAMPS
@@ -310,8 +330,10 @@ hipError_t read_stamps_persist(unsigned long long* host96) {
 #endif
 
 hipError_t launch_attention_persistent(const AttnPersistParams& p, hipStream_t s) {
-    if (!attention_persistent_supported(p.B, p.L, PA_A, 32, p.kl, PA_E, 1024, 1024) || p.n_slabs != PA_SLABS || p.T < 1) return hipErrorInvalidValue;
-    attn_persistent_kernel<<<dim3(p.B), dim3(PA_THREADS), PA_LDS_FLOATS * sizeof(float), s>>>(p);
+    if (!attention_persistent_supported(p.B, p.L, PA_A, 32, p.kl, PA_E, 1024, 1024) || (p.n_slabs != PA_SLABS && p.n_slabs != PA_SLABS_AR) || p.T < 1)
+        return hipErrorInvalidValue;
+    if (p.n_slabs == PA_SLABS) attn_persistent_kernel<3><<<dim3(p.B), dim3(PA_THREADS), PA_LDS_FLOATS * sizeof(float), s>>>(p);
+    else attn_persistent_kernel<4><<<dim3(p.B), dim3(PA_THREADS), PA_LDS_FLOATS * sizeof(float), s>>>(p);
     return hipGetLastError();
 }
 

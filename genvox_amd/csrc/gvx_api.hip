@@ -78,7 +78,7 @@ struct Blob {  // offsets in floats into the packed weight blob
     size_t pre_w0, pre_w1, pre_w0_t, pre_w1_t;
     size_t att_frag, att_bias, att_wpre, wq_t, wmem, v, loc_conv, loc_dense;
     size_t dec_frag, dec_bias;
-    size_t proj_w, proj_b, proj_frag, proj_hd_t, proj_ctx_frag;   // last two: autoregressive split of the projection (see gvx_decoder_autoregressive)
+    size_t proj_w, proj_b, proj_frag, proj_hd_t, proj_ctx_frag, proj_ctx_t;   // last three: autoregressive split of the projection (see gvx_decoder_autoregressive)
     size_t post_w[MAX_CONV], post_b[MAX_CONV];
     size_t total;
 };
@@ -132,6 +132,10 @@ struct gvx_model {
     // teacher-forced loop: attention as one kernel that lives beside the LSTM launches (attn_persist.hip) when the shape
     // allows it; GVX_ATTN_PERSISTENT=0 keeps the launch per step
     bool attn_persistent = true;
+    // GVX_AR_RESIDENT=1: the autoregressive loop runs beside the resident attention kernel too.  Off by default: measured
+    // (round 3, 200-step decodes) 49 vs 47 us per step at batch 1 and no gain at 2 x 32 rows - launch C then has 256 equal
+    // tiles for 256 - B free CUs, so one CU streams two of them
+    bool ar_resident = false;
     int pa_depth = 4;                  // GVX_PA_DEPTH=6: prefetch depth of the launch beside the resident kernel (tests, A/B runs)
     unsigned spin_limit = 0;           // GVX_HANDOFF_SPIN_LIMIT: polls before an in-launch wait gives up (0 = the built-in limit)
     bool debug_skip_resident = false;  // GVX_DEBUG_SKIP_RESIDENT=1: never launch the resident attention kernel, so that every
@@ -193,6 +197,7 @@ Blob make_blob_layout(const gvx_dims& d) {
     b.proj_frag = take(frag_floats(M + 1, D + E));
     b.proj_hd_t = take((size_t)D * ((M + 1 + 7) & ~7));
     b.proj_ctx_frag = take(frag_floats(M + 1, E));
+    b.proj_ctx_t = take((size_t)(E / 4) * ((M + 1 + 7) & ~7) * 4);
     for (int i = 0; i < d.postnet_n_conv; ++i) {
         const int cin = i == 0 ? M : d.postnet_dim, cout = i == d.postnet_n_conv - 1 ? M : d.postnet_dim;
         b.post_w[i] = take((size_t)cout * d.postnet_kernel * cin);
@@ -419,6 +424,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     for (const char* name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"})
         if (const char* e = std::getenv(name))
             if (e[0] != '\0' && e[0] != '0') m->attn_persistent = false;
+    if (const char* e = std::getenv("GVX_AR_RESIDENT")) m->ar_resident = e[0] == '1';
     if (const char* e = std::getenv("GVX_PA_DEPTH")) m->pa_depth = std::atoi(e) == 6 ? 6 : 4;
     if (const char* e = std::getenv("GVX_HANDOFF_SPIN_LIMIT")) m->spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("GVX_DEBUG_SKIP_RESIDENT")) m->debug_skip_resident = e[0] == '1';
@@ -433,7 +439,7 @@ void gvx_model_destroy(gvx_model* m) {
     for (auto& e : m->kev) (void)hipEventDestroy(e);
     m->drop_graphs();
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-    if (m->pa_stream) (void)hipStreamDestroy(m->pa_stream);
+    // (pa_stream belongs to the process-wide side-stream pool)
     if (m->pa_fork) (void)hipEventDestroy(m->pa_fork);
     if (m->pa_join) (void)hipEventDestroy(m->pa_join);
     delete m;
@@ -539,6 +545,12 @@ int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, vo
         std::vector<float> wc((size_t)(M + 1) * E);
         for (int n = 0; n <= M; ++n) std::memcpy(&wc[(size_t)n * E], &w[(size_t)n * K + D], sizeof(float) * E);
         pack_frag(wc, M + 1, E, out + bl.proj_ctx_frag);
+        // ... and once more tile-major [E/4][PSB][4]: four context columns ride on the projection slab of each decoder-LSTM
+        // tile (skinny.hip, extra slab terms) when the tile counts match (E / 4 == D / 8)
+        for (int t = 0; t < E / 4; ++t)
+            for (int n = 0; n < PSBp; ++n)
+                for (int jj = 0; jj < 4; ++jj)
+                    out[bl.proj_ctx_t + ((size_t)t * PSBp + n) * 4 + jj] = n <= M ? w[(size_t)n * K + D + t * 4 + jj] : 0.f;
         if (!(src = wt.get("decoder.linear_projection.linear_layer.bias", M, &rc))) return rc;
         std::memcpy(out + bl.proj_b, src, sizeof(float) * M);
         if (!(src = wt.get("decoder.gate_layer.linear_layer.bias", 1, &rc))) return rc;
@@ -793,17 +805,35 @@ bool persistent_path(const gvx_model* m, int B, int L) {
            attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
 }
 
+// Side stream of the resident attention kernels: ONE per device, shared by every handle of the process (GVX_SIDE_POOL=2: two,
+// dealt round-robin per call, for concurrent resident loops - the opt-in autoregressive lanes).
+// Highest priority: HIP keeps separate hardware queues per priority, so this stream can never be dealt the queue of a
+// (normal-priority) stream an LSTM chain runs on - the attention kernel would then sit in front of the launches it waits
+// for until its spin limit (observed in a process that had created a dozen streams before).  Shared instead of one per
+// handle because a process has only ~4 hardware queues, dealt in order of first use: with the null stream and the host
+// mirror's two lane streams in use, a second side stream landed on the queue of a stream that feeds it and every other
+// forward took 17 instead of 6.7 ms (tools/queue_probe.py, round 3).  Calls that share the stream only serialise their
+// resident kernels (the later one starts when the earlier loop has ended, well inside the spin limit).
+struct SidePool { hipStream_t s[2] = {nullptr, nullptr}; unsigned next = 0; };
+std::mutex g_pool_mutex;
+std::unordered_map<int, SidePool> g_side_pools;
+
 int ensure_side_stream(gvx_model* m) {
-    if (m->pa_stream) return GVX_OK;
-    // Highest priority: HIP keeps separate hardware queues per priority, so this stream can never be dealt the queue of
-    // the (normal-priority) stream the LSTM chain runs on.  Two ordinary streams may share one of the few hardware queues
-    // (round-robin in order of first use); the attention kernel would then sit in front of the launches it waits for
-    // until its spin limit - observed in a process that had created a dozen streams before.
-    int least = 0, greatest = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_TRY(hipStreamCreateWithPriority(&m->pa_stream, hipStreamNonBlocking, greatest));
-    HIP_TRY(hipEventCreateWithFlags(&m->pa_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&m->pa_join, hipEventDisableTiming));
+    if (!m->pa_fork) {
+        HIP_TRY(hipEventCreateWithFlags(&m->pa_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->pa_join, hipEventDisableTiming));
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    SidePool& pool = g_side_pools[dev];
+    if (!pool.s[0]) {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        for (auto& st : pool.s) HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+    }
+    static const unsigned pool_size = [] { const char* e = std::getenv("GVX_SIDE_POOL"); return e && e[0] == '2' ? 2u : 1u; }();
+    m->pa_stream = pool.s[pool.next++ % pool_size];
     return GVX_OK;
 }
 
@@ -879,7 +909,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     // forked stream; the LSTM tiles stream the k-groups of the context last and wait for it in the launch.
     const bool pa = persistent_path(m, B, L);
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
-    if (pa) {
+    if (pa && !prenet_done) {   // (the fused forward has taken a side stream for this call already: the encoder ran on it)
         rc = ensure_side_stream(m);
         if (rc != GVX_OK) return rc;
     }
@@ -913,7 +943,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         pp.w_out = db.align_tm; pp.w_out_bs = (long)L; pp.w_out_ts = (long)B * L;
         pp.ctx_base = db.hc + (size_t)B * (D + E) + (size_t)D * B; pp.ctx_ts = (long)B * (D + E);   // slot t + 1
         pp.sync = sync; pp.B = B; pp.L = L; pp.T = T; pp.kl = d.att_loc_kernel;
-        pp.spin_limit = m->spin_limit;
+        pp.spin_limit = m->spin_limit; pp.q_first = 2;   // (launch 0 announces its start too)
         if (!m->debug_skip_resident) HIP_TRY(launch_attention_persistent(pp, m->pa_stream));
         HIP_TRY(hipEventRecord(m->pa_join, m->pa_stream));
         return GVX_OK;
@@ -1293,6 +1323,18 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     }
     rc = decoder_init_states(m, memory_ws, B, L, db, s);
     if (rc != GVX_OK) return rc;
+    // Resident attention (attn_persist.hip) when the shape allows it: ONE attention kernel lives beside the step launches for
+    // the whole decode, the context of a step arrives inside launch C (deferred segment) and the attention launch leaves the
+    // step's chain.  The projection's context columns then ride on the decoder-LSTM tiles' projection slabs (`fold`), so that
+    // launch C is exactly 256 tiles.
+    const bool pa = m->ar_resident && m->attn_one_launch &&
+                    attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
+    const bool fold = B <= 32 && E / 4 == D / 8;
+    unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
+    if (pa) {
+        rc = ensure_side_stream(m);
+        if (rc != GVX_OK) return rc;
+    }
     HIP_TRY(zero_async(db.prenet, (size_t)B * P * sizeof(float), s));       // Prenet of the go-frame: no biases, relu(W 0) = 0
     HIP_TRY(zero_async(db.att_part, (size_t)B * 4 * A * sizeof(float), s)); // ctx(-1) = h_a(-1) = 0
     HIP_TRY(zero_async(n_done, sizeof(int32_t), s));                         // (the sticky status words in between stay)
@@ -1336,12 +1378,20 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
                 J.N = 4 * D; J.nkg = kgD; J.kg0 = kgA + kgE; J.nkg_w = kgA + kgE + kgD; J.mode = 2; J.B = B;
                 J.y = db.dec_part;
             }
-            LocJob lq;
-            fill_loc(m, lq, t, B, L, db.align_tm, (long)L, (long)B * L, db);
-            HIP_TRY(launch_skinny(ja, 2, SK_AR, st, &lq));
-            AttnParams ap;
-            fill_attn(m, ap, memory_ws, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
-            HIP_TRY(launch_attn(m, ap, st));
+            if (pa) {
+                if (t == 0) {   // the first launch does not end before the resident kernel is resident: launch C waits for it
+                    ja[0].ready_cnt = sync + HANDOFF_READY; ja[0].ready_target = (unsigned)B;
+                    ja[0].tmo = sync + HANDOFF_TIMEOUT; ja[0].spin_limit = m->spin_limit;
+                }
+                HIP_TRY(launch_skinny(ja, 2, SK_AR, st));
+            } else {
+                LocJob lq;
+                fill_loc(m, lq, t, B, L, db.align_tm, (long)L, (long)B * L, db);
+                HIP_TRY(launch_skinny(ja, 2, SK_AR, st, &lq));
+                AttnParams ap;
+                fill_attn(m, ap, memory_ws, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
+                HIP_TRY(launch_attn(m, ap, st));
+            }
             SkinnyJob jc[3];
             std::memset(jc, 0, sizeof jc);
             {   // decoder LSTM of step t: final tiles over [h_a(t) ; ctx(t)]; every tile also emits the mel/gate projection
@@ -1354,16 +1404,27 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
                 J.addend = db.dec_part; J.add_bs = 4 * D; J.add_ts = 0;
                 J.c = db.c_d; J.h_out = hc_n;
                 J.Wq_t = m->dev_blob + m->blob.proj_hd_t; J.q_slab = db.p_slab; J.att_dim = PSB;
+                if (fold) { J.xw = m->dev_blob + m->blob.proj_ctx_t; J.xsrc = hc_n + (size_t)D * B; }
             }
-            {   // attention LSTM of step t+1: partial sums over [ctx(t) ; h_a(t)]
+            {   // attention LSTM of step t+1: partial sums over [ctx(t) ; h_a(t)]  (x[0] is an empty segment so that the
+                // context is x[1], the segment the deferred order streams last)
                 SkinnyJob& J = jc[1];
                 J.Wp = m->dev_blob + m->blob.att_frag;
-                J.x[0] = XSeg{hc_n + (size_t)D * B, E};
-                J.x[1] = XSeg{ha_new, A};
+                J.x[0] = XSeg{hc_n + (size_t)D * B, 0};
+                J.x[1] = XSeg{hc_n + (size_t)D * B, E};
+                J.x[2] = XSeg{ha_new, A};
                 J.N = 4 * A; J.nkg = kgE + kgA; J.kg0 = kgP; J.nkg_w = kgP + kgE + kgA; J.mode = 2; J.B = B;
                 J.y = db.att_part;
             }
-            {   // context columns of the mel/gate projection (known before the launch)
+            if (pa)
+                for (int i = 0; i < 2; ++i) {   // the context of step t is published by the resident kernel while this launch streams
+                    SkinnyJob& J = jc[i];
+                    J.defer_seg = 1;
+                    J.ctx_cnt = sync + HANDOFF_CNT_CTX; J.ctx_target = (unsigned)B * (unsigned)(t + 1);
+                    J.tmo = sync + HANDOFF_TIMEOUT; J.spin_limit = m->spin_limit;
+                    if (i == 0) J.start_cnt = sync + HANDOFF_CNT_Q;   // "launch A of this step has completed: its query slabs are in memory"
+                }
+            if (!fold) {   // context columns of the mel/gate projection (known before the launch)
                 SkinnyJob& J = jc[2];
                 J.Wp = m->dev_blob + m->blob.proj_ctx_frag; J.bias = m->dev_blob + m->blob.proj_b;
                 J.x[0] = XSeg{hc_n + (size_t)D * B, E};
@@ -1371,7 +1432,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
                 J.y = db.p_ctx;
             }
             (void)ha_prev;
-            HIP_TRY(launch_skinny(jc, 3, SK_AR, st));
+            HIP_TRY(launch_skinny(jc, fold ? 2 : 3, SK_AR, st));
             const bool more = t + 1 < T;
             HIP_TRY(launch_ar_project(db.p_slab, D / 8, db.p_ctx, proj_t, M, gate_threshold, t, B, n_frames_ws, n_done,
                                       m->dev_blob + m->blob.pre_w0_t, m->dev_blob + m->blob.pre_w1_t, P,
@@ -1380,6 +1441,29 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
         }
         return GVX_OK;
     };
+    if (fold) {   // p_ctx = the projection's bias, once: the linear job on the all-zero context of slot 0
+        SkinnyJob J;
+        std::memset(&J, 0, sizeof J);
+        J.Wp = m->dev_blob + m->blob.proj_ctx_frag; J.bias = m->dev_blob + m->blob.proj_b;
+        J.x[0] = XSeg{db.hc + (size_t)D * B, E};
+        J.N = M + 1; J.nkg = kgE; J.mode = 1; J.B = B; J.act = ACT_NONE;
+        J.y = db.p_ctx;
+        HIP_TRY(launch_skinny(&J, 1, SK_AR, s));
+    }
+    if (pa) {   // the resident kernel: launched eagerly on the handle's side stream, behind everything queued on `s` so far
+        HIP_TRY(hipEventRecord(m->pa_fork, s));
+        HIP_TRY(hipStreamWaitEvent(m->pa_stream, m->pa_fork, 0));
+        AttnPersistParams pp{};
+        pp.q_slab = db.q_slab; pp.n_slabs = A / 8;
+        pp.v = m->dev_blob + m->blob.v; pp.pm = db.pm; pp.memory = memory_ws; pp.lengths = len_ws;
+        pp.loc_conv_t = m->dev_blob + m->blob.loc_conv; pp.loc_dense_t = m->dev_blob + m->blob.loc_dense;
+        pp.w_out = db.align_tm; pp.w_out_bs = (long)L; pp.w_out_ts = (long)B * L;
+        pp.ctx_base = db.hc + (size_t)B * (D + E) + (size_t)D * B; pp.ctx_ts = (long)B * (D + E);   // slot t + 1
+        pp.sync = sync; pp.B = B; pp.L = L; pp.T = T; pp.kl = d.att_loc_kernel;
+        pp.spin_limit = m->spin_limit; pp.q_first = 1;   // one signalling launch (C) per step
+        if (!m->debug_skip_resident) HIP_TRY(launch_attention_persistent(pp, m->pa_stream));
+        HIP_TRY(hipEventRecord(m->pa_join, m->pa_stream));
+    }
     const int CHUNK = 16;  // steps per graph = steps between host checks of the all-rows-finished counter
     int t = 0;
     int32_t done_host = 0;
@@ -1387,6 +1471,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     if (m->use_graph) {
         gvx_model::LoopKey key{ws, memory_ws, m->dev_blob, B, L, T, lengths != nullptr};
         key.threshold = gate_threshold;
+        key.variant = pa ? 1 : 0;
         gset = touch_graph_set(m, m->ar_graphs, key);
     }
     while (t < T) {
@@ -1398,6 +1483,10 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
         HIP_TRY(hipStreamSynchronize(s));
         if (done_host >= B) break;
     }
+    if (pa) {   // the loop may have ended early: tell the resident kernel (it leaves at its next look), then wait for it
+        HIP_TRY(launch_handoff_set(sync + HANDOFF_STOP, s));
+        HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));
+    }
     // rows that never fired ran into the cap ("Warning! Reached max decoder steps", models/tts/tacotron2.py:407-409)
     HIP_TRY(launch_ar_stop(db.proj, M, -1.f, t - 1, B, n_frames_ws, n_done, s));
     HIP_TRY(hipMemcpyAsync(n_frames_out, n_frames_ws, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
@@ -1405,6 +1494,11 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     // padding values (mel 0, gate 1e3, alignment 0 - mask_padding, models/tts/tacotron2.py:466-473)
     HIP_TRY(launch_ar_emit_all(db.proj, mel_out, gate_out, B, M, T, t, n_frames_ws, s));
     HIP_TRY(launch_permute01_partial(db.align_tm, align_out, t, T, B, L, n_frames_ws, s));
+    if (pa) {   // a hand-off that timed out must not leave numbers that look like results
+        float* outs[3] = {mel_out, gate_out, align_out};
+        const size_t counts[3] = {(size_t)B * M * T, (size_t)B * T, (size_t)B * T * L};
+        HIP_TRY(launch_poison_on_timeout(sync + HANDOFF_TIMEOUT, flags + FLAG_TIMEOUT, outs, counts, 3, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     if (steps_run_out) *steps_run_out = t;
     return GVX_OK;

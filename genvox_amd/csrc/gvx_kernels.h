@@ -87,6 +87,10 @@ struct SkinnyJob {
     // attention query partial products: slab[tile][b][a] = sum_{j in tile} Wq[a][j] * h'[b][j]
     const float* Wq_t;      // [H/8][att_dim][8] (tile-major repack of query_layer.weight) or nullptr
     float* q_slab; int att_dim;
+    // extra terms of the slab (autoregressive decoder LSTM: the context columns of the mel / gate projection ride on the
+    // projection slabs of the tiles): slab[tile][b][d] += sum_{j < 4} xw[(tile * att_dim + d) * 4 + j] * xsrc[b][4 tile + j],
+    // xsrc a blocked vector; one batch tile only (B <= 32)
+    const float* xw; const float* xsrc;
     // teacher-forced decoder with the persistent attention kernel (attn_persist.hip); all 0 / nullptr otherwise
     int defer_seg;                  // 1: every wave streams its share of x[1]'s k-groups (the context) after its share of the others
     const unsigned* ctx_cnt; unsigned ctx_target;   // wait for *ctx_cnt >= ctx_target before x[1]; x[1] is then read with sc1 loads
@@ -153,6 +157,7 @@ bool attention_supported(int L, int a, int F, int kl, int E);
 // ---------------------------------------------------------------------------------------------
 // word indices: 4 KB apart, so that the pollers of one word do not queue in front of another word's traffic at the same channel
 constexpr int HANDOFF_CNT_Q = 0, HANDOFF_CNT_CTX = 1024, HANDOFF_READY = 2048, HANDOFF_TIMEOUT = 3072;
+constexpr int HANDOFF_STOP = 3072 + 512;   // the host's "the loop has ended early" word (autoregressive decode): the resident kernel leaves
 constexpr int HANDOFF_WORDS = 4096;
 constexpr unsigned HANDOFF_SPIN_LIMIT = 200000u;   // polls with ~2 us of s_sleep between them (a few hundred ms), then the wait gives up
 struct AttnPersistParams {
@@ -164,11 +169,15 @@ struct AttnPersistParams {
     unsigned* sync;                         // HANDOFF_WORDS words
     int B, L, T, kl;
     unsigned spin_limit;                    // polls before a wait gives up (0 = HANDOFF_SPIN_LIMIT)
+    unsigned q_first;                       // step t waits for the query counter to reach t + q_first (teacher-forced loop: 2 -
+                                            // launch 0 signals too; autoregressive loop: 1 - one signalling launch per step)
 };
 bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, int att_rnn_dim, int dec_rnn_dim);
 int attention_persistent_slabs();
 hipError_t attention_persistent_init();
 hipError_t launch_attention_persistent(const AttnPersistParams& p, hipStream_t s);
+// *word = 1 with an agent-scope store (the form every polled hand-off word is written in)
+hipError_t launch_handoff_set(unsigned* word, hipStream_t s);
 
 #if defined(__HIPCC__)
 // write-through / L1-bypassing 16-byte accesses of handed-off bytes (aux 16 = sc1)
@@ -180,6 +189,9 @@ __device__ __forceinline__ float4 load_sc1(__amdgpu_buffer_rsrc_t r, unsigned by
     const gvx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ float load_sc1_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 16));
+}
 __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
     gvx_u32x4 u;
     u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
@@ -187,7 +199,8 @@ __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t r, unsigned byt
 }
 // One lane waits until *cnt >= target.  Bounded; a timeout (or one raised by anybody else) makes every wait return at once.
 template <bool FEW_WAITERS = false>
-__device__ __forceinline__ bool handoff_wait(const unsigned* cnt, unsigned target, unsigned* tmo, unsigned code, unsigned limit = 0u) {
+__device__ __forceinline__ bool handoff_wait(const unsigned* cnt, unsigned target, unsigned* tmo, unsigned code, unsigned limit = 0u,
+                                             const unsigned* stop = nullptr) {
     if (limit == 0u) limit = HANDOFF_SPIN_LIMIT;
     // Normally the word is there at the first look.  A waiter that is early backs off (up to ~2 us between polls): a launch has
     // ~220 waves that may wait on the same word, and their polls queue in front of the producer's own traffic.  FEW_WAITERS
@@ -198,6 +211,7 @@ __device__ __forceinline__ bool handoff_wait(const unsigned* cnt, unsigned targe
         ++spins;
         if ((spins & (FEW_WAITERS ? 127u : 7u)) == 1u) {   // (after a timeout every wait gives up at its first look)
             if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;   // not an error
             if (spins > (FEW_WAITERS ? 16u : 1u) * limit) {
                 __hip_atomic_store(tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;

@@ -229,14 +229,35 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 
     // Query-slab weights of this wave's 32 attention dims (MFMA form of the slab phase, one batch tile only): fetched now
     // as well - loaded after the cells they were a dependent global round trip at the end of the launch's slowest workgroups
-    const bool slab_mfma = MT == 1 && J.mode == 0 && J.q_slab && (J.att_dim & 31) == 0 && (J.att_dim >> 5) <= SK_WAVES;
-    float4 wq_a = make_float4(0.f, 0.f, 0.f, 0.f), wq_b = wq_a, wq_c = wq_a;
-    if (slab_mfma && wave < (J.att_dim >> 5)) {
+    const int a_tiles = (J.att_dim + 31) >> 5;   // 32-wide slices of the slab's columns, one per wave
+#ifdef SK_NO_MFMA_SLAB   // A/B builds only
+    const bool slab_mfma = false;
+#else
+    const bool slab_mfma = MT == 1 && J.mode == 0 && J.q_slab && a_tiles <= SK_WAVES;
+#endif
+    float4 wq_a = make_float4(0.f, 0.f, 0.f, 0.f), wq_b = wq_a, wq_c = wq_a, wq_x = wq_a;
+    const bool slab_wave = slab_mfma && wave < a_tiles;
+    if (slab_wave && 32 * wave + bl < J.att_dim) {   // (columns past att_dim keep zero weights and are never stored)
         const float* wq_l = J.Wq_t + ((long)tile * J.att_dim + 32 * wave + bl) * 8;
         wq_a = *reinterpret_cast<const float4*>(wq_l);
         wq_b = *reinterpret_cast<const float4*>(wq_l + 4);
         if (XH && has_x) wq_c = *reinterpret_cast<const float4*>(J.Wq_t + ((long)xt * J.att_dim + 32 * wave + bl) * 8 + 4 * xhalf);
+        if (J.xw) wq_x = *reinterpret_cast<const float4*>(J.xw + ((long)tile * J.att_dim + 32 * wave + bl) * 4);
     }
+    // extra slab terms (J.xw): the lane's two values xsrc[b][4 tile + kh], xsrc[b][4 tile + 2 + kh].  Read with sc1 loads - the
+    // vector may have been published inside this launch by another kernel -, at the start of the launch or, when it is the
+    // deferred segment, right after its arrival (their latency then hides under the deferred k-groups)
+    float xe_a = 0.f, xe_b = 0.f;
+    auto load_extra = [&]() {
+        if (slab_wave && J.xw) {
+            const __amdgpu_buffer_rsrc_t rxs = make_rsrc(J.xsrc);
+            const unsigned k0 = 4u * (unsigned)tile;
+            const unsigned off = ((k0 >> 3) * (unsigned)blk + (unsigned)(bl < B ? bl : 0) * 8u + (k0 & 7u) + (unsigned)h) * 4u;
+            xe_a = load_sc1_f32(rxs, off);
+            xe_b = load_sc1_f32(rxs, off + 8u);
+        }
+    };
+    if (!(DEFER && J.defer_seg && J.ctx_cnt)) load_extra();
 
     // ---- main loop: this wave's K slice, software pipelined DEPTH k-groups deep.
     // Per k-group a wave issues one 1-KiB weight load (HBM / Infinity Cache) and MT 1-KiB x-loads (L2); with DEPTH
@@ -374,6 +395,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                 while (*seen == 0) __builtin_amdgcn_s_sleep(4);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the compiler from moving the loads above the poll
+            load_extra();
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(J.x[1].p);
             unsigned xo[MT];
 #pragma unroll
@@ -520,7 +542,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             // B = Wq^T (lane (d, kh): Wq[d][2 s + kh]); lane (d, hh) receives D[b = 8 g + 4 hh + r][d] in register 4 g + r,
             // so every store instruction writes two rows of 32 consecutive floats.  The sum runs over j in index order,
             // the chain the VALU form used (which took ~2 us of dependent FMAs and LDS reads here).
-            if (wave < (a >> 5)) {
+            if (slab_wave) {
                 f32x16 qa;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) qa[q] = 0.f;
@@ -534,14 +556,20 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                     qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow2[0], h ? wq_c.y : wq_c.x, qa, 0, 0, 0);
                     qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow2[2], h ? wq_c.w : wq_c.z, qa, 0, 0, 0);
                 }
-                float* qout = J.q_slab + (long)slab * B * a + 32 * wave + bl;
+                if (J.xw) {
+                    qa = __builtin_amdgcn_mfma_f32_32x32x2f32(xe_a, h ? wq_x.y : wq_x.x, qa, 0, 0, 0);
+                    qa = __builtin_amdgcn_mfma_f32_32x32x2f32(xe_b, h ? wq_x.w : wq_x.z, qa, 0, 0, 0);
+                }
+                if (32 * wave + bl < a) {
+                    float* qout = J.q_slab + (long)slab * B * a + 32 * wave + bl;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                    for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int b = 8 * g + 4 * h + r;
-                        if (b < B) qout[(long)b * a] = qa[4 * g + r];
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const int b = 8 * g + 4 * h + r;
+                            if (b < B) qout[(long)b * a] = qa[4 * g + r];
+                        }
+                }
             }
             if (J.ready_cnt && tid == 0) handoff_wait(J.ready_cnt, J.ready_target, J.tmo, 0x300u, J.spin_limit);
             if (jobs.njobs >= 2) GVX_STAMP(0, 4);
@@ -625,6 +653,8 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_ker
     if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }
     skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
 }
+// autoregressive launch C beside the resident attention kernel: the context of the step arrives inside the launch (deferred segment)
+__global__ __launch_bounds__(SK_THREADS) void ar_lstm_defer_kernel(SkinnyJobs jobs) { skinny_body<1, SK_DEPTH1, false, true>(jobs); }
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs); }
 
 static size_t skinny_lds(int MT) { return (size_t)(SK_WAVES * MT * 16 * 64 + MT * 32 * 8) * sizeof(float); }
@@ -644,6 +674,7 @@ hipError_t skinny_init() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel<SK_DEPTH1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
     if ((e = set_lds(decoder_lstm_drain_pa_kernel, 1)) != hipSuccess) return e;
+    if ((e = set_lds(ar_lstm_defer_kernel, 1)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
     return set_lds(encoder_lstm_step_kernel<2>, 2);
 }
@@ -678,6 +709,8 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
     for (int i = 0; i < njobs; ++i)
         if (jobs[i].mode == 2 && (jobs[i].N & 31)) return hipErrorInvalidValue;   // partial tiles store whole float4 rows
     if (B < 1 || B > 64) return hipErrorInvalidValue;
+    for (int i = 0; i < njobs; ++i)
+        if ((jobs[i].defer_seg || jobs[i].xw) && B > 32) return hipErrorInvalidValue;   // one batch tile only
     int extra = 0;
     js.loc = LocJob{};
     if (loc && loc->G > 0) {
@@ -703,7 +736,10 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
             decoder_lstm_drain_pa_kernel<<<grid, block, lds, s>>>(js);
         } else if (kind == SK_DECODER) decoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
         else if (kind == SK_ENCODER) encoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
-        else ar_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
+        else if (jobs[0].defer_seg) {
+            if (extra) return hipErrorInvalidValue;
+            ar_lstm_defer_kernel<<<grid, block, lds, s>>>(js);
+        } else ar_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
     }
     return hipGetLastError();
 }

@@ -401,3 +401,54 @@ def test_status_words_are_sticky_across_calls():
     with pytest.raises(IndexError):
         m.check_status()
     m.check_status()          # cleared by the look
+
+
+def test_autoregressive_resident_attention_equals_per_step(monkeypatch):
+    """The autoregressive loop can run its attention as ONE kernel beside the step launches (GVX_AR_RESIDENT=1; default
+    layer sizes, B <= 32, L <= 128; the context of a step is handed over inside launch C) instead of a launch per step.  Ragged token lengths, rows that
+    stop at different steps (gate threshold chosen so that some rows fire early and the host ends the loop before
+    max_decoder_steps: the resident kernel must leave on the stop word), fixed masks: same frame counts, same numbers, no
+    time-out, repeatable bit for bit; row 0 against a batch-1 oracle run."""
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
+    steps = 40
+    mc.max_decoder_steps = steps
+    sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+    lens = [50, 41, 33, 20, 9]
+    B, L = len(lens), max(lens)
+    tok = (gw.hashed_uniform(31, "arres", B * L) * tc.n_tokens).astype(np.int64).reshape(B, L)
+    for b, n in enumerate(lens):
+        tok[b, n:] = 0
+    masks = torch.from_numpy(gw.prenet_keep_masks(steps * B, mc.prenet_dim, seed=9)).reshape(2, steps, B, mc.prenet_dim)
+    inputs = {"tokens": torch.from_numpy(tok), "token_lengths": torch.tensor(lens), "prenet_keep_masks": masks}
+
+    def run(threshold):
+        mc.gate_threshold = threshold
+        m = Tacotron2(mc, ac, tc)
+        m.load_state_dict(sd)
+        m = m.to("cuda:0")
+        a = m.inference(inputs)
+        b = m.inference(inputs)
+        for k in KEYS:
+            assert torch.equal(a[k], b[k]), k
+        return a
+
+    monkeypatch.setenv("GVX_AR_RESIDENT", "1")   # opt-in path (off by default: no faster, see gvx_api.hip)
+    # pick a threshold between the rows' gate values so that rows stop at different steps
+    probe = run(1.0)
+    g = torch.sigmoid(probe["gate_outputs"][:, :8]).cpu()
+    thr = float(g.flatten().sort().values[g.numel() // 2])
+    res = run(thr)
+    monkeypatch.setenv("GVX_AR_RESIDENT", "0")
+    per = run(thr)
+    assert res["mel_lengths"].cpu().tolist() == per["mel_lengths"].cpu().tolist()
+    assert res["mel_outputs"].shape == per["mel_outputs"].shape
+    assert int(res["mel_lengths"].min()) < steps   # at least one row stopped on its gate
+    for k in KEYS:
+        assert torch.isfinite(res[k]).all(), k
+        assert max_abs_diff(res[k], per[k]) <= 2e-5, k
+    want = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(tok[:1]), masks[:, :, 0], thr, steps, token_length=lens[0])
+    nf = want["mel_outputs"].shape[2]
+    assert int(res["mel_lengths"][0]) == nf
+    for k in ("mel_outputs", "gate_outputs", "alignments"):
+        got = res[k][:1, ..., :nf] if k != "alignments" else res[k][:1, :nf]
+        assert max_abs_diff(got, want[k]) <= TOL, k

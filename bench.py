@@ -51,7 +51,7 @@ def algorithmic_bytes_lstm_launch(mc, B, L, persistent=False):
     P, E, A, D, a = mc.prenet_dim, mc.encoder_embedding_dim, mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.attention_dim
     weights = 4 * A * (P + E + A) + 4 * D * (A + E + D) + 4 * A + 4 * D
     per_row = (P + E + A) + (A + E + D) + 2 * (A + D) + (A + D)
-    slabs = (96 if persistent else A // 8) * a
+    slabs = ((96 if L <= 128 else 64) if persistent else A // 8) * a   # launch layouts of skinny.hip: 224 / 192 workgroups
     loc = 0 if persistent else 2 * L + L * a
     if persistent:   # the Prenet columns of the attention LSTM are applied by one GEMM before the loop: the launch reads their
         weights -= 4 * A * P          # product (4A floats per row) instead of the 4A x P weights and the P inputs per row

@@ -41,6 +41,7 @@ constexpr int PA_KL_MAX = 31;
 constexpr int PA_SLABS = 96;   // workgroups of the attention LSTM in the teacher-forced launch's layout (skinny.hip): one query slab each
 constexpr int PA_SLABS_AR = 128;   // autoregressive launches: one slab per attention-LSTM tile
 constexpr int PA_WC_S = PA_L + 32;   // stride of the two halo-padded weight rows (prev, cum); taps are padded to 32
+constexpr int PA_XCH = PA_E + 64;    // floats of one exchange buffer of the split kernel: c[512], (m, s, -, -), edge energies[16]
 
 // LDS layout (floats)
 constexpr int PA_OFF_LOC = 0;                                  // [128][128] location features, float4 groups swizzled by (l & 1)
@@ -90,8 +91,17 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 }  // namespace
 
 // SPG: query slabs per group of 32 threads (32 groups): 3 = the 96 slabs of the teacher-forced launch, 4 = the 128 of the
-// autoregressive launches
-template <int SPG>
+// autoregressive launches, 2 = the 64 of the launch beside the split kernel.
+// SPLIT (128 < L <= 256): TWO workgroups per batch row, each with one half of the positions resident (a row of 256 positions
+// is 512 KB of encoder memory: two CUs' worth of registers).  Per step each half computes its energies, its local maximum m,
+// the local sum s of exp(e - m) and the unnormalised context c = sum exp(e - m) memory[l], and hands (m, s, c, the 16
+// energies next to the cut) to its partner through global memory (write-through stores, one flag word per half, double
+// buffered by step parity: guideline 16 again); both then form M = max(m0, m1), f_h = exp(m_h - M), S = s0 f0 + s1 f1 and
+// the context (c0 f0 + c1 f1) / S with the operands in half order - bit-identical in both -, and normalise their own
+// weights and those of the partner's 15 positions next to the cut (the halo of the location convolution) as
+// exp(e - M) / S.  Half 0 publishes the context.  The softmax equals the reference's (models/tts/tacotron2.py:126) up to
+// rounding (1e-7 relative).
+template <int SPG, bool SPLIT>
 __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersistParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* locf = smem + PA_OFF_LOC;
@@ -106,10 +116,13 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     float* cp = smem + PA_OFF_CP;
     volatile int* leave = reinterpret_cast<volatile int*>(smem + PA_OFF_FLAG);
 
-    const int b = blockIdx.x, B = p.B, L = p.L, kl = p.kl, pad = (kl - 1) / 2;
+    const int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, hf = SPLIT ? (int)(blockIdx.x & 1) : 0;
+    const int B = p.B, kl = p.kl, pad = (kl - 1) / 2;
+    const int l_base = PA_L * hf;                    // first position of this workgroup
+    const int L = min(PA_L, p.L - l_base);           // positions held here (>= 1: the split kernel runs for p.L > PA_L only)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int len = p.lengths ? p.lengths[b] : L;
+    const int len = (p.lengths ? p.lengths[b] : p.L) - l_base;   // valid positions among them (may be <= 0 in half 1)
     unsigned* const cnt_q = p.sync + HANDOFF_CNT_Q;
     unsigned* const cnt_ctx = p.sync + HANDOFF_CNT_CTX;
     unsigned* const tmo = p.sync + HANDOFF_TIMEOUT;
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     float4 mem[16];
     {
         const int e4 = tid & 127, lg = tid >> 7;
-        const float4* mb = reinterpret_cast<const float4*>(p.memory) + (long)b * L * (PA_E / 4);
+        const float4* mb = reinterpret_cast<const float4*>(p.memory) + ((long)b * p.L + l_base) * (PA_E / 4);
 #pragma unroll
         for (int i = 0; i < 16; ++i) mem[i] = mb[(long)min(16 * lg + i, L - 1) * (PA_E / 4) + e4];
     }
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     float4 pmr[4];
     {
         const int el = tid >> 3, dg = tid & 7;
-        const float4* pb = reinterpret_cast<const float4*>(p.pm) + ((long)b * L + min(el, L - 1)) * (PA_A / 4);
+        const float4* pb = reinterpret_cast<const float4*>(p.pm) + ((long)b * p.L + l_base + min(el, L - 1)) * (PA_A / 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) pmr[j] = pb[dg + 8 * j];
     }
@@ -256,22 +269,24 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         float mx = -INFINITY;
         for (int l = lane; l < L; l += 64) mx = fmaxf(mx, es[l]);
         mx = wave_max_dpp(mx);
+        // SPLIT: a half whose positions are all masked has mx = -inf; its local terms use reference 0 and come out as zeros
+        const float mref = (SPLIT && mx == -INFINITY) ? 0.f : mx;
         float sum = 0.f;
-        for (int l = lane; l < L; l += 64) sum += __expf(es[l] - mx);
+        for (int l = lane; l < L; l += 64) sum += __expf(es[l] - mref);
         sum = wave_sum_dpp(sum);
-        const float inv = 1.f / sum;
+        float inv = SPLIT ? 1.f : 1.f / sum;   // SPLIT: the context partials stay unnormalised until the halves have met
         {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int l = 16 * lg + i;
-                const float w = l < L ? __expf(es[l] - mx) * inv : 0.f;   // exactly 0 past the row's length (exp(-inf))
+                const float w = l < L ? __expf(es[l] - mref) * inv : 0.f;   // exactly 0 past the row's length (exp(-inf))
                 acc.x = fmaf(w, mem[i].x, acc.x); acc.y = fmaf(w, mem[i].y, acc.y);
                 acc.z = fmaf(w, mem[i].z, acc.z); acc.w = fmaf(w, mem[i].w, acc.w);
             }
             reinterpret_cast<float4*>(cp)[lg * 128 + e4] = acc;
         }
-        if (wave == 0) {   // alignment row out; previous / cumulative weights for the next location features
+        if (!SPLIT && wave == 0) {   // alignment row out; previous / cumulative weights for the next location features
             for (int l = lane; l < L; l += 64) {
                 const float w = __expf(es[l] - mx) * inv;
                 p.w_out[(long)t * p.w_out_ts + (long)b * p.w_out_bs + l] = w;
@@ -281,20 +296,78 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         }
         __syncthreads();
         PA_STAMP(4);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tq < 128) {
-            float4 o = reinterpret_cast<const float4*>(cp)[tq];
+            o = reinterpret_cast<const float4*>(cp)[tq];
 #pragma unroll
             for (int g = 1; g < 8; ++g) {
                 const float4 x = reinterpret_cast<const float4*>(cp)[g * 128 + tq];
                 o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w;
             }
+        }
+        if (SPLIT) {
+            // ---- hand (m, s, c, edge energies) to the partner half and take its; buffers alternate with the step's parity
+            // (a half can be at most one publication ahead of what its partner has read)
+            float* const xb_own = p.xchg + (((long)b * 2 + hf) * 2 + (t & 1)) * PA_XCH;
+            const float* const xb_par = p.xchg + (((long)b * 2 + (hf ^ 1)) * 2 + (t & 1)) * PA_XCH;
+            unsigned* const flag_own = p.sync + HANDOFF_PAIR + (b * 2 + hf) * 32;
+            const unsigned* const flag_par = p.sync + HANDOFF_PAIR + (b * 2 + (hf ^ 1)) * 32;
+            {
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(xb_own);
+                if (tq < 128) store_sc1(ro, (unsigned)tq * 16u, o);
+                else if (tq == 128) store_sc1(ro, 512u * 4u, make_float4(mx, sum, 0.f, 0.f));
+                else if (tq >= 132 && tq < 136) {   // the 16 energies next to the cut: the last 16 positions of half 0, the first 16 of half 1
+                    const int i4 = tq - 132, e0 = hf == 0 ? PA_L - 16 : 0;
+                    store_sc1(ro, (516u + 4u * (unsigned)i4) * 4u, *reinterpret_cast<const float4*>(es + e0 + 4 * i4));
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the flag goes up
+            }
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(flag_own, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!handoff_wait<true>(flag_par, (unsigned)t + 1u, tmo, 0x400u + (unsigned)blockIdx.x, p.spin_limit, stop)) *leave = 1;
+            }
+            __syncthreads();
+            if (*leave) break;
+            const __amdgpu_buffer_rsrc_t rp = make_rsrc(xb_par);
+            const float4 hd = load_sc1(rp, 512u * 4u);                          // partner's (m, s)
+            const float4 cpar = tq < 128 ? load_sc1(rp, (unsigned)tq * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float m0 = hf == 0 ? mx : hd.x, m1 = hf == 0 ? hd.x : mx;     // operands in half order: both halves compute the same bits
+            const float s0 = hf == 0 ? sum : hd.y, s1 = hf == 0 ? hd.y : sum;
+            const float M = fmaxf(m0, m1);                                      // finite: position 0 of half 0 is never masked
+            const float f0 = m0 == -INFINITY ? 0.f : __expf(m0 - M), f1 = m1 == -INFINITY ? 0.f : __expf(m1 - M);
+            inv = 1.f / (s0 * f0 + s1 * f1);
+            if (tq < 128) {
+                const float4 c0 = hf == 0 ? o : cpar, c1 = hf == 0 ? cpar : o;
+                o.x = (c0.x * f0 + c1.x * f1) * inv; o.y = (c0.y * f0 + c1.y * f1) * inv;
+                o.z = (c0.z * f0 + c1.z * f1) * inv; o.w = (c0.w * f0 + c1.w * f1) * inv;
+            }
+            if (wave == 0) {   // alignment row out; previous / cumulative weights (own positions + the partner's `pad` next to the cut)
+                for (int l = lane; l < L; l += 64) {
+                    const float w = __expf(es[l] - M) * inv;
+                    p.w_out[(long)t * p.w_out_ts + (long)b * p.w_out_bs + l_base + l] = w;
+                    wc[pad + l] = w;
+                    wc[PA_WC_S + pad + l] += w;
+                }
+                if (lane < pad) {
+                    // half 0: halo = local positions 128 .. 128 + pad - 1 = the partner's first `pad` energies (edge[i]);
+                    // half 1: halo = local positions -pad .. -1 = the partner's last `pad` (edge[16 - pad + i])
+                    const float e = load_sc1_f32(rp, (516u + (unsigned)(hf == 0 ? lane : 16 - pad + lane)) * 4u);
+                    const float w = __expf(e - M) * inv;
+                    const int idx = hf == 0 ? pad + PA_L + lane : lane;
+                    wc[idx] = w;
+                    wc[PA_WC_S + idx] += w;
+                }
+            }
+        }
+        if (tq < 128 && hf == 0) {
             // blocked context vector [E/8][B][8] of step t, write-through
             const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.ctx_base + (long)t * p.ctx_ts);
             store_sc1(rc, (unsigned)((tq >> 1) * B * 8 + b * 8 + 4 * (tq & 1)) * 4u, o);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt_ctx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && hf == 0) __hip_atomic_fetch_add(cnt_ctx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PA_STAMP(5);
         // ---- off the chain: location features of step t + 1
         if (t + 1 < p.T) location_features();
@@ -303,18 +376,25 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
 }
 
 bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, int att_rnn_dim, int dec_rnn_dim) {
-    // default layer sizes only: the launch layout (skinny.hip) deals 128 + 128 tiles to 224 workgroups
-    return B >= 1 && B <= 32 && L >= 1 && L <= PA_L && a == PA_A && E == PA_E && F >= 1 && F <= 32 && kl >= 1 && kl <= PA_KL_MAX &&
+    // default layer sizes only: the launch layouts (skinny.hip) deal 128 + 128 tiles to 224 / 192 workgroups.
+    // L <= 128: one workgroup per row (32 CUs at most); 128 < L <= 256: two per row (64 CUs at most)
+    return B >= 1 && B <= 32 && L >= 1 && L <= 2 * PA_L && a == PA_A && E == PA_E && F >= 1 && F <= 32 && kl >= 1 && kl <= PA_KL_MAX &&
            (kl & 1) && att_rnn_dim == 1024 && dec_rnn_dim == 1024;
 }
-int attention_persistent_slabs() { return PA_SLABS; }
+int attention_persistent_layout(int L) { return L <= PA_L ? 1 : 2; }
+int attention_persistent_slabs(int layout) { return layout == 2 ? 64 : PA_SLABS; }
+int attention_persistent_workgroups(int B, int L) { return L <= PA_L ? B : 2 * B; }
+size_t attention_persistent_xchg_floats(int B) { return (size_t)B * 2 * 2 * PA_XCH; }
 
+template <typename K>
+static hipError_t pa_set_lds(K kern) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS_FLOATS * (int)sizeof(float));
+}
 hipError_t attention_persistent_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_persistent_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       PA_LDS_FLOATS * (int)sizeof(float));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_persistent_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               PA_LDS_FLOATS * (int)sizeof(float));
+    hipError_t e;
+    if ((e = pa_set_lds(attn_persistent_kernel<3, false>)) != hipSuccess) return e;
+    if ((e = pa_set_lds(attn_persistent_kernel<4, false>)) != hipSuccess) return e;
+    return pa_set_lds(attn_persistent_kernel<2, true>);
 }
 
 __global__ void handoff_set_kernel(unsigned* word) { __hip_atomic_store(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -330,10 +410,14 @@ hipError_t read_stamps_persist(unsigned long long* host96) {
 #endif
 
 hipError_t launch_attention_persistent(const AttnPersistParams& p, hipStream_t s) {
-    if (!attention_persistent_supported(p.B, p.L, PA_A, 32, p.kl, PA_E, 1024, 1024) || (p.n_slabs != PA_SLABS && p.n_slabs != PA_SLABS_AR) || p.T < 1)
-        return hipErrorInvalidValue;
-    if (p.n_slabs == PA_SLABS) attn_persistent_kernel<3><<<dim3(p.B), dim3(PA_THREADS), PA_LDS_FLOATS * sizeof(float), s>>>(p);
-    else attn_persistent_kernel<4><<<dim3(p.B), dim3(PA_THREADS), PA_LDS_FLOATS * sizeof(float), s>>>(p);
+    if (!attention_persistent_supported(p.B, p.L, PA_A, 32, p.kl, PA_E, 1024, 1024) || p.T < 1) return hipErrorInvalidValue;
+    const size_t lds = PA_LDS_FLOATS * sizeof(float);
+    if (p.L > PA_L) {
+        if (p.n_slabs != 64 || !p.xchg) return hipErrorInvalidValue;
+        attn_persistent_kernel<2, true><<<dim3(2 * p.B), dim3(PA_THREADS), lds, s>>>(p);
+    } else if (p.n_slabs == PA_SLABS) attn_persistent_kernel<3, false><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
+    else if (p.n_slabs == PA_SLABS_AR) attn_persistent_kernel<4, false><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

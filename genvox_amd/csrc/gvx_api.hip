@@ -88,7 +88,7 @@ inline size_t frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * (K / 
 struct WsPlan {  // byte offsets into the caller's workspace
     size_t xa, xb, xg, enc_h, enc_c, flags, sync, memory;
     size_t pm, frames, pre1, prenet, h_a, c_a, c_d, hc, w_cum, q_slab, proj, energies, align_tm, len_copy, loc, ar_masks, p_slab, p_ctx;
-    size_t att_part, dec_part, pre_gate;
+    size_t att_part, dec_part, pre_gate, xchg;
     size_t ya, yb;
     size_t total;
 };
@@ -255,6 +255,7 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T, int mode = WS_TEACH
     // teacher-forced loop beside the persistent attention kernel: Prenet contribution to the attention LSTM's gates, all steps
     // (only where that loop can run: 0.5 GB at B = 32, T = 1000 that the autoregressive / launch-per-step paths never touch)
     w.pre_gate = take(mode == WS_TEACHER_FORCED && persistent_path(m, B, L) ? (size_t)T * B * 4 * A : 0);
+    w.xchg = take(attention_persistent_xchg_floats(B));   // split resident kernel (128 < L <= 256): exchange buffers of the row halves
     w.ar_masks = take(((size_t)2 * T * B * P + 3) / 4);  // autoregressive mode: keep masks copied next to the graphs' operands (bytes)
     const int cmax = d.postnet_dim > M ? d.postnet_dim : M;
     w.ya = take((size_t)B * (T + 2 * pp) * cmax);
@@ -908,6 +909,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     // Persistent attention (attn_persist.hip): the loop is then T + 1 LSTM launches on `st` and ONE attention kernel on a
     // forked stream; the LSTM tiles stream the k-groups of the context last and wait for it in the launch.
     const bool pa = persistent_path(m, B, L);
+    const int pa_layout = attention_persistent_layout(L);   // 1: L <= 128 (32 CUs, 224 workgroups); 2: L <= 256 (64 CUs, 192 workgroups)
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
     if (pa && !prenet_done) {   // (the fused forward has taken a side stream for this call already: the encoder ran on it)
         rc = ensure_side_stream(m);
@@ -928,7 +930,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         J.spin_limit = m->spin_limit;
         if (t_ctx >= 0) { J.ctx_cnt = sync + HANDOFF_CNT_CTX; J.ctx_target = (unsigned)B * (unsigned)(t_ctx + 1); }
         J.start_cnt = sync + HANDOFF_CNT_Q;   // every launch of the loop (and the drain launch) announces its start
-        if (first) { J.ready_cnt = sync + HANDOFF_READY; J.ready_target = (unsigned)B; }
+        if (first) { J.ready_cnt = sync + HANDOFF_READY; J.ready_target = (unsigned)attention_persistent_workgroups(B, L); }
     };
     // The resident kernel is launched eagerly on the handle's side stream, ordered behind everything already queued on `s`;
     // only the LSTM chain is replayed from a graph (a graph that contains both may run its branches one after the other -
@@ -937,7 +939,8 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         HIP_TRY(hipEventRecord(m->pa_fork, st));
         HIP_TRY(hipStreamWaitEvent(m->pa_stream, m->pa_fork, 0));
         AttnPersistParams pp{};
-        pp.q_slab = db.q_slab; pp.n_slabs = attention_persistent_slabs();
+        pp.q_slab = db.q_slab; pp.n_slabs = attention_persistent_slabs(pa_layout);
+        pp.xchg = ws_ptr<float>(ws, wp.xchg);
         pp.v = m->dev_blob + m->blob.v; pp.pm = db.pm; pp.memory = memory; pp.lengths = len_ws;
         pp.loc_conv_t = m->dev_blob + m->blob.loc_conv; pp.loc_dense_t = m->dev_blob + m->blob.loc_dense;
         pp.w_out = db.align_tm; pp.w_out_bs = (long)L; pp.w_out_ts = (long)B * L;
@@ -958,7 +961,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
                 defer(jobs[1], t - 1, false);
             }
             if (pa) {
-                HIP_TRY(launch_skinny_pa(jobs[0], t > 0 ? &jobs[1] : nullptr, st, m->pa_depth));
+                HIP_TRY(launch_skinny_pa(jobs[0], t > 0 ? &jobs[1] : nullptr, st, m->pa_depth, pa_layout));
                 ++launches;
                 continue;
             }
@@ -982,7 +985,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         if (rc != GVX_OK) return rc;
     }
     if (m->use_graph && !kt) {
-        const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr, 0.f, pa ? m->pa_depth : 0};
+        const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr, 0.f, pa ? m->pa_depth + 16 * pa_layout : 0};
         rc = run_chunk(m, touch_graph_set(m, m->loop_graphs, key), 0, s, enqueue_loop);
         if (rc != GVX_OK) return rc;
         launches = pa ? T + 1 : (m->attn_one_launch ? 2 : 3) * T + 1;
@@ -1011,7 +1014,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
             if (tm > 0) defer(jobs[1], tm - 1, false);
             jobs[0].start_cnt = jobs[1].start_cnt = nullptr;
             HIP_TRY(hipEventRecord(m->kev[0], s));
-            for (int i = 0; i < REPS; ++i) HIP_TRY(launch_skinny_pa(jobs[0], tm > 0 ? &jobs[1] : nullptr, s, m->pa_depth));
+            for (int i = 0; i < REPS; ++i) HIP_TRY(launch_skinny_pa(jobs[0], tm > 0 ? &jobs[1] : nullptr, s, m->pa_depth, pa_layout));
             HIP_TRY(hipEventRecord(m->kev[1], s));
             HIP_TRY(hipEventRecord(m->kev[2], s));
             m->n_lstm_ev = REPS;
@@ -1327,7 +1330,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     // the whole decode, the context of a step arrives inside launch C (deferred segment) and the attention launch leaves the
     // step's chain.  The projection's context columns then ride on the decoder-LSTM tiles' projection slabs (`fold`), so that
     // launch C is exactly 256 tiles.
-    const bool pa = m->ar_resident && m->attn_one_launch &&
+    const bool pa = m->ar_resident && m->attn_one_launch && attention_persistent_layout(L) == 1 &&
                     attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
     const bool fold = B <= 32 && E / 4 == D / 8;
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);

@@ -121,7 +121,8 @@ enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_AR = 2 };  // kernel 
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc = nullptr);
 // teacher-forced step beside the persistent attention kernel: attention-LSTM (+ decoder-LSTM of the previous step) dealt to
 // 96 (224) workgroups of equal weight (skinny.hip); default layer sizes, B <= 32
-hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s, int depth = 4);
+// layout 1: 224 (96) workgroups beside a 32-CU resident kernel; layout 2: 192 (64) workgroups beside a 64-CU one (skinny.hip)
+hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s, int depth = 4, int layout = 1);
 
 // ---------------------------------------------------------------------------------------------
 // Location-sensitive attention, one decoder step, split over G workgroups per batch row:
@@ -158,7 +159,8 @@ bool attention_supported(int L, int a, int F, int kl, int E);
 // word indices: 4 KB apart, so that the pollers of one word do not queue in front of another word's traffic at the same channel
 constexpr int HANDOFF_CNT_Q = 0, HANDOFF_CNT_CTX = 1024, HANDOFF_READY = 2048, HANDOFF_TIMEOUT = 3072;
 constexpr int HANDOFF_STOP = 3072 + 512;   // the host's "the loop has ended early" word (autoregressive decode): the resident kernel leaves
-constexpr int HANDOFF_WORDS = 4096;
+constexpr int HANDOFF_PAIR = 4096;   // split resident kernel: flag word of half hf of row b at HANDOFF_PAIR + (2 b + hf) * 32
+constexpr int HANDOFF_WORDS = 8192;
 constexpr unsigned HANDOFF_SPIN_LIMIT = 200000u;   // polls with ~2 us of s_sleep between them (a few hundred ms), then the wait gives up
 struct AttnPersistParams {
     const float* q_slab; int n_slabs;       // [n_slabs][B][a], rewritten (sc1) by the attention-LSTM tiles every step
@@ -169,11 +171,15 @@ struct AttnPersistParams {
     unsigned* sync;                         // HANDOFF_WORDS words
     int B, L, T, kl;
     unsigned spin_limit;                    // polls before a wait gives up (0 = HANDOFF_SPIN_LIMIT)
+    float* xchg;                            // split kernel (L > 128): exchange buffers of the row halves, attention_persistent_xchg_floats(B)
     unsigned q_first;                       // step t waits for the query counter to reach t + q_first (teacher-forced loop: 2 -
                                             // launch 0 signals too; autoregressive loop: 1 - one signalling launch per step)
 };
 bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, int att_rnn_dim, int dec_rnn_dim);
-int attention_persistent_slabs();
+int attention_persistent_layout(int L);             // 1: one workgroup per row, launch layout 1; 2: two per row, launch layout 2
+int attention_persistent_slabs(int layout);         // query slabs of the launch layout
+int attention_persistent_workgroups(int B, int L);  // resident workgroups (= CUs held)
+size_t attention_persistent_xchg_floats(int B);
 hipError_t attention_persistent_init();
 hipError_t launch_attention_persistent(const AttnPersistParams& p, hipStream_t s);
 // *word = 1 with an agent-scope store (the form every polled hand-off word is written in)

@@ -167,16 +167,29 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 //   blocks [64, 96):  attention-LSTM tiles 96 .. 127             (224 KB)
 //   blocks [96, 224): decoder-LSTM tiles                         (320 KB)
 // block 2m carries tile 3m and rows 0..15 of tile 3m + 1, block 2m + 1 tile 3m + 2 and rows 16..31 of tile 3m + 1.
-template <int MT, int DEPTH, bool XH = false, bool DEFER = false>
+//
+// RT = 2: the workgroup carries TWO consecutive row tiles (tile, tile + 1: 64 packed rows) through one pass over x - two
+// weight fragments per x fragment.  Layout of the teacher-forced launch beside a resident attention kernel that holds 64
+// CUs (two workgroups per batch row, 128 < L <= 256: attn_persist.hip), pa_layout 2, 192 workgroups:
+//   blocks [0, 64):   attention-LSTM tiles 2 m, 2 m + 1   (448 KB of weights + 224 KB of x)
+//   blocks [64, 192): decoder-LSTM tiles                   (320 KB of weights + 320 KB of x)
+// - about equal bytes through every CU's load path.  One batch tile only (MT = 1), no half tiles.
+template <int MT, int DEPTH, bool XH = false, bool DEFER = false, int RT = 1>
 __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
+    static_assert(RT == 1 || (RT == 2 && MT == 1 && !XH), "two row tiles: one batch tile, no half tile");
+    constexpr int NT = MT * RT;   // accumulator tiles per wave; t = rt (RT = 2) or mt (MT = 2)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* red = smem;                                   // [SK_WAVES][MT][16][64]
-    float* hs = smem + SK_WAVES * MT * 16 * 64;          // [MT*32][8] h' of this tile (LSTM + q slabs)
-    float* red2 = hs + MT * 32 * 8;                      // XH: [SK_WAVES][8][64] of the extra half tile, then its h' [32][4]
+    float* red = smem;                                   // [SK_WAVES][NT][16][64]
+    float* hs = smem + SK_WAVES * NT * 16 * 64;          // [MT*32][RT*8] h' of this workgroup's hidden units (LSTM + q slabs)
+    float* red2 = hs + NT * 32 * 8;                      // XH: [SK_WAVES][8][64] of the extra half tile, then its h' [32][4]
 
     int jsel = 0, tile = (int)blockIdx.x;
     int xt = -1, xhalf = 0;    // extra half tile: packed rows 16 xhalf .. 16 xhalf + 15 of tile xt
-    if (XH && jobs.pa_layout) {
+    if (jobs.pa_layout == 2) {
+        const int bid = (int)blockIdx.x;
+        if (RT == 2) tile = 2 * bid;
+        else { jsel = 1; tile = bid - 64; }
+    } else if (XH && jobs.pa_layout) {
         const int bid = (int)blockIdx.x;
         if (bid < 64) { const int m = bid >> 1, odd = bid & 1; tile = 3 * m + 2 * odd; xt = 3 * m + 1; xhalf = odd; }
         else if (bid < 96) tile = 96 + (bid - 64);
@@ -190,7 +203,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     if (DEFER && J.start_cnt && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_fetch_add(J.start_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (DEFER && J.ctx_cnt) {   // workgroup-local "context has arrived" word (see the deferred segment below)
-        if (threadIdx.x == 0) reinterpret_cast<volatile int*>(hs)[MT * 32 * 8 - 1] = 0;
+        if (threadIdx.x == 0) reinterpret_cast<volatile int*>(hs)[NT * 32 * 8 - 1] = 0;
         __syncthreads();
     }
     if (jobs.njobs >= 2) GVX_STAMP(0, 0);   // (stamps build: the single-job drain launch must not overwrite a step's stamps)
@@ -203,14 +216,15 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     // epilogue operands of this wave's unit (cell state, bias): fetched now so their latency hides under the main loop
     float c_pref = 0.f;
     float4 bias_pref = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (J.mode == 0 && wave < 4 * MT) {
-        const int mt_ = wave >> 2, g_ = wave & 3;
-        const int b_ = mt_ * 32 + bl, j_ = tile * 8 + 2 * g_ + h;
+    if (J.mode == 0 && wave < 4 * NT) {
+        const int t_ = wave >> 2, g_ = wave & 3;
+        const int mt_ = RT > 1 ? 0 : t_, tile_ = tile + (RT > 1 ? t_ : 0);
+        const int b_ = mt_ * 32 + bl, j_ = tile_ * 8 + 2 * g_ + h;
         if (b_ < B) c_pref = J.c[(long)b_ * (J.N >> 2) + j_];
-        if (J.bias) bias_pref = *reinterpret_cast<const float4*>(J.bias + tile * 32 + 8 * g_ + 4 * h);
+        if (J.bias) bias_pref = *reinterpret_cast<const float4*>(J.bias + tile_ * 32 + 8 * g_ + 4 * h);
         // decoder cells finished from partial sums (autoregressive launches): the addend is known at launch, fetch it now
         if (J.addend && !J.seq_out && b_ < B) {
-            const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b_ * J.add_bs + tile * 32 + 8 * g_ + 4 * h);
+            const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b_ * J.add_bs + tile_ * 32 + 8 * g_ + 4 * h);
             bias_pref.x += ad.x; bias_pref.y += ad.y; bias_pref.z += ad.z; bias_pref.w += ad.w;
         }
     }
@@ -242,7 +256,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         wq_a = *reinterpret_cast<const float4*>(wq_l);
         wq_b = *reinterpret_cast<const float4*>(wq_l + 4);
         if (XH && has_x) wq_c = *reinterpret_cast<const float4*>(J.Wq_t + ((long)xt * J.att_dim + 32 * wave + bl) * 8 + 4 * xhalf);
-        if (J.xw) wq_x = *reinterpret_cast<const float4*>(J.xw + ((long)tile * J.att_dim + 32 * wave + bl) * 4);
+        if (RT == 2) {   // second row tile: its 8 hidden units follow the first tile's in the slab's sum
+            const float* wq_l2 = J.Wq_t + ((long)(tile + 1) * J.att_dim + 32 * wave + bl) * 8;
+            wq_c = *reinterpret_cast<const float4*>(wq_l2);
+            wq_x = *reinterpret_cast<const float4*>(wq_l2 + 4);
+        }
+        if (RT == 1 && J.xw) wq_x = *reinterpret_cast<const float4*>(J.xw + ((long)tile * J.att_dim + 32 * wave + bl) * 4);
     }
     // extra slab terms (J.xw): the lane's two values xsrc[b][4 tile + kh], xsrc[b][4 tile + 2 + kh].  Read with sc1 loads - the
     // vector may have been published inside this launch by another kernel -, at the start of the launch or, when it is the
@@ -286,14 +305,15 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     // of the recurrent matrices: see the autoregressive step in gvx_api.hip)
     const int nkg_w = J.nkg_w > 0 ? J.nkg_w : J.nkg;
     const float4* wp = reinterpret_cast<const float4*>(J.Wp) + ((long)tile * nkg_w + J.kg0) * 64 + lane;
+    const float4* wp_b = wp + (long)nkg_w * 64;   // RT = 2: the same k-groups of tile + 1
     // extra half tile: the lanes of the other half read their partner's address (same bytes, no extra traffic): the copies
     // feed the second batch-row block of the 16x16x1 MFMAs below
     const bool x_mine = ((lane >> 4) & 1) == xhalf;
     const float4* wp2 = reinterpret_cast<const float4*>(J.Wp) + ((long)(has_x ? xt : tile) * nkg_w + J.kg0) * 64 + (x_mine ? lane : (lane ^ 16));
 
-    f32x16 acc[MT];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[mt][q] = 0.f;
     f32x16 acc2;   // XH only
@@ -304,7 +324,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     // XLOAD(mt, kg) loads the x fragment of k-group kg.
 #define SK_STREAM(S_BEGIN, S_END, MAP, XLOAD)                                                            \
     if ((S_BEGIN) < (S_END)) {                                                                            \
-        float4 wv[DEPTH], xv[MT][DEPTH], wv2[XH ? DEPTH : 1];                                             \
+        float4 wv[DEPTH], xv[MT][DEPTH], wv2[(XH || RT == 2) ? DEPTH : 1];                                \
         const int s_last = (S_END) - 1;                                                                   \
         _Pragma("unroll") for (int u = 0; u < DEPTH; ++u) SK_LOAD(u, (S_BEGIN) + u, MAP, XLOAD)           \
         int base = (S_BEGIN);                                                                             \
@@ -340,6 +360,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             const int s_ = min((ss), s_last);                                                         \
             const int g_ = MAP(s_);                                                                   \
             wv[slot] = wp[(long)g_ * 64];                                                            \
+            if (RT == 2) wv2[slot] = wp_b[(long)g_ * 64];                                            \
             if (XH && has_x) wv2[slot] = wp2[(long)g_ * 64];                                         \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) xv[mt][slot] = XLOAD(mt, g_);           \
         }
@@ -353,6 +374,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].y, xv[mt][slot].y, acc[mt], 0, 0, 0); \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].z, xv[mt][slot].z, acc[mt], 0, 0, 0); \
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot].w, xv[mt][slot].w, acc[mt], 0, 0, 0); \
+        }                                                                                                 \
+        if (RT == 2) {                                                                                    \
+            acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv2[slot].x, xv[0][slot].x, acc[NT - 1], 0, 0, 0); \
+            acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv2[slot].y, xv[0][slot].y, acc[NT - 1], 0, 0, 0); \
+            acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv2[slot].z, xv[0][slot].z, acc[NT - 1], 0, 0, 0); \
+            acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv2[slot].w, xv[0][slot].w, acc[NT - 1], 0, 0, 0); \
         }                                                                                                 \
         if (XH && has_x) {                                                                                \
             /* extra half tile on v_mfma_f32_16x16x1_4b_f32: four independent 16 x 16 blocks, block = lane >> 4.  With */ \
@@ -385,7 +412,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             // ONE wave per workgroup polls the counter (1 800 waves polling one word queue in front of the producer's own
             // add to it); the others watch a word in LDS that the polling wave sets.  The context is then read with sc1
             // loads only: the bytes were stored write-through by another kernel, a plain load could hit a stale L1 / L2 line
-            volatile int* seen = reinterpret_cast<volatile int*>(hs) + MT * 32 * 8 - 1;   // last word of hs (free until the epilogue)
+            volatile int* seen = reinterpret_cast<volatile int*>(hs) + NT * 32 * 8 - 1;   // last word of hs (free until the epilogue)
             if (wave == 0) {
                 handoff_wait(J.ctx_cnt, J.ctx_target, J.tmo, 0x200u, J.spin_limit);
                 *seen = 1;
@@ -427,9 +454,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
 #endif
     // ---- cross-wave K reduction through LDS
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) red[((wave * MT + mt) * 16 + q) * 64 + lane] = acc[mt][q];
+        for (int q = 0; q < 16; ++q) red[((wave * NT + mt) * 16 + q) * 64 + lane] = acc[mt][q];
     if (XH && has_x) {   // the two k-half blocks of a batch-row block are added here, before the cross-wave sum
 #pragma unroll
         for (int q = 0; q < 8; ++q) red2[(wave * 8 + q) * 64 + lane] = acc2[q] + acc2[8 + q];
@@ -461,15 +488,18 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         hs2[b2 * 4 + g2] = hval;
     }
 
-    // unit u = (mt, g): register group g (4 registers) of batch tile mt; one unit per wave
-    for (int u = wave; u < 4 * MT; u += SK_WAVES) {
-        const int mt = u >> 2, g = u & 3;
+    // unit u = (t, g): register group g (4 registers) of accumulator tile t (batch tile mt or row tile rt); one unit per wave
+    const int tile0 = tile;
+    for (int u = wave; u < 4 * NT; u += SK_WAVES) {
+        const int tt = u >> 2, g = u & 3;
+        const int mt = RT > 1 ? 0 : tt, rt = RT > 1 ? tt : 0;
+        const int tile = tile0 + rt;   // (shadows the workgroup's first tile inside the unit)
         float s[4];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < SK_WAVES; ++w) t += red[((w * MT + mt) * 16 + 4 * g + qq) * 64 + lane];
+            for (int w = 0; w < SK_WAVES; ++w) t += red[((w * NT + tt) * 16 + 4 * g + qq) * 64 + lane];
             s[qq] = t;
         }
         const int b = mt * 32 + bl;
@@ -506,7 +536,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                 }
                 J.h_out[hoff] = hval;
             }
-            if (J.q_slab) hs[b * 8 + jloc] = hval;
+            if (J.q_slab) hs[(b * RT + rt) * 8 + jloc] = hval;
         } else if (J.mode == 2) {
             // partial pre-activations of a column slice: raw sums, batch-major [B][N] (the layout `addend` is read in)
             if (b < B) *reinterpret_cast<float4*>(J.y + (long)b * J.N + n) = make_float4(s[0], s[1], s[2], s[3]);
@@ -535,7 +565,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         const int a = J.att_dim;
         const float* wq = J.Wq_t + (long)tile * a * 8;
         const float* wq2 = J.Wq_t + (long)(has_x ? xt : tile) * a * 8 + 4 * xhalf;
-        const int slab = (XH && jobs.pa_layout) ? (int)blockIdx.x : tile;   // one slab per workgroup
+        const int slab = jobs.pa_layout ? (int)blockIdx.x : tile;   // one slab per workgroup
         if (slab_mfma) {
             // slab[b][d] = sum_j h'[b][j] Wq[d][j] over the workgroup's 8 (12) hidden units on the matrix pipe: wave w takes
             // the attention dims 32 w .. 32 w + 31.  v_mfma_f32_32x32x2_f32 with A = h' (lane (b, kh): h'[b][2 s + kh]) and
@@ -546,7 +576,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                 f32x16 qa;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) qa[q] = 0.f;
-                const float* hrow = hs + bl * 8 + h;
+                const float* hrow = hs + bl * RT * 8 + h;
                 qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[0], h ? wq_a.y : wq_a.x, qa, 0, 0, 0);
                 qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[2], h ? wq_a.w : wq_a.z, qa, 0, 0, 0);
                 qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[4], h ? wq_b.y : wq_b.x, qa, 0, 0, 0);
@@ -556,7 +586,13 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                     qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow2[0], h ? wq_c.y : wq_c.x, qa, 0, 0, 0);
                     qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow2[2], h ? wq_c.w : wq_c.z, qa, 0, 0, 0);
                 }
-                if (J.xw) {
+                if (RT == 2) {   // hidden units of tile + 1
+                    qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[8], h ? wq_c.y : wq_c.x, qa, 0, 0, 0);
+                    qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[10], h ? wq_c.w : wq_c.z, qa, 0, 0, 0);
+                    qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[12], h ? wq_x.y : wq_x.x, qa, 0, 0, 0);
+                    qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[14], h ? wq_x.w : wq_x.z, qa, 0, 0, 0);
+                }
+                if (RT == 1 && J.xw) {
                     qa = __builtin_amdgcn_mfma_f32_32x32x2f32(xe_a, h ? wq_x.y : wq_x.x, qa, 0, 0, 0);
                     qa = __builtin_amdgcn_mfma_f32_32x32x2f32(xe_b, h ? wq_x.w : wq_x.z, qa, 0, 0, 0);
                 }
@@ -647,6 +683,13 @@ template <int DEPTH> __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_
     skinny_body<1, DEPTH, true, true>(jobs);
     GVX_WG_END();
 }
+// teacher-forced step beside the 64-CU resident attention kernel (128 < L <= 256): 192 (64) workgroups, attention-LSTM tiles in pairs
+__global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_pa192_kernel(SkinnyJobs jobs) {
+    GVX_WG_BEGIN();
+    if (blockIdx.x < 64) skinny_body<1, SK_DEPTH1, false, true, 2>(jobs);   // uniform per workgroup
+    else skinny_body<1, SK_DEPTH1, false, true, 1>(jobs);
+    GVX_WG_END();
+}
 // the launch that drains the loop (decoder-LSTM of the last step): ordinary layout, context handed over in-launch
 __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_drain_pa_kernel(SkinnyJobs jobs) { skinny_body<1, SK_DEPTH1, false, true>(jobs); }
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_kernel(SkinnyJobs jobs) {   // autoregressive launches A / C
@@ -674,15 +717,27 @@ hipError_t skinny_init() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel<SK_DEPTH1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
     if ((e = set_lds(decoder_lstm_drain_pa_kernel, 1)) != hipSuccess) return e;
+    if ((e = set_lds(decoder_lstm_step_pa192_kernel, 2)) != hipSuccess) return e;
     if ((e = set_lds(ar_lstm_defer_kernel, 1)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
     return set_lds(encoder_lstm_step_kernel<2>, 2);
 }
 
-hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s, int depth) {
-    // the layout is built for the default layer sizes: 128 tiles per cell, batch rows in one MFMA tile
+hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s, int depth, int layout) {
+    // the layouts are built for the default layer sizes: 128 tiles per cell, batch rows in one MFMA tile
     if (att.N != 4096 || att.B < 1 || att.B > 32 || att.mode != 0 || !att.q_slab || (dec && (dec->N != 4096 || dec->B != att.B || dec->mode != 0)))
         return hipErrorInvalidValue;
+    if (layout == 2) {   // attention-LSTM tiles in pairs: the slab phase exists in its MFMA form only
+        if ((att.att_dim + 31) / 32 > SK_WAVES) return hipErrorInvalidValue;
+        SkinnyJobs js;
+        js.njobs = dec ? 2 : 1;
+        js.job[0] = att; js.job[1] = dec ? *dec : att; js.job[2] = js.job[1];
+        js.tiles0 = 128; js.tiles1 = dec ? 128 : 0; js.tiles = js.tiles0 + js.tiles1;
+        js.loc = LocJob{};
+        js.pa_layout = 2;
+        decoder_lstm_step_pa192_kernel<<<dim3(dec ? 192 : 64), dim3(SK_THREADS), skinny_lds(2), s>>>(js);
+        return hipGetLastError();
+    }
     SkinnyJobs js;
     js.njobs = dec ? 2 : 1;
     js.job[0] = att; js.job[1] = dec ? *dec : att; js.job[2] = js.job[1];

@@ -218,7 +218,7 @@ class Tacotron2(nn.Module):
         """Scratch for the C-ABI calls.  The status words at its front (gvx_workspace_status) are only ever written by the
         kernels that raise them, so they start out cleared; the rest needs no initialisation."""
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        ws[:32768].zero_()
+        ws[:65536].zero_()
         return ws
 
     def check_status(self) -> None:

@@ -260,7 +260,9 @@ def test_persistent_attention_equals_per_step_attention():
         assert max_abs_diff(outs["persistent"][k], want[k]) <= TOL, k
 
 
-@pytest.mark.parametrize("B,L,T", [(1, 1, 1), (1, 128, 3), (32, 5, 2), (17, 127, 9), (2, 64, 1), (31, 128, 17), (32, 128, 1)])
+@pytest.mark.parametrize("B,L,T", [(1, 1, 1), (1, 128, 3), (32, 5, 2), (17, 127, 9), (2, 64, 1), (31, 128, 17), (32, 128, 1),
+                                   # 128 < L <= 256: two resident workgroups per row (positions split at 128), 192-workgroup launches
+                                   (3, 129, 6), (1, 256, 4), (32, 190, 12), (32, 256, 3), (5, 143, 9), (2, 144, 1)])
 def test_persistent_attention_edge_shapes(B, L, T):
     """Edge shapes of the persistent-attention loop (single row / token / step, maximum rows and tokens, ragged lengths):
     same numbers as the launch-per-step loop (which test_shapes_against_oracle pins to the oracle), repeatable bit for bit,
@@ -452,3 +454,36 @@ def test_autoregressive_resident_attention_equals_per_step(monkeypatch):
     for k in ("mel_outputs", "gate_outputs", "alignments"):
         got = res[k][:1, ..., :nf] if k != "alignments" else res[k][:1, :nf]
         assert max_abs_diff(got, want[k]) <= TOL, k
+
+
+def test_persistent_attention_long_rows_match_oracle():
+    """LJSpeech transcripts reach ~190 characters: rows of 128 < L <= 256 positions run beside the SPLIT resident kernel (two
+    workgroups per row that exchange softmax partials every step, attn_persist.hip) and the 192-workgroup launch layout
+    (attention-LSTM tiles in pairs, skinny.hip).  Ragged lengths on both sides of the cut at position 128 - rows that end
+    before it (half 1 fully masked), just after it (the location convolution's halo crosses the cut) and at L - against
+    the oracle over 40 steps, all four outputs, with the peaky attention weights (sharp alignments exercise the masked
+    softmax and the location features); repeatable bit for bit; no time-out."""
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
+    sd = gw.generate_state_dict(mc, ac, tc, seed=0, peaky_attention=True)
+    m = Tacotron2(mc, ac, tc)
+    m.load_state_dict(sd)
+    m = m.to("cuda:0")
+    B, L, T, P = 6, 190, 40, mc.prenet_dim
+    tl = np.array([190, 171, 140, 129, 128, 57])
+    ml = np.array([40, 33, 40, 12, 40, 25])
+    inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=21, token_lengths=tl, mel_lengths=ml)
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    masks = torch.from_numpy(gw.prenet_keep_masks((T + 1) * B, P, seed=22)).reshape(2, T + 1, B, P)
+    batch["prenet_keep_masks"] = masks
+    got = {k: v.clone() for k, v in m.forward(batch).items()}
+    m.check_status()
+    again = m.forward(batch)
+    want = tacotron2_ref.tacotron2_forward(sd, batch, masks.reshape(2, -1, P), mask_padding=True)
+    for k in KEYS:
+        assert torch.equal(got[k], again[k]), k
+        d = max_abs_diff(got[k], want[k])
+        assert d <= TOL, f"{k}: {d}"
+    a = got["alignments"]
+    assert float((a.sum(dim=2) - 1).abs().max()) <= 1e-5
+    for b in range(B):
+        assert torch.all(a[b, :, int(tl[b]):] == 0)

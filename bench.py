@@ -51,7 +51,7 @@ def algorithmic_bytes_lstm_launch(mc, B, L, persistent=False):
     P, E, A, D, a = mc.prenet_dim, mc.encoder_embedding_dim, mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.attention_dim
     weights = 4 * A * (P + E + A) + 4 * D * (A + E + D) + 4 * A + 4 * D
     per_row = (P + E + A) + (A + E + D) + 2 * (A + D) + (A + D)
-    slabs = ((96 if L <= 128 else 64) if persistent else A // 8) * a   # launch layouts of skinny.hip: 224 / 192 workgroups
+    slabs = ((128 if B > 32 else (96 if L <= 128 else 64)) if persistent else A // 8) * a   # launch layouts of skinny.hip
     loc = 0 if persistent else 2 * L + L * a
     if persistent:   # the Prenet columns of the attention LSTM are applied by one GEMM before the loop: the launch reads their
         weights -= 4 * A * P          # product (4A floats per row) instead of the 4A x P weights and the P inputs per row
@@ -247,7 +247,9 @@ def main():
         alg = algorithmic_bytes_lstm_launch(mc, b, L, persistent)
         sec = kt["decoder_lstm_step"] * 1e-3
         gbs, tfl = alg / sec / 1e9, flops_lstm_launch(mc, b) / sec / 1e12
-        return {"bound": "hbm", "kernel": "decoder_lstm_step_pa_kernel" if persistent else f"decoder_lstm_step_kernel<{2 if b > 32 else 1}>",
+        kname = ("decoder_lstm_step_pa64_kernel" if b > 32 else ("decoder_lstm_step_pa_kernel" if L <= 128 else "decoder_lstm_step_pa192_kernel")) \
+            if persistent else f"decoder_lstm_step_kernel<{2 if b > 32 else 1}>"
+        return {"bound": "hbm", "kernel": kname,
                 "achieved": round(gbs, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(kt["decoder_lstm_step"] * 1e3, 2),
@@ -365,15 +367,20 @@ def main():
             model.enable_stage_timing(True)
             dt = timed(torch, lambda: model.forward(b64), 2, args.steps)
             model.check_status()
-            st64, _ = model.stage_times_ms(lane=0)
+            lanes = getattr(model, "last_forward_lanes", False)
+            st64, _ = model.stage_times_ms(lane=0 if lanes else None)
             model.enable_stage_timing(False)
-            # 64 rows run as two 32-row chunks on two HIP streams at once (genvox_amd/tacotron2.py STREAM_ROWS): the kernel that
-            # runs is the 32-row launch, measured above; what changes is how many launches the chip overlaps
-            extra["tf_b64x800"] = {"mel_frames_per_s": round(64 * T / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": args.steps,
-                                   "execution": "2 chunks x 32 rows, concurrently on 2 HIP streams, one C-ABI call each",
-                                   "lane_stage_ms": {k: round(v, 3) for k, v in st64.items()},
-                                   "decoder_step_us_per_64_rows": round(st64["decoder_loop"] * 1e3 / T, 2),
-                                   "weights_GBs_both_lanes": round(2 * algorithmic_bytes_lstm_launch(mc, 32, L) * T / (st64["decoder_loop"] * 1e-3) / 1e9, 1)}
+            if lanes:
+                execution = "2 chunks x 32 rows, concurrently on 2 HIP streams, one C-ABI call each (launch per attention step)"
+            else:
+                execution = ("ONE call: 64-row loop beside the resident attention kernel (64 CUs), 384-workgroup launches with two batch "
+                             "tiles each - one pass over the recurrent weights per step for all 64 rows")
+            e64 = {"mel_frames_per_s": round(64 * T / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": args.steps, "execution": execution,
+                   "stage_ms": {k: round(v, 3) for k, v in st64.items()},
+                   "decoder_step_us_per_64_rows": round(st64["decoder_loop"] * 1e3 / T, 2)}
+            if not lanes:
+                e64["roofline"] = lstm_roofline(model, 64, b64, st64["decoder_loop"])
+            extra["tf_b64x800"] = e64
             del b64
         for key, bb in (("ar_b64_1000", 64), ("ar_b1_1000", 1)):
             if key not in want:

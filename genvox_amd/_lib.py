@@ -61,6 +61,7 @@ SIGNATURES = {
     "gvx_wav_finalize": (_i, [_vp, _i, C.c_long, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _vp, _vp, _vp]),
     "gvx_kernel_timing_enable": (_i, [_vp, _i]),
     "gvx_model_set_persistent_attention": (_i, [_vp, _i]),
+    "gvx_teacher_forced_rows_per_call": (_i, [_vp, _i]),
     "gvx_kernel_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i)]),
 }
 

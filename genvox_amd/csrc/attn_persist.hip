@@ -375,15 +375,23 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     }
 }
 
+// The resident kernel may hold 64 of the 256 CUs at most:
+//   layout 1: B <= 32, L <= 128        one workgroup per row (<= 32 CUs), launches of 224 workgroups (skinny.hip)
+//   layout 2: B <= 32, 128 < L <= 256  two workgroups per row (<= 64 CUs), launches of 192 workgroups
+//   layout 3: 32 < B <= 64, L <= 128   one workgroup per row (<= 64 CUs), launches of 384 workgroups with two batch tiles
+//                                      each, two per CU (gvx_api.hip, decoder_tf_impl)
+int attention_persistent_layout(int B, int L) {
+    if (B < 1 || L < 1) return 0;
+    if (B <= 32) return L <= PA_L ? 1 : (L <= 2 * PA_L ? 2 : 0);
+    return B <= 64 && L <= PA_L ? 3 : 0;
+}
 bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, int att_rnn_dim, int dec_rnn_dim) {
-    // default layer sizes only: the launch layouts (skinny.hip) deal 128 + 128 tiles to 224 / 192 workgroups.
-    // L <= 128: one workgroup per row (32 CUs at most); 128 < L <= 256: two per row (64 CUs at most)
-    return B >= 1 && B <= 32 && L >= 1 && L <= 2 * PA_L && a == PA_A && E == PA_E && F >= 1 && F <= 32 && kl >= 1 && kl <= PA_KL_MAX &&
+    // default layer sizes only: the launch layouts deal 128 + 128 tiles of the two cells
+    return attention_persistent_layout(B, L) != 0 && a == PA_A && E == PA_E && F >= 1 && F <= 32 && kl >= 1 && kl <= PA_KL_MAX &&
            (kl & 1) && att_rnn_dim == 1024 && dec_rnn_dim == 1024;
 }
-int attention_persistent_layout(int L) { return L <= PA_L ? 1 : 2; }
-int attention_persistent_slabs(int layout) { return layout == 2 ? 64 : PA_SLABS; }
-int attention_persistent_workgroups(int B, int L) { return L <= PA_L ? B : 2 * B; }
+int attention_persistent_slabs(int layout) { return layout == 2 ? 64 : (layout == 3 ? PA_SLABS_AR : PA_SLABS); }
+int attention_persistent_workgroups(int B, int L) { return attention_persistent_layout(B, L) == 2 ? 2 * B : B; }
 size_t attention_persistent_xchg_floats(int B) { return (size_t)B * 2 * 2 * PA_XCH; }
 
 template <typename K>

@@ -136,6 +136,10 @@ struct gvx_model {
     // (round 3, 200-step decodes) 49 vs 47 us per step at batch 1 and no gain at 2 x 32 rows - launch C then has 256 equal
     // tiles for 256 - B free CUs, so one CU streams two of them
     bool ar_resident = false;
+    // GVX_TF_ROWS64=1: batches of 33 .. 64 rows run as ONE call beside a 64-CU resident kernel (layout 3).  Off by default:
+    // with two batch tiles per workgroup the fp32 matrix pipe sets the launch length (37 us per 64-row step, MFMA pipe 54 %
+    // busy on the 192 CUs, round 3) and two 32-row lanes on two streams are faster (40.1 vs 44.4 us per 64-row step)
+    bool tf_rows64 = false;
     int pa_depth = 4;                  // GVX_PA_DEPTH=6: prefetch depth of the launch beside the resident kernel (tests, A/B runs)
     unsigned spin_limit = 0;           // GVX_HANDOFF_SPIN_LIMIT: polls before an in-launch wait gives up (0 = the built-in limit)
     bool debug_skip_resident = false;  // GVX_DEBUG_SKIP_RESIDENT=1: never launch the resident attention kernel, so that every
@@ -251,7 +255,8 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T, int mode = WS_TEACH
     w.p_slab = take((size_t)(D / 8) * B * m->PSB());   // autoregressive mode: projection partials of the decoder-LSTM tiles
     w.p_ctx = take((size_t)B * m->PSB());            //   and of the context columns (blocked vector)
     w.att_part = take((size_t)B * 4 * A);            // autoregressive mode: partial gate pre-activations [B][4A] / [B][4D] of the
-    w.dec_part = take((size_t)B * 4 * D);            //   column slices that are known one launch early
+    w.dec_part = take((size_t)2 * B * 4 * D);        //   column slices that are known one launch early (two buffers: the 64-row
+                                                     //   teacher-forced loop finishes a decoder cell one launch after its partial)
     // teacher-forced loop beside the persistent attention kernel: Prenet contribution to the attention LSTM's gates, all steps
     // (only where that loop can run: 0.5 GB at B = 32, T = 1000 that the autoregressive / launch-per-step paths never touch)
     w.pre_gate = take(mode == WS_TEACHER_FORCED && persistent_path(m, B, L) ? (size_t)T * B * 4 * A : 0);
@@ -426,6 +431,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
         if (const char* e = std::getenv(name))
             if (e[0] != '\0' && e[0] != '0') m->attn_persistent = false;
     if (const char* e = std::getenv("GVX_AR_RESIDENT")) m->ar_resident = e[0] == '1';
+    if (const char* e = std::getenv("GVX_TF_ROWS64")) m->tf_rows64 = e[0] == '1';
     if (const char* e = std::getenv("GVX_PA_DEPTH")) m->pa_depth = std::atoi(e) == 6 ? 6 : 4;
     if (const char* e = std::getenv("GVX_HANDOFF_SPIN_LIMIT")) m->spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("GVX_DEBUG_SKIP_RESIDENT")) m->debug_skip_resident = e[0] == '1';
@@ -802,6 +808,7 @@ hipError_t launch_attn(const gvx_model* m, const AttnParams& p, hipStream_t s) {
 // whether the teacher-forced loop of this shape runs beside the persistent attention kernel
 bool persistent_path(const gvx_model* m, int B, int L) {
     const gvx_dims& d = m->d;
+    if (B > 32 && !m->tf_rows64) return false;
     return m->attn_persistent && m->attn_one_launch &&
            attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
 }
@@ -909,7 +916,8 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     // Persistent attention (attn_persist.hip): the loop is then T + 1 LSTM launches on `st` and ONE attention kernel on a
     // forked stream; the LSTM tiles stream the k-groups of the context last and wait for it in the launch.
     const bool pa = persistent_path(m, B, L);
-    const int pa_layout = attention_persistent_layout(L);   // 1: L <= 128 (32 CUs, 224 workgroups); 2: L <= 256 (64 CUs, 192 workgroups)
+    const int pa_layout = attention_persistent_layout(B, L);   // 1: L <= 128 (32 CUs, 224 workgroups); 2: L <= 256 (64 CUs, 192
+                                                               // workgroups); 3: 33 .. 64 rows (64 CUs, 384 workgroups, two per CU)
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
     if (pa && !prenet_done) {   // (the fused forward has taken a side stream for this call already: the encoder ran on it)
         rc = ensure_side_stream(m);
@@ -980,11 +988,68 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         ++launches;
         return GVX_OK;
     };
+    // Layout 3 (33 .. 64 rows): every launch has two batch tiles per workgroup, so the matrix pipe, not the weight stream,
+    // sets its length - and a decoder-LSTM tile (320 k-groups) would take 1.7x an attention-LSTM tile (192).  The decoder cell
+    // is therefore cut in two along K and finished one launch later:
+    //   launch t:  att-LSTM(t)            [ctx(t-1) deferred ; h_a(t-1)]            128 tiles x 192 k-groups
+    //              dec-LSTM(t-1) partial  [h_a(t-1) ; ctx(t-1) deferred] -> sums    128 tiles x 192 k-groups   (mode 2)
+    //              dec-LSTM(t-2) final    [h_d(t-3)] + those sums of launch t-1     128 tiles x 128 k-groups
+    // 384 workgroups on the 192 CUs the resident kernel leaves, two per CU; two drain launches end the loop.
+    float* dec_part2[2] = {db.dec_part, db.dec_part + (size_t)B * 4 * D};
+    auto jobs64 = [&](int t, SkinnyJob* jobs) -> int {
+        const int A = d.att_rnn_dim;
+        int n = 0;
+        if (t < T) {
+            fill_att_job(m, jobs[n], db.prenet + (size_t)t * B * P, t, B, db);
+            defer(jobs[n], t - 1, t == 0);
+            ++n;
+        }
+        if (t >= 1 && t - 1 < T) {
+            SkinnyJob& J = jobs[n];
+            fill_dec_job(m, J, t - 1, B, db);
+            J.x[2] = XSeg{nullptr, 0};
+            J.nkg = (A + E) / 8; J.kg0 = 0; J.nkg_w = (A + E + D) / 8;
+            J.mode = 2; J.bias = nullptr; J.c = nullptr; J.h_out = nullptr;
+            J.y = dec_part2[t & 1];
+            defer(J, t - 1, false);
+            ++n;
+        }
+        if (t >= 2 && t - 2 < T) {
+            SkinnyJob& J = jobs[n];
+            std::memset(&J, 0, sizeof J);
+            const float* hc_t = db.hc + (size_t)(t - 2) * B * (D + E);
+            float* hc_n = db.hc + (size_t)(t - 1) * B * (D + E);
+            J.Wp = m->dev_blob + m->blob.dec_frag; J.bias = m->dev_blob + m->blob.dec_bias;
+            J.x[0] = XSeg{hc_t, D};
+            J.N = 4 * D; J.nkg = D / 8; J.kg0 = (A + E) / 8; J.nkg_w = (A + E + D) / 8; J.mode = 0; J.B = B;
+            J.c = db.c_d; J.h_out = hc_n;
+            J.addend = dec_part2[(t - 1) & 1]; J.add_bs = 4 * D;
+            J.start_cnt = sync + HANDOFF_CNT_Q;   // (only counts when this job owns block 0: never, a partial job precedes it)
+            ++n;
+        }
+        return n;
+    };
+    auto enqueue_loop64 = [&](hipStream_t st) -> int {
+        for (int t = 0; t < T + 2; ++t) {
+            SkinnyJob jobs[3];
+            const int n = jobs64(t, jobs);
+            HIP_TRY(launch_skinny_pa64(jobs, n, st));
+            ++launches;
+        }
+        return GVX_OK;
+    };
     if (pa) {
         rc = pa_begin(s);   // (the hand-off words were zeroed at the top of this call)
         if (rc != GVX_OK) return rc;
     }
-    if (m->use_graph && !kt) {
+    if (pa && pa_layout == 3) {
+        if (m->use_graph && !kt) {
+            const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr, 0.f, 48};
+            rc = run_chunk(m, touch_graph_set(m, m->loop_graphs, key), 0, s, enqueue_loop64);
+            launches = T + 2;
+        } else rc = enqueue_loop64(s);
+        if (rc != GVX_OK) return rc;
+    } else if (m->use_graph && !kt) {
         const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr, 0.f, pa ? m->pa_depth + 16 * pa_layout : 0};
         rc = run_chunk(m, touch_graph_set(m, m->loop_graphs, key), 0, s, enqueue_loop);
         if (rc != GVX_OK) return rc;
@@ -1006,7 +1071,18 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         SkinnyJob jobs[2];
         fill_att_job(m, jobs[0], db.prenet + (size_t)tm * B * P, tm, B, db);
         if (tm > 0) fill_dec_job(m, jobs[1], tm - 1, B, db);
-        if (pa) {
+        if (pa && pa_layout == 3) {
+            HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));
+            SkinnyJob j3[3];
+            const int n = jobs64(tm > 2 ? tm : 2, j3);
+            for (int i = 0; i < n; ++i) j3[i].start_cnt = nullptr;
+            HIP_TRY(hipEventRecord(m->kev[0], s));
+            for (int i = 0; i < REPS; ++i) HIP_TRY(launch_skinny_pa64(j3, n, s));
+            HIP_TRY(hipEventRecord(m->kev[1], s));
+            HIP_TRY(hipEventRecord(m->kev[2], s));
+            m->n_lstm_ev = REPS;
+            m->n_attn_ev = 0;
+        } else if (pa) {
             // the launch of the loop as it ran: deferred context columns read with sc1 loads; the context counter already
             // stands at its final value, so no replay waits (the attention runs in its own kernel: nothing to time per step)
             HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));
@@ -1112,6 +1188,11 @@ PostnetPlan make_postnet_plan(const gvx_model* m, int B, int T) {
 
 // =====================================================================================================
 extern "C" {
+
+int gvx_teacher_forced_rows_per_call(const gvx_model* m, int L) {
+    if (!m) return 0;
+    return persistent_path(m, 64, L) ? 64 : 32;
+}
 
 int gvx_model_set_persistent_attention(gvx_model* m, int enable) {
     if (!m) return fail(GVX_ERR_INVALID_ARG, "null argument");
@@ -1330,7 +1411,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     // the whole decode, the context of a step arrives inside launch C (deferred segment) and the attention launch leaves the
     // step's chain.  The projection's context columns then ride on the decoder-LSTM tiles' projection slabs (`fold`), so that
     // launch C is exactly 256 tiles.
-    const bool pa = m->ar_resident && m->attn_one_launch && attention_persistent_layout(L) == 1 &&
+    const bool pa = m->ar_resident && m->attn_one_launch && attention_persistent_layout(B, L) == 1 &&
                     attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
     const bool fold = B <= 32 && E / 4 == D / 8;
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);

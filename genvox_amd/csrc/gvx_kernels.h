@@ -123,6 +123,8 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
 // 96 (224) workgroups of equal weight (skinny.hip); default layer sizes, B <= 32
 // layout 1: 224 (96) workgroups beside a 32-CU resident kernel; layout 2: 192 (64) workgroups beside a 64-CU one (skinny.hip)
 hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStream_t s, int depth = 4, int layout = 1);
+// layout 3 (33 .. 64 rows): up to three jobs of 128 tiles each, two batch tiles per workgroup, deferred context segments
+hipError_t launch_skinny_pa64(const SkinnyJob* jobs, int njobs, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Location-sensitive attention, one decoder step, split over G workgroups per batch row:
@@ -176,7 +178,7 @@ struct AttnPersistParams {
                                             // launch 0 signals too; autoregressive loop: 1 - one signalling launch per step)
 };
 bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, int att_rnn_dim, int dec_rnn_dim);
-int attention_persistent_layout(int L);             // 1: one workgroup per row, launch layout 1; 2: two per row, launch layout 2
+int attention_persistent_layout(int B, int L);      // 0: not served; 1 / 2 / 3: see attn_persist.hip
 int attention_persistent_slabs(int layout);         // query slabs of the launch layout
 int attention_persistent_workgroups(int B, int L);  // resident workgroups (= CUs held)
 size_t attention_persistent_xchg_floats(int B);

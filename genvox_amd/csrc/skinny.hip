@@ -24,6 +24,8 @@
 //     per batch row.
 #include "gvx_kernels.h"
 
+#include <cstdlib>
+
 namespace gvx {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -51,6 +53,8 @@ struct SkinnyJobs {
     int tiles;    // tiles of all jobs; blocks >= tiles are location-feature workgroups
     LocJob loc;
     int pa_layout;   // teacher-forced step beside the persistent attention kernel: 224 (96) workgroups, see skinny_body
+    int rot;         // > 0: every workgroup walks its waves' k-group slices from a start rotated by (tile * rot) - thousands of
+                     // waves otherwise read the same 1-KiB x fragments (L2 lines) at the same time
 };
 
 constexpr int LOC_LC = 32;   // positions per pass
@@ -394,7 +398,11 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(w2_.w, xv[0][slot].w, acc2, 0, 0, 0);             \
         } }
 #define SK_X_PLAIN(mt, g) (*reinterpret_cast<const float4*>(((g) < g0 ? xb0[mt] : ((g) < g1 ? xb1[mt] : xb2[mt])) + (long)(g) * blk))
-#define SK_MAP_ID(s) (s)
+    // rotated walk over a slice [b_, e_): stream index s -> b_ + (s - b_ + r_) mod (e_ - b_)   (scalar arithmetic)
+    const int rot_t = jobs.rot > 0 ? tile * jobs.rot : 0;
+#define SK_ROT(s, b_, e_, r_) ((s) + (r_) < (e_) ? (s) + (r_) : (s) + (r_) - ((e_) - (b_)))
+    const int rot_id = kg_end > kg_begin ? rot_t % (kg_end - kg_begin) : 0;
+#define SK_MAP_ID(s) SK_ROT(s, kg_begin, kg_end, rot_id)
     if (!DEFER || !J.defer_seg) {   // (DEFER is a template parameter so that the ordinary kernels do not carry the code below)
         SK_STREAM(kg_begin, kg_end, SK_MAP_ID, SK_X_PLAIN)
     } else {
@@ -405,8 +413,10 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         const int per_n = (nn + SK_WAVES - 1) / SK_WAVES, per_c = (nc + SK_WAVES - 1) / SK_WAVES;
         const int n_begin = min(nn, wave * per_n), n_end = min(nn, n_begin + per_n);
         const int c_begin = min(nc, wave * per_c), c_end = min(nc, c_begin + per_c);
-#define SK_MAP_N(s) ((s) < g0 ? (s) : (s) + nc)
-#define SK_MAP_C(s) ((s) + g0)
+        const int rot_n = n_end > n_begin ? rot_t % (n_end - n_begin) : 0, rot_c = c_end > c_begin ? rot_t % (c_end - c_begin) : 0;
+#define SK_MAP_N0(s) ((s) < g0 ? (s) : (s) + nc)
+#define SK_MAP_N(s) SK_MAP_N0(SK_ROT(s, n_begin, n_end, rot_n))
+#define SK_MAP_C(s) (SK_ROT(s, c_begin, c_end, rot_c) + g0)
         SK_STREAM(n_begin, n_end, SK_MAP_N, SK_X_PLAIN)
         if (J.ctx_cnt) {
             // ONE wave per workgroup polls the counter (1 800 waves polling one word queue in front of the producer's own
@@ -437,9 +447,11 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             SK_STREAM(c_begin, c_end, SK_MAP_C, SK_X_PLAIN)
         }
 #undef SK_MAP_N
+#undef SK_MAP_N0
 #undef SK_MAP_C
     }
 #undef SK_MAP_ID
+#undef SK_ROT
 #undef SK_X_PLAIN
 #undef SK_MFMA
 #undef SK_LOAD
@@ -690,6 +702,13 @@ __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_step_pa192_kernel(Ski
     else skinny_body<1, SK_DEPTH1, false, true, 1>(jobs);
     GVX_WG_END();
 }
+// teacher-forced step of 33 .. 64 rows beside the 64-CU resident attention kernel: two batch tiles per workgroup, two workgroups
+// per CU (4 waves per SIMD: at most 128 VGPRs)
+__global__ __launch_bounds__(SK_THREADS, 4) void decoder_lstm_step_pa64_kernel(SkinnyJobs jobs) {
+    GVX_WG_BEGIN();
+    skinny_body<2, SK_DEPTH2, false, true>(jobs);
+    GVX_WG_END();
+}
 // the launch that drains the loop (decoder-LSTM of the last step): ordinary layout, context handed over in-launch
 __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_drain_pa_kernel(SkinnyJobs jobs) { skinny_body<1, SK_DEPTH1, false, true>(jobs); }
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_kernel(SkinnyJobs jobs) {   // autoregressive launches A / C
@@ -708,6 +727,11 @@ static hipError_t set_lds(K kern, int MT) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_lds(MT));
 }
 
+static int sk_rot() {   // GVX_SK_ROT=<stride>: rotated k-group walk (A/B knob; 0 = off)
+    static const int r = [] { const char* e = std::getenv("GVX_SK_ROT"); return e ? std::atoi(e) : 0; }();
+    return r;
+}
+
 hipError_t skinny_init() {
     hipError_t e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
@@ -718,6 +742,7 @@ hipError_t skinny_init() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_lstm_step_pa_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)skinny_pa_lds())) != hipSuccess) return e;
     if ((e = set_lds(decoder_lstm_drain_pa_kernel, 1)) != hipSuccess) return e;
     if ((e = set_lds(decoder_lstm_step_pa192_kernel, 2)) != hipSuccess) return e;
+    if ((e = set_lds(decoder_lstm_step_pa64_kernel, 2)) != hipSuccess) return e;
     if ((e = set_lds(ar_lstm_defer_kernel, 1)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
     return set_lds(encoder_lstm_step_kernel<2>, 2);
@@ -734,7 +759,7 @@ hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStrea
         js.job[0] = att; js.job[1] = dec ? *dec : att; js.job[2] = js.job[1];
         js.tiles0 = 128; js.tiles1 = dec ? 128 : 0; js.tiles = js.tiles0 + js.tiles1;
         js.loc = LocJob{};
-        js.pa_layout = 2;
+        js.pa_layout = 2; js.rot = sk_rot();
         decoder_lstm_step_pa192_kernel<<<dim3(dec ? 192 : 64), dim3(SK_THREADS), skinny_lds(2), s>>>(js);
         return hipGetLastError();
     }
@@ -743,9 +768,24 @@ hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStrea
     js.job[0] = att; js.job[1] = dec ? *dec : att; js.job[2] = js.job[1];
     js.tiles0 = 128; js.tiles1 = dec ? 128 : 0; js.tiles = js.tiles0 + js.tiles1;
     js.loc = LocJob{};
-    js.pa_layout = 1;
+    js.pa_layout = 1; js.rot = sk_rot();
     if (depth == 6) decoder_lstm_step_pa_kernel<6><<<dim3(dec ? 224 : 96), dim3(SK_THREADS), skinny_pa_lds(), s>>>(js);
     else decoder_lstm_step_pa_kernel<SK_DEPTH1><<<dim3(dec ? 224 : 96), dim3(SK_THREADS), skinny_pa_lds(), s>>>(js);
+    return hipGetLastError();
+}
+
+hipError_t launch_skinny_pa64(const SkinnyJob* jobs, int njobs, hipStream_t s) {
+    if (njobs < 1 || njobs > 3) return hipErrorInvalidValue;
+    SkinnyJobs js;
+    js.njobs = njobs;
+    js.pa_layout = 0;   // ordinary block -> (job, tile) mapping; one slab per attention-LSTM tile
+    js.rot = sk_rot();
+    js.loc = LocJob{};
+    for (int i = 0; i < 3; ++i) js.job[i] = jobs[i < njobs ? i : njobs - 1];
+    for (int i = 0; i < njobs; ++i)
+        if (jobs[i].N != 4096 || jobs[i].B != jobs[0].B || jobs[i].B <= 32 || jobs[i].B > 64) return hipErrorInvalidValue;
+    js.tiles0 = 128; js.tiles1 = njobs > 1 ? 128 : 0; js.tiles = 128 * njobs;
+    decoder_lstm_step_pa64_kernel<<<dim3(js.tiles), dim3(SK_THREADS), skinny_lds(2), s>>>(js);
     return hipGetLastError();
 }
 
@@ -753,7 +793,7 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
     if (njobs < 1 || njobs > 3) return hipErrorInvalidValue;
     SkinnyJobs js;
     js.njobs = njobs;
-    js.pa_layout = 0;
+    js.pa_layout = 0; js.rot = sk_rot();
     for (int i = 0; i < 3; ++i) js.job[i] = jobs[i < njobs ? i : njobs - 1];
     js.tiles0 = (jobs[0].N + 31) / 32;
     js.tiles1 = njobs > 1 ? (jobs[1].N + 31) / 32 : 0;

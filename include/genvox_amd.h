@@ -114,6 +114,12 @@ int gvx_workspace_status(const gvx_model* model, void* workspace, size_t workspa
  * resident kernel owns the handle's side stream for the whole loop.  Results are identical either way. */
 int gvx_model_set_persistent_attention(gvx_model* model, int enable);
 
+/* Batch rows gvx_tacotron2_forward / gvx_decoder_teacher_forced serve best per call for rows of L tokens: 64 where the 64-row
+ * loop beside the resident attention kernel applies (default layer sizes, L <= 128, resident attention enabled: one pass over
+ * the recurrent weights per step for all 64 rows), else 32 (callers with more rows run 32-row chunks on two streams with a
+ * handle each, as the host mirror does).  Any B in [1, 64] is accepted by every call regardless. */
+int gvx_teacher_forced_rows_per_call(const gvx_model* model, int L);
+
 /* ---- Encoder: embedding + conv/BN/relu stack + BiLSTM with packed-sequence semantics.
  * Replaces nn.Embedding + Encoder.forward / Encoder.inference (models/tts/tacotron2.py:459,
  * :231-246, :248-256).  tokens: int64 [B, L]; lengths: int32 [B] or NULL (= all L);

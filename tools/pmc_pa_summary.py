@@ -3,7 +3,7 @@
 only the LAST 64 dispatches of the kernel count (the back-to-back replays; the loop's own launches ran serialised against
 the resident attention kernel and spent their time in hand-off time-outs).  Units as in tools/pmc_sq_summary.py; FETCH_SIZE
 is doubled (gfx950 half-count, MI355X_MICROARCH.md section HBM).
-    python tools/pmc_pa_summary.py r03 [B]"""
+    python tools/pmc_pa_summary.py r03 [B [kernel [subdir of gpurun_out]]]"""
 import collections
 import csv
 import glob
@@ -12,11 +12,12 @@ import sys
 
 tag = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-KERNEL = "decoder_lstm_step_pa_kernel"
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "decoder_lstm_step_pa_kernel"
+SUB = sys.argv[4] if len(sys.argv) > 4 else "pmc_pa"
 REPLAYS = 64
 vals = collections.defaultdict(list)
 durs = []
-for f in sorted(glob.glob("gpurun_out/pmc_pa/**/*counter_collection.csv", recursive=True)):
+for f in sorted(glob.glob(f"gpurun_out/{SUB}/**/*counter_collection.csv", recursive=True)):
     per = collections.defaultdict(list)   # counter -> [(dispatch id, value)]
     for r in csv.DictReader(open(f)):
         if KERNEL in r["Kernel_Name"]:
@@ -24,7 +25,7 @@ for f in sorted(glob.glob("gpurun_out/pmc_pa/**/*counter_collection.csv", recurs
     for c, lst in per.items():
         lst.sort()
         vals[c] += [v for _, v in lst[-REPLAYS:]]
-for f in sorted(glob.glob("gpurun_out/pmc_pa/**/*kernel_trace.csv", recursive=True)):
+for f in sorted(glob.glob(f"gpurun_out/{SUB}/**/*kernel_trace.csv", recursive=True)):
     rows = [(int(r["Dispatch_Id"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
     rows.sort()
     durs += [d for _, d in rows[-REPLAYS:]]
@@ -53,5 +54,5 @@ if "fetch_bytes_corrected" in row and "write_bytes" in row:
     row["hbm_bytes_per_launch"] = row["fetch_bytes_corrected"] + row["write_bytes"]
 json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --output-format csv --pmc <set> -d gpurun_out/pmc_pa/<set> -- python3 tools/pa_pmc.py",
            "note": "last 64 dispatches (back-to-back replays of a mid-sequence launch) only", "kernel": row},
-          open(f"profiles/{tag}_pmc_sq_pa.json", "w"), indent=1)
+          open(f"profiles/{tag}_pmc_sq_{'pa' if SUB == 'pmc_pa' else SUB}.json", "w"), indent=1)
 print(json.dumps(row, indent=1))

@@ -73,7 +73,13 @@ if lib2.gvx_debug_read_wg_spans(spans) == 0:
                 worst = max(ids, key=lambda i: end[i])
                 print(f"{name:16s} {len(ids):4d} workgroups: begin {min(b):6d}..{max(b):6d} ns, end {min(e):6d}..{max(e):6d} ns (last: block {worst})")
         print("last multi-job LSTM launch, per workgroup (ns after the first workgroup began):")
-        if os.environ.get("GVX_ATTN_PERSISTENT", "1") != "0" and B <= 32:
+        if os.environ.get("GVX_ATTN_PERSISTENT", "1") != "0" and B > 32:
+            grp("attention (2 bt)", range(0, 128))
+            grp("decoder partial", range(128, 256))
+            grp("decoder final", range(256, 384))
+            for lo in range(0, 384, 32):   # in dispatch order: which blocks start late / end late
+                grp(f"blocks {lo}..{lo + 31}", range(lo, lo + 32))
+        elif os.environ.get("GVX_ATTN_PERSISTENT", "1") != "0" and B <= 32:
             grp("attention 48 rows", range(0, 64))
             grp("attention 32 rows", range(64, 96))
             grp("decoder tiles", range(96, 224))

@@ -23,9 +23,13 @@ Rank 0 prints ONE JSON line.
                 boundaries) taken from HIP events recorded around the decoder loop INSIDE the timed region.  `traffic` is
                 null here: HBM bytes come from separate rocprofv3 --pmc passes (profiles/README.md), never from a file.
   cpu_baseline  the oracle (CPU restatement of the reference) on the host cores, bounded sample of the same workload.
-  extra         (N = 1 only) the other BASELINE configurations, each timed like the headline (warm-up, then K runs
-                bracketed by synchronize) with its own roofline fraction and CPU-oracle figure:
-                tf_b64x800, ar_b64_1000, ar_b1_1000, postnet_b256x800, gl_60it_b256x800.
+  validated     the run checks what it times: device status words after the timed region and after every leg (a hand-off
+                time-out or a bad token id fails the run), and the last timed forward must equal an un-timed run with the
+                same Prenet-mask seed bit for bit.
+  extra         (N = 1) the other BASELINE configurations, each timed like the headline (warm-up, then K runs bracketed by
+                synchronize) with its own roofline fraction and CPU-oracle figure: c1_b1x568 (configs[0]), tf_b64x800,
+                ar_b64_1000, ar_b1_1000, postnet_b256x800, gl_60it_b256x800.
+                (N > 1) ar_b64_1000_per_rank: every rank decodes 64 rows autoregressively at the same time.
 """
 import argparse
 import contextlib

@@ -13,7 +13,7 @@ from genvox_amd.configs import AudioConfig, Tacotron2Config, TextConfig
 from genvox_amd.tacotron2 import Tacotron2
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-T, L = 60, 128
+T, L = 60, int(sys.argv[2]) if len(sys.argv) > 2 else 128
 mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
 m = Tacotron2(mc, ac, tc)
 m.load_state_dict(gw.generate_state_dict(mc, ac, tc, 0))
@@ -79,6 +79,9 @@ if lib2.gvx_debug_read_wg_spans(spans) == 0:
             grp("decoder final", range(256, 384))
             for lo in range(0, 384, 32):   # in dispatch order: which blocks start late / end late
                 grp(f"blocks {lo}..{lo + 31}", range(lo, lo + 32))
+        elif os.environ.get("GVX_ATTN_PERSISTENT", "1") != "0" and B <= 32 and L > 128:
+            grp("attention pairs", range(0, 64))
+            grp("decoder tiles", range(64, 192))
         elif os.environ.get("GVX_ATTN_PERSISTENT", "1") != "0" and B <= 32:
             grp("attention 48 rows", range(0, 64))
             grp("attention 32 rows", range(64, 96))

@@ -47,6 +47,11 @@ SIGNATURES = {
     "gvx_mask_padding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gvx_tacotron2_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_tacotron2_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "gvx_conv_train_saved_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "gvx_conv_train_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "gvx_conv_bn_act_train_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "gvx_conv_bn_act_train_backward": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_tacotron2_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gvx_prenet_masks_generate": (_i, [_vp, _sz, C.c_uint64, _vp]),
     "gvx_stage_timing_enable": (_i, [_vp, _i]),
     "gvx_stage_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),

@@ -526,8 +526,10 @@ class Tacotron2(nn.Module):
         return Tacotron2(**configs)
 
     def train_step(self, *args, **kwargs):
-        raise NotImplementedError("genvox_amd.Tacotron2 is an inference-only forward path (no backward kernels); "
-                                  "train with the reference and load the checkpoint here.")
+        raise NotImplementedError("genvox_amd.Tacotron2.train_step: the backward through the LSTMs and the attention (BPTT) and the "
+                                  "optimiser step are not built; what exists of the training step - the training-mode convolution "
+                                  "stacks, the criterion backward and the Postnet / encoder-convolution gradients - is in "
+                                  "genvox_amd.training.  Train with the reference and load the checkpoint here.")
 
     def get_criterion(self) -> Dict:
         """Reference: tacotron2.py:501-504."""

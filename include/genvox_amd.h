@@ -183,6 +183,36 @@ int gvx_tacotron2_loss(const float* mel_out, const float* mel_post_out, const fl
                        const float* gate_target, int B, int n_mels, int T, float* loss_out, void* scratch, size_t scratch_bytes,
                        void* stream);
 
+/* =====================================================================================================
+ * Training, first slice: the convolution layers of the encoder and Postnet stacks as the
+ * reference runs them under .train() - nn.Conv1d + nn.BatchNorm1d with BATCH statistics + activation + F.dropout
+ * (models/tts/tacotron2.py:149-199, :207-220, :234-235) - forward and backward, and the backward of Tacotron2Loss
+ * (:598-615).  Parameters are taken in the reference's own layout (conv weight [Cout, Cin, k]); activations in its
+ * [B, C, T] layout.  act: 0 none, 1 relu, 2 tanh.  keep: uint8 {0,1} [B, Cout, T] (the dropout's keep mask; NULL = no
+ * dropout); kept values are scaled by 1 / (1 - p).  Channels must be multiples of 8, k odd.
+ * `saved` carries what the backward needs (gvx_conv_train_saved_bytes); both buffers 256-byte aligned.
+ * The LSTM / attention backward (BPTT) and the optimiser step are not built yet: Tacotron2.train_step still raises.
+ * ===================================================================================================== */
+size_t gvx_conv_train_saved_bytes(int B, int Cin, int Cout, int T, int k);
+size_t gvx_conv_train_workspace_bytes(int B, int Cin, int Cout, int T, int k);
+/* y = dropout(act(BatchNorm_train(conv1d(x, w, bias, padding (k-1)/2)))).  running_mean / running_var (may be NULL) get the
+ * momentum-0.1 update of torch.nn.BatchNorm1d (unbiased variance), in place. */
+int gvx_conv_bn_act_train_forward(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, int B, int Cin, int Cout, int T, int k, int act,
+                                  const uint8_t* keep, float p_drop, float* y, void* saved, size_t saved_bytes, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+/* Gradients of one layer given dy = d loss / d y: dx [B, Cin, T] (may be NULL), dw [Cout, Cin, k], dbias, dgamma, dbeta [Cout].
+ * x_wgrad (may be NULL): input to use for the weight gradient instead of the saved one - the reference masks the Postnet's
+ * input in place after its forward, outside autograd, so its first layer's weight gradient sees the masked tensor. */
+int gvx_conv_bn_act_train_backward(const float* dy, const void* saved, size_t saved_bytes, const float* w, const float* gamma,
+                                   const float* x_wgrad, int B, int Cin, int Cout, int T, int k, int act, const uint8_t* keep,
+                                   float p_drop, float* dx, float* dw, float* dbias, float* dgamma, float* dbeta, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+/* d loss / d (mel_out [its own MSE term], mel_post_out, gate_out) of Tacotron2Loss on the (masked) outputs of the forward. */
+int gvx_tacotron2_loss_backward(const float* mel_out, const float* mel_post_out, const float* gate_out, const float* mel_target,
+                                const float* gate_target, int B, int n_mels, int T, float* dmel_out, float* dmel_post_out,
+                                float* dgate_out, void* stream);
+
 /* ---- Prenet keep-mask generator for callers that do not supply masks (the reference draws them from
  * torch's RNG inside F.dropout, models/tts/tacotron2.py:143).  Writes n bytes of Bernoulli(0.5) {0,1}. */
 int gvx_prenet_masks_generate(uint8_t* masks_out, size_t n, uint64_t seed, void* stream);

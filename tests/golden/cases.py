@@ -29,6 +29,11 @@ AR_CASES = {
                           gate_fires=True),
 }
 
+# training mode (BatchNorm batch statistics, encoder / LSTM-output / Postnet dropouts on): forward outputs, loss and the
+# gradients of the reference's loss.backward() (models/tts/tacotron2.py:515-522)
+TRAIN_CASE = dict(dims=SMALL, weight_seed=3, input_seed=9, mask_seed=17, peaky=True, B=4, L=9, T=10,
+                  token_lengths=[9, 7, 4, 2], mel_lengths=[10, 6, 10, 3])
+
 AUDIO_CASE = dict(fs=22050, n_fft=1024, hop=256, n_mels=80, fmin=0.0, fmax=8000.0, log_func="np.log", ref=1.0,
                   frames=40, seed=21)
 

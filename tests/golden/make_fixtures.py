@@ -49,7 +49,7 @@ from core.processors import AudioProcessor as RefAudioProcessor  # noqa: E402  (
 from utils.audio import base as ref_audio  # noqa: E402  (reference)
 
 from genvox_amd import weights as gw  # noqa: E402
-from tests.golden.cases import AR_CASES, AUDIO_CASE, TF_CASES, case_configs  # noqa: E402
+from tests.golden.cases import AR_CASES, AUDIO_CASE, TF_CASES, TRAIN_CASE, case_configs  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -120,6 +120,72 @@ def make_tf_case(name, case):
     )
     a = out["alignments"]
     print(f"{name}: mel_post |max| {out['mel_outputs_postnet'].abs().max():.3f}  max alignment {a.max():.3f}")
+
+
+def make_train_case(case):
+    """Reference in .train() mode: forward, Tacotron2Loss, loss.backward() (what train_step does before clipping,
+    models/tts/tacotron2.py:515-520).  Every dropout the reference draws goes through F.dropout; it is replaced for the
+    duration of the call by an equivalent that draws an explicit Bernoulli keep mask, so that the masks are inputs of the
+    fixture (call order: encoder convolutions, Prenet x 2, then per decoder step attention-LSTM / decoder-LSTM output,
+    Postnet convolutions) and the gradient that reaches each dropout output can be read back."""
+    model, (mc, ac, tc) = build_reference_model(case)
+    model.train()
+    B, L, T = case["B"], case["L"], case["T"]
+    inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=case["input_seed"],
+                              token_lengths=case["token_lengths"], mel_lengths=case["mel_lengths"])
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    drawn = []   # (keep mask uint8, output tensor with retained grad)
+    real_dropout = F.dropout
+
+    def recording_dropout(x, p=0.5, training=True, inplace=False):
+        if not training:
+            return x
+        keep = torch.bernoulli(torch.full_like(x, 1.0 - p))
+        out = x * keep / (1.0 - p)
+        if out.requires_grad:
+            out.retain_grad()
+        drawn.append((keep.to(torch.uint8), out))
+        return out
+
+    taps = {}
+    hook = model.decoder.register_forward_hook(lambda m, i, o: taps.__setitem__("dec_mel", o[0].detach().clone()))
+    torch.manual_seed(case["mask_seed"])
+    F.dropout = recording_dropout
+    try:
+        out = model.forward({k: v.clone() for k, v in batch.items()})
+        hook.remove()
+        dec_mel = out["mel_outputs"]
+        dec_mel.retain_grad()
+        loss = RefTacotron2Loss({k: v.clone() for k, v in batch.items()}, out)
+        loss["loss"].backward()
+    finally:
+        F.dropout = real_dropout
+    ne, npn = mc.encoder_n_convolutions, mc.postnet_n_convolutions
+    assert len(drawn) == ne + 2 + 2 * T + npn, len(drawn)
+    enc, pre, steps, post = drawn[:ne], drawn[ne:ne + 2], drawn[ne + 2:ne + 2 + 2 * T], drawn[ne + 2 + 2 * T:]
+    pack = lambda ms: np.packbits(np.stack([m.numpy().reshape(-1) for m in ms]), axis=1)
+    grads = {("grad." + k): v.grad.numpy() for k, v in model.named_parameters()}
+    bn_stats = {("state." + k): v.detach().numpy() for k, v in model.state_dict().items() if "running_" in k}
+    np.savez_compressed(
+        os.path.join(HERE, "train_small.npz"),
+        **{k: v for k, v in inp.items()},
+        enc_keep_packed=pack([m for m, _ in enc]),               # [n_enc][B, E, L]
+        prenet_keep_packed=pack([m for m, _ in pre]),            # [2][T+1, B, P]
+        att_keep_packed=pack([m for m, _ in steps[0::2]]),       # [T][B, A]
+        dec_keep_packed=pack([m for m, _ in steps[1::2]]),       # [T][B, D]
+        post_keep_packed=pack([m.reshape(-1)[: m.numel()] for m, _ in post[:-1]]) if npn > 1 else np.zeros((0, 0), np.uint8),
+        post_last_keep_packed=pack([post[-1][0]]),               # [B, n_mels, T] (the last layer has n_mels channels)
+        mel_outputs=out["mel_outputs"].detach().numpy(), mel_outputs_postnet=out["mel_outputs_postnet"].detach().numpy(),
+        gate_outputs=out["gate_outputs"].detach().numpy(), alignments=out["alignments"].detach().numpy(),
+        loss=np.float32(loss["loss"].item()), mel_loss=np.float32(loss["mel_loss"].item()), gate_loss=np.float32(loss["gate_loss"].item()),
+        decoder_mel_unmasked=taps["dec_mel"].numpy(),            # the Postnet's input: the decoder's mel output BEFORE the padding mask (:463, :466-473)
+        grad_mel_outputs=dec_mel.grad.numpy(),                   # d loss / d (decoder mel output), all paths
+        grad_gate_outputs=np.zeros(0, np.float32),
+        grad_enc_conv_out=enc[-1][1].grad.numpy(),               # d loss / d (output of the encoder's convolution stack) [B, E, L]
+        grad_post_out=post[-1][1].grad.numpy(),                  # d loss / d (Postnet output before the residual add)
+        **grads, **bn_stats,
+    )
+    print(f"train_small: loss {loss['loss'].item():.5f}  dropouts {len(drawn)}  |grad mel| max {dec_mel.grad.abs().max():.4e}")
 
 
 def make_ar_case(name, case):
@@ -269,6 +335,9 @@ def make_host_fixtures():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        make_train_case(TRAIN_CASE)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "host":
         make_host_fixtures()
         sys.exit(0)

@@ -84,3 +84,49 @@ def test_oracle_loss_matches_reference_criterion(name):
     got = tacotron2_ref.tacotron2_loss(batch, outputs)
     for k in ("loss", "mel_loss", "gate_loss"):
         assert abs(float(got[k]) - float(fx[k])) <= 2e-6 * max(1.0, abs(float(fx[k]))), k
+
+
+def test_training_oracle_matches_reference_gradients():
+    """oracle/train_ref.py (explicit forward / backward formulas of the training-mode convolution stacks and of the
+    criterion) against tests/golden/train_small.npz: the reference's own .train() forward and loss.backward()."""
+    import numpy as np
+
+    from genvox_amd import weights as gw
+    from oracle import train_ref as tr
+    from tests.golden.cases import TRAIN_CASE
+
+    z = load_fixture("train_small")
+    mc, ac, tc = case_configs(TRAIN_CASE)
+    sd = gw.generate_state_dict(mc, ac, tc, seed=TRAIN_CASE["weight_seed"], peaky_attention=True)
+    B, L, T = TRAIN_CASE["B"], TRAIN_CASE["L"], TRAIN_CASE["T"]
+    M, C, n, E, ne = ac.n_mels, mc.postnet_embedding_dim, mc.postnet_n_convolutions, mc.encoder_embedding_dim, mc.encoder_n_convolutions
+
+    def unpack(packed, shape):
+        k = int(np.prod(shape))
+        return torch.from_numpy(np.unpackbits(packed, axis=1)[:, :k].reshape((packed.shape[0],) + tuple(shape)))
+
+    pk, pl = unpack(z["post_keep_packed"], (B, C, T)), unpack(z["post_last_keep_packed"], (B, M, T))
+    keeps = [pk[i] for i in range(n - 1)] + [pl[0]]
+    x = torch.from_numpy(z["decoder_mel_unmasked"])
+    y, saved = tr.convstack_train_forward(sd, "postnet.convolutions", n, tr.postnet_acts(n), x, keeps)
+    post = x + y
+    for b in range(B):
+        post[b, :, int(z["mel_lengths"][b]):] = 0
+    assert max_abs_diff(post, z["mel_outputs_postnet"]) <= 1e-5
+    outs = {k: torch.from_numpy(z[k]) for k in ("mel_outputs", "mel_outputs_postnet", "gate_outputs")}
+    dmel, dpost, dgate = tr.loss_backward({k: torch.from_numpy(z[k]) for k in ("mel_padded", "gate_padded")}, outs)
+    assert max_abs_diff(dpost, z["grad_post_out"]) <= 1e-7
+    saved[0]["x"] = outs["mel_outputs"]   # masked in place by the reference after its forward (models/tts/tacotron2.py:470)
+    dx, grads = tr.convstack_train_backward(sd, "postnet.convolutions", n, tr.postnet_acts(n), dpost, saved, keeps)
+    assert max_abs_diff(dmel + dpost + dx, z["grad_mel_outputs"]) <= 1e-6
+    ek = unpack(z["enc_keep_packed"], (B, E, L))
+    emb = sd["embedding.weight"][torch.from_numpy(z["token_padded"])].transpose(1, 2)
+    _, esaved = tr.convstack_train_forward(sd, "encoder.convolutions", ne, tr.encoder_acts(ne), emb, [ek[i] for i in range(ne)])
+    _, egrads = tr.convstack_train_backward(sd, "encoder.convolutions", ne, tr.encoder_acts(ne), torch.from_numpy(z["grad_enc_conv_out"]), esaved,
+                                            [ek[i] for i in range(ne)])
+    for k, v in {**grads, **egrads}.items():
+        assert max_abs_diff(v, z["grad." + k]) <= 2e-6, k
+    rm, rv = tr.bn_running_update(sd["encoder.convolutions.0.1.running_mean"], sd["encoder.convolutions.0.1.running_var"],
+                                  esaved[0]["mean"], esaved[0]["var"], B * L)
+    assert max_abs_diff(rm, z["state.encoder.convolutions.0.1.running_mean"]) <= 1e-6
+    assert max_abs_diff(rv, z["state.encoder.convolutions.0.1.running_var"]) <= 1e-6

@@ -47,6 +47,8 @@ SIGNATURES = {
     "gvx_mask_padding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gvx_tacotron2_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_tacotron2_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "gvx_encoder_lstm_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "gvx_decoder_teacher_forced_train": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_conv_train_saved_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "gvx_conv_train_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "gvx_conv_bn_act_train_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _sz, _vp, _sz, _vp]),

@@ -628,8 +628,11 @@ int conv_layer(const gvx_model* m, const float* in, float* out, int B, int T, in
     return GVX_OK;
 }
 
+// conv_out (training mode only): the output of the convolution stack, [B, E, L] in the reference's layout, computed by the
+// caller with batch statistics and dropout (gvx_conv_bn_act_train_forward); the embedding and the folded-BatchNorm
+// convolutions are then skipped and only the BiLSTM part runs
 int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, int B, int L, float* memory_out, void* ws,
-                 const WsPlan& wp, hipStream_t s) {
+                 const WsPlan& wp, hipStream_t s, const float* conv_out = nullptr) {
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, H = E / 2, pe = (d.enc_kernel - 1) / 2;
     float* xa = ws_ptr<float>(ws, wp.xa);
@@ -639,17 +642,21 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
     float* enc_c = ws_ptr<float>(ws, wp.enc_c);
     int* flags = ws_ptr<int>(ws, wp.flags);
     const size_t xbytes = (size_t)B * (L + 2 * pe) * E * sizeof(float);
-    HIP_TRY(zero_async(xa, xbytes, s));
-    HIP_TRY(zero_async(xb, xbytes, s));
-    // (the token-error word is sticky: raised here, cleared only by gvx_workspace_status - a later chunk on the same
-    // workspace must not wipe an earlier chunk's error)
-    HIP_TRY(launch_embed(tokens, m->dev_blob + m->blob.emb, d.n_tokens, xa, B, L, E, pe, flags + FLAG_TOKEN, s));
     float* cur = xa;
     float* nxt = xb;
-    for (int i = 0; i < d.enc_n_conv; ++i) {
-        int rc = conv_layer(m, cur, nxt, B, L, E, E, d.enc_kernel, m->blob.enc_w[i], m->blob.enc_b[i], ACT_RELU, pe, s);
-        if (rc != GVX_OK) return rc;
-        float* t = cur; cur = nxt; nxt = t;
+    if (conv_out) {
+        HIP_TRY(launch_to_channels_last(conv_out, xa, B, E, L, pe, nullptr, s));
+    } else {
+        HIP_TRY(zero_async(xa, xbytes, s));
+        HIP_TRY(zero_async(xb, xbytes, s));
+        // (the token-error word is sticky: raised here, cleared only by gvx_workspace_status - a later chunk on the same
+        // workspace must not wipe an earlier chunk's error)
+        HIP_TRY(launch_embed(tokens, m->dev_blob + m->blob.emb, d.n_tokens, xa, B, L, E, pe, flags + FLAG_TOKEN, s));
+        for (int i = 0; i < d.enc_n_conv; ++i) {
+            int rc = conv_layer(m, cur, nxt, B, L, E, E, d.enc_kernel, m->blob.enc_w[i], m->blob.enc_b[i], ACT_RELU, pe, s);
+            if (rc != GVX_OK) return rc;
+            float* t = cur; cur = nxt; nxt = t;
+        }
     }
     {   // LSTM input projection for both directions: xg[b][l][dir*4H + 4j+gate]
         GemmParams g{};
@@ -880,9 +887,13 @@ int decoder_prenet_part(gvx_model* m, int B, int L, const float* mel_in, int T, 
     return GVX_OK;
 }
 
+// Training mode (models/tts/tacotron2.py:341, :358): the outputs of both LSTM cells go through dropout before anything uses
+// them (next step's recurrence, the attention query, the other cell, the projection).  Explicit keep masks, as for the Prenet.
+struct LstmDropout { const uint8_t* att_keep; const uint8_t* dec_keep; float att_scale, dec_scale; };   // [T][B][A], [T][B][D]
+
 int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
                     const uint8_t* keep_masks, float* mel_out, float* gate_out, float* align_out, void* ws, const WsPlan& wp,
-                    hipStream_t s, bool prenet_done = false) {
+                    hipStream_t s, bool prenet_done = false, const LstmDropout* train = nullptr) {
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, D = d.dec_rnn_dim;
     const DecoderBuffers db = decoder_buffers(ws, wp);
@@ -915,7 +926,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     }
     // Persistent attention (attn_persist.hip): the loop is then T + 1 LSTM launches on `st` and ONE attention kernel on a
     // forked stream; the LSTM tiles stream the k-groups of the context last and wait for it in the launch.
-    const bool pa = persistent_path(m, B, L);
+    const bool pa = !train && persistent_path(m, B, L);   // (training mode runs the launch-per-step loop)
     const int pa_layout = attention_persistent_layout(B, L);   // 1: L <= 128 (32 CUs, 224 workgroups); 2: L <= 256 (64 CUs, 192
                                                                // workgroups); 3: 33 .. 64 rows (64 CUs, 384 workgroups, two per CU)
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
@@ -968,6 +979,10 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
                 fill_dec_job(m, jobs[1], t - 1, B, db);
                 defer(jobs[1], t - 1, false);
             }
+            if (train) {
+                jobs[0].h_keep = train->att_keep + (size_t)t * B * d.att_rnn_dim; jobs[0].h_scale = train->att_scale;
+                if (t > 0) { jobs[1].h_keep = train->dec_keep + (size_t)(t - 1) * B * D; jobs[1].h_scale = train->dec_scale; }
+            }
             if (pa) {
                 HIP_TRY(launch_skinny_pa(jobs[0], t > 0 ? &jobs[1] : nullptr, st, m->pa_depth, pa_layout));
                 ++launches;
@@ -984,6 +999,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         SkinnyJob job;
         fill_dec_job(m, job, T - 1, B, db);
         defer(job, T - 1, false);
+        if (train) { job.h_keep = train->dec_keep + (size_t)(T - 1) * B * D; job.h_scale = train->dec_scale; }
         HIP_TRY(launch_skinny(&job, 1, SK_DECODER, st));
         ++launches;
         return GVX_OK;
@@ -1049,7 +1065,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
             launches = T + 2;
         } else rc = enqueue_loop64(s);
         if (rc != GVX_OK) return rc;
-    } else if (m->use_graph && !kt) {
+    } else if (m->use_graph && !kt && !train) {
         const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr, 0.f, pa ? m->pa_depth + 16 * pa_layout : 0};
         rc = run_chunk(m, touch_graph_set(m, m->loop_graphs, key), 0, s, enqueue_loop);
         if (rc != GVX_OK) return rc;
@@ -1242,6 +1258,26 @@ int gvx_decoder_teacher_forced(gvx_model* m, const float* memory, const int32_t*
     float* outs[3] = {mel_out, gate_out, align_out};
     const size_t counts[3] = {(size_t)B * m->d.n_mels * T, (size_t)B * T, (size_t)B * T * L};
     return poison_if_timed_out(m, B, L, ws, wp, outs, counts, 3, (hipStream_t)stream);
+}
+
+int gvx_encoder_lstm_forward(gvx_model* m, const float* conv_out, const int32_t* lengths, int B, int L, float* memory_out, void* ws,
+                             size_t ws_bytes, void* stream) {
+    int rc = check_common(m, B, L, 1, ws, ws_bytes, WS_AUTOREGRESSIVE);
+    if (rc != GVX_OK) return rc;
+    if (!conv_out || !memory_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    return encoder_impl(m, nullptr, lengths, B, L, memory_out, ws, make_ws_plan(m, B, L, 1, WS_AUTOREGRESSIVE), (hipStream_t)stream, conv_out);
+}
+
+int gvx_decoder_teacher_forced_train(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
+                                     const uint8_t* keep_masks, const uint8_t* att_keep, const uint8_t* dec_keep, float p_att, float p_dec,
+                                     float* mel_out, float* gate_out, float* align_out, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(m, B, L, T, ws, ws_bytes);
+    if (rc != GVX_OK) return rc;
+    if (!memory || !mel_in || !keep_masks || !att_keep || !dec_keep || !mel_out || !gate_out || !align_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (!(p_att >= 0.f && p_att < 1.f && p_dec >= 0.f && p_dec < 1.f)) return fail(GVX_ERR_INVALID_ARG, "dropout probabilities must be in [0, 1)");
+    const LstmDropout tr{att_keep, dec_keep, 1.f / (1.f - p_att), 1.f / (1.f - p_dec)};
+    return decoder_tf_impl(m, memory, lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws, make_ws_plan(m, B, L, T),
+                           (hipStream_t)stream, false, &tr);
 }
 
 size_t gvx_postnet_workspace_bytes(const gvx_model* m, int B, int T) {

@@ -84,6 +84,9 @@ struct SkinnyJob {
     const int32_t* lengths; int step; int reverse; int seq_len;  // packed-sequence semantics
     float* seq_out; long seq_bs, seq_ts;       // seq_out[b][t_b][j] (row-major encoder output)
     const float* h_prev;                       // blocked; carried over for inactive rows
+    // training mode: dropout on the cell's hidden output (models/tts/tacotron2.py:341, :358): h' = keep ? h' * h_scale : 0
+    // before anything consumes it (h_out, sequence output, query slab); keep [B][H] uint8, nullptr = no dropout
+    const uint8_t* h_keep; float h_scale;
     // attention query partial products: slab[tile][b][a] = sum_{j in tile} Wq[a][j] * h'[b][j]
     const float* Wq_t;      // [H/8][att_dim][8] (tile-major repack of query_layer.weight) or nullptr
     float* q_slab; int att_dim;

@@ -300,8 +300,13 @@ class Tacotron2(nn.Module):
 
     # ------------------------------------------------------------------ reference surface
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """Teacher-forced text->mel (reference: models/tts/tacotron2.py:450-481). Inference only."""
+        """Teacher-forced text->mel (reference: models/tts/tacotron2.py:450-481).  No autograd graph is built in either
+        mode.  Under ``.train()`` the forward is the reference's training-mode forward - BatchNorm batch statistics (and the
+        running-statistics update), dropout after the encoder / Postnet convolutions and on both LSTM cells' outputs - see
+        ``_forward_train``; the backward of the training step exists for its convolution stacks only (genvox_amd.training)."""
         dev = self._require_gpu()
+        if self.training:
+            return self._forward_train(batch)[0]
         self._ensure_packed()
         tokens = batch["token_padded"].to(device=dev, dtype=torch.int64).contiguous()
         tok_len = batch["token_lengths"].to(device=dev, dtype=torch.int32).contiguous()
@@ -360,6 +365,72 @@ class Tacotron2(nn.Module):
         for lane in streams:
             cur.wait_stream(lane)
         return out
+
+    def _forward_train(self, batch: Dict[str, torch.Tensor]):
+        """Training-mode forward (models/tts/tacotron2.py:450-481 under .train()).  Keep masks of every dropout may be given
+        in ``batch["train_keep_masks"]`` (parity tests): dict with ``encoder`` [n_enc, B, E, L], ``attention_rnn`` [T, B, A],
+        ``decoder_rnn`` [T, B, D], ``postnet`` list of [B, C_i, T]; otherwise they are drawn on the device from torch's
+        generator.  Returns (outputs, tape) - the tape holds what genvox_amd.training's backward pieces need."""
+        from . import training
+
+        dev = self._require_gpu()
+        mc = self.model_config
+        self._ensure_packed()   # LSTM / attention / Prenet / projection weights come from the packed blob
+        lib = _lib.load()
+        tokens = batch["token_padded"].to(device=dev, dtype=torch.int64).contiguous()
+        tok_len = batch["token_lengths"].to(device=dev, dtype=torch.int32).contiguous()
+        mel_in = batch["mel_padded"].to(device=dev, dtype=torch.float32).contiguous()
+        mel_len = batch["mel_lengths"].to(device=dev, dtype=torch.int32).contiguous()
+        B, L = tokens.shape
+        _, M, T = mel_in.shape
+        if B > STREAM_ROWS:
+            raise NotImplementedError("training-mode forward: at most 32 rows per call")
+        E, A, D, P = mc.encoder_embedding_dim, mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.prenet_dim
+        given = batch.get("train_keep_masks") or {}
+        draw = lambda shape, p: (torch.rand(shape, device=dev) >= p).to(torch.uint8)
+        enc_keep = given.get("encoder")
+        enc_keep = [draw((B, E, L), 0.5) for _ in range(mc.encoder_n_convolutions)] if enc_keep is None else list(enc_keep)
+        att_keep = given.get("attention_rnn")
+        att_keep = draw((T, B, A), mc.p_attention_dropout) if att_keep is None else att_keep
+        dec_keep = given.get("decoder_rnn")
+        dec_keep = draw((T, B, D), mc.p_decoder_dropout) if dec_keep is None else dec_keep
+        post_keep = given.get("postnet")
+        if post_keep is None:
+            n = mc.postnet_n_convolutions
+            post_keep = [draw((B, mc.postnet_embedding_dim if i < n - 1 else M, T), 0.5) for i in range(n)]
+        att_keep = att_keep.to(device=dev, dtype=torch.uint8).contiguous()
+        dec_keep = dec_keep.to(device=dev, dtype=torch.uint8).contiguous()
+        pk = batch.get("prenet_keep_masks")
+        masks = self._keep_masks(pk.to(device=dev, dtype=torch.uint8).reshape(2, T + 1, B, P).contiguous() if pk is not None else None,
+                                 2 * (T + 1) * B * P, dev)
+        # encoder: embedding, training-mode convolution stack (parameters in place), BiLSTM
+        emb = self.embedding.weight.data[tokens].transpose(1, 2).contiguous()          # [B, E, L]  (:459)
+        conv_out, enc_tape = training.convstack_train_forward(self, "encoder.convolutions", training.encoder_acts(self), emb, enc_keep)
+        ws = self._get_workspace(B, L, T)
+        st = self._stream()
+        memory = torch.empty(B, L, E, device=dev)
+        _lib.check(lib.gvx_encoder_lstm_forward(self._handle, conv_out.data_ptr(), tok_len.data_ptr(), B, L, memory.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), st))
+        dec_mel = torch.empty(B, M, T, device=dev)
+        gate = torch.empty(B, T, device=dev)
+        align = torch.empty(B, T, L, device=dev)
+        _lib.check(lib.gvx_decoder_teacher_forced_train(
+            self._handle, memory.data_ptr(), tok_len.data_ptr(), B, L, mel_in.data_ptr(), T, masks.data_ptr(), att_keep.data_ptr(),
+            dec_keep.data_ptr(), float(mc.p_attention_dropout), float(mc.p_decoder_dropout), dec_mel.data_ptr(), gate.data_ptr(),
+            align.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        post_y, post_tape = training.convstack_train_forward(self, "postnet.convolutions", training.postnet_acts(self), dec_mel, post_keep)
+        mel_out, mel_post = dec_mel.clone(), dec_mel + post_y
+        if mc.mask_padding:
+            pad = torch.arange(T, device=dev)[None, :] >= mel_len[:, None]
+            mel_out.masked_fill_(pad[:, None, :], 0.0)
+            mel_post.masked_fill_(pad[:, None, :], 0.0)
+            gate.masked_fill_(pad, 1e3)
+        outputs = {"mel_outputs": mel_out, "mel_outputs_postnet": mel_post, "gate_outputs": gate, "alignments": align}
+        tape = {"encoder": enc_tape, "postnet": post_tape, "decoder_mel_unmasked": dec_mel, "memory": memory}
+        # the HIP kernels updated the BatchNorm running statistics through raw pointers (no tensor version bump): the packed
+        # blob - whose eval-mode convolutions have those statistics folded in - is stale now
+        self._packed_key = None
+        return outputs, tape
 
     def inference(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Autoregressive text->mel (reference: models/tts/tacotron2.py:483-499; Decoder.inference :390-414).

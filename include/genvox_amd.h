@@ -193,6 +193,17 @@ int gvx_tacotron2_loss(const float* mel_out, const float* mel_post_out, const fl
  * `saved` carries what the backward needs (gvx_conv_train_saved_bytes); both buffers 256-byte aligned.
  * The LSTM / attention backward (BPTT) and the optimiser step are not built yet: Tacotron2.train_step still raises.
  * ===================================================================================================== */
+/* The rest of the training-mode FORWARD (models/tts/tacotron2.py:231-246, :333-363 under .train()): the encoder's BiLSTM on
+ * the output of its training-mode convolution stack (conv_out [B, embed_dim, L], reference layout), and the teacher-forced
+ * decoder with dropout on the hidden outputs of both LSTM cells (att_keep uint8 [T, B, att_rnn_dim], dec_keep uint8
+ * [T, B, dec_rnn_dim]; kept values scaled by 1 / (1 - p); the dropped state is what the next step, the attention query, the
+ * other cell and the projection see).  Both read the LSTM / attention / Prenet / projection weights from the bound blob. */
+int gvx_encoder_lstm_forward(gvx_model* model, const float* conv_out, const int32_t* lengths, int B, int L, float* memory_out,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int gvx_decoder_teacher_forced_train(gvx_model* model, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in,
+                                     int T, const uint8_t* keep_masks, const uint8_t* att_keep, const uint8_t* dec_keep, float p_att,
+                                     float p_dec, float* mel_out, float* gate_out, float* align_out, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 size_t gvx_conv_train_saved_bytes(int B, int Cin, int Cout, int T, int k);
 size_t gvx_conv_train_workspace_bytes(int B, int Cin, int Cout, int T, int k);
 /* y = dropout(act(BatchNorm_train(conv1d(x, w, bias, padding (k-1)/2)))).  running_mean / running_var (may be NULL) get the

@@ -130,3 +130,42 @@ def test_training_oracle_matches_reference_gradients():
                                   esaved[0]["mean"], esaved[0]["var"], B * L)
     assert max_abs_diff(rm, z["state.encoder.convolutions.0.1.running_mean"]) <= 1e-6
     assert max_abs_diff(rv, z["state.encoder.convolutions.0.1.running_var"]) <= 1e-6
+
+
+def test_training_step_oracle_matches_reference_backward():
+    """oracle/train_ref.py train_forward / train_backward - the whole training step in explicit formulas: BPTT over the decoder
+    loop (both LSTM cells with output dropout, location-sensitive attention incl. the cumulative-weights path), Prenet,
+    encoder BiLSTM with packed-sequence semantics, convolution stacks, embedding - against the gradient of EVERY parameter
+    that the reference's loss.backward() produced (tests/golden/train_small.npz, 48 tensors)."""
+    import numpy as np
+
+    from genvox_amd import weights as gw
+    from oracle import train_ref as tr
+    from tests.golden.cases import TRAIN_CASE
+
+    z = load_fixture("train_small")
+    mc, ac, tc = case_configs(TRAIN_CASE)
+    sd = gw.generate_state_dict(mc, ac, tc, seed=TRAIN_CASE["weight_seed"], peaky_attention=True)
+    B, L, T = TRAIN_CASE["B"], TRAIN_CASE["L"], TRAIN_CASE["T"]
+    M, C, n, E = ac.n_mels, mc.postnet_embedding_dim, mc.postnet_n_convolutions, mc.encoder_embedding_dim
+    A, D, P = mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.prenet_dim
+
+    def unpack(packed, shape):
+        k = int(np.prod(shape))
+        return torch.from_numpy(np.unpackbits(packed, axis=1)[:, :k].reshape((packed.shape[0],) + tuple(shape)))
+
+    pk, pl = unpack(z["post_keep_packed"], (B, C, T)), unpack(z["post_last_keep_packed"], (B, M, T))
+    masks = {"encoder": list(unpack(z["enc_keep_packed"], (B, E, L))), "prenet": unpack(z["prenet_keep_packed"], (T + 1, B, P)),
+             "attention_rnn": unpack(z["att_keep_packed"], (B, A)), "decoder_rnn": unpack(z["dec_keep_packed"], (B, D)),
+             "postnet": [pk[i] for i in range(n - 1)] + [pl[0]]}
+    batch = {k: torch.from_numpy(z[k]) for k in ("token_padded", "token_lengths", "mel_padded", "gate_padded", "mel_lengths")}
+    out, tape = tr.train_forward(sd, batch, masks, mc)
+    for k in ("mel_outputs", "mel_outputs_postnet", "gate_outputs", "alignments"):
+        assert max_abs_diff(out[k], z[k]) <= ORACLE_TOL, k
+    grads = tr.train_backward(sd, batch, masks, mc, out, tape)
+    names = [k[5:] for k in z if k.startswith("grad.")]
+    assert sorted(grads) == sorted(names)
+    for k in names:
+        ref = z["grad." + k]
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        assert max_abs_diff(grads[k], ref) <= max(1e-4 * scale, 2e-6), k

@@ -25,7 +25,7 @@ class gvx_weight_desc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
 
 
-_vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+_vp, _i, _sz, _f, _l = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_long
 
 # name -> (restype, argtypes); every symbol include/genvox_amd.h declares
 SIGNATURES = {
@@ -47,13 +47,28 @@ SIGNATURES = {
     "gvx_mask_padding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gvx_tacotron2_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_tacotron2_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "gvx_encoder_lstm_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
-    "gvx_decoder_teacher_forced_train": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_encoder_lstm_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_decoder_teacher_forced_train": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_train_export": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp, _vp]),
     "gvx_conv_train_saved_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "gvx_conv_train_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "gvx_conv_bn_act_train_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _sz, _vp, _sz, _vp]),
     "gvx_conv_bn_act_train_backward": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_tacotron2_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gvx_train_gemm_nt": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _vp, _vp]),
+    "gvx_train_transpose": (_i, [_vp, _l, _vp, _l, _i, _l, _vp]),
+    "gvx_train_colsum": (_i, [_vp, _l, _i, _vp, _vp]),
+    "gvx_train_axpby": (_i, [_vp, _l, _f, _vp, _l, _f, _vp, _l, _l, _i, _vp]),
+    "gvx_train_lstm_cell_backward": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "gvx_train_attention_weights_backward": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gvx_train_location_conv_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gvx_train_attention_energy_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gvx_train_location_conv_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gvx_train_relu_dropout_backward": (_i, [_vp, _vp, _vp, _f, _l, _vp, _vp]),
+    "gvx_train_unblock": (_i, [_vp, _vp, _l, _i, _i, _vp]),
+    "gvx_train_embedding_backward": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp]),
+    "gvx_train_sqnorm_accumulate": (_i, [_vp, _l, _vp, _vp]),
+    "gvx_train_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _i, _vp]),
     "gvx_prenet_masks_generate": (_i, [_vp, _sz, C.c_uint64, _vp]),
     "gvx_stage_timing_enable": (_i, [_vp, _i]),
     "gvx_stage_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),

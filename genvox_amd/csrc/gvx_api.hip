@@ -632,7 +632,7 @@ int conv_layer(const gvx_model* m, const float* in, float* out, int B, int T, in
 // caller with batch statistics and dropout (gvx_conv_bn_act_train_forward); the embedding and the folded-BatchNorm
 // convolutions are then skipped and only the BiLSTM part runs
 int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, int B, int L, float* memory_out, void* ws,
-                 const WsPlan& wp, hipStream_t s, const float* conv_out = nullptr) {
+                 const WsPlan& wp, hipStream_t s, const float* conv_out = nullptr, float* c_seq_out = nullptr, float* xg_out = nullptr) {
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, H = E / 2, pe = (d.enc_kernel - 1) / 2;
     float* xa = ws_ptr<float>(ws, wp.xa);
@@ -696,6 +696,7 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
                 J.addend = xg + (size_t)dir * 4 * H; J.add_bs = (long)L * 8 * H; J.add_ts = 8 * H;
                 J.lengths = len_ws; J.step = step; J.reverse = dir; J.seq_len = L;
                 J.seq_out = mem_ws + (size_t)dir * H; J.seq_bs = (long)L * E; J.seq_ts = E;
+                if (c_seq_out) J.c_seq_out = c_seq_out + (size_t)dir * H;   // (training tape; the loop is then not replayed from a graph)
                 J.h_prev = h_cur;
             }
             HIP_TRY(launch_skinny(jobs, 2, SK_ENCODER, st));
@@ -703,8 +704,9 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
         return GVX_OK;
     };
     const gvx_model::LoopKey key{ws, mem_ws, m->dev_blob, B, L, 0, lengths != nullptr};
-    const int rc = run_chunk(m, m->use_graph ? touch_graph_set(m, m->enc_graphs, key) : nullptr, 0, s, enqueue);
+    const int rc = run_chunk(m, m->use_graph && !c_seq_out ? touch_graph_set(m, m->enc_graphs, key) : nullptr, 0, s, enqueue);
     if (rc != GVX_OK) return rc;
+    if (xg_out) HIP_TRY(hipMemcpyAsync(xg_out, xg, (size_t)B * L * 8 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (memory_out != mem_ws)
         HIP_TRY(hipMemcpyAsync(memory_out, mem_ws, (size_t)B * L * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     return GVX_OK;
@@ -889,7 +891,12 @@ int decoder_prenet_part(gvx_model* m, int B, int L, const float* mel_in, int T, 
 
 // Training mode (models/tts/tacotron2.py:341, :358): the outputs of both LSTM cells go through dropout before anything uses
 // them (next step's recurrence, the attention query, the other cell, the projection).  Explicit keep masks, as for the Prenet.
-struct LstmDropout { const uint8_t* att_keep; const uint8_t* dec_keep; float att_scale, dec_scale; };   // [T][B][A], [T][B][D]
+struct LstmDropout {
+    const uint8_t* att_keep; const uint8_t* dec_keep; float att_scale, dec_scale;   // [T][B][A], [T][B][D]
+    // tape for back-propagation through time (all may be nullptr): the attention LSTM's (dropped) hidden state of every step as
+    // blocked vectors [T+1][A/8][B][8] (slot t + 1 = after step t, slot 0 = zeros) and both cells' states [T+1][B][H] row-major
+    float* h_a_all; float* c_a_all; float* c_d_all;
+};
 
 int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
                     const uint8_t* keep_masks, float* mel_out, float* gate_out, float* align_out, void* ws, const WsPlan& wp,
@@ -980,8 +987,17 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
                 defer(jobs[1], t - 1, false);
             }
             if (train) {
-                jobs[0].h_keep = train->att_keep + (size_t)t * B * d.att_rnn_dim; jobs[0].h_scale = train->att_scale;
-                if (t > 0) { jobs[1].h_keep = train->dec_keep + (size_t)(t - 1) * B * D; jobs[1].h_scale = train->dec_scale; }
+                const size_t BA = (size_t)B * d.att_rnn_dim, BD = (size_t)B * D;
+                jobs[0].h_keep = train->att_keep + (size_t)t * BA; jobs[0].h_scale = train->att_scale;
+                if (train->h_a_all) {
+                    jobs[0].x[2].p = train->h_a_all + (size_t)t * BA; jobs[0].h_out = train->h_a_all + (size_t)(t + 1) * BA;
+                }
+                if (train->c_a_all) { jobs[0].c = train->c_a_all + (size_t)t * BA; jobs[0].c_out = train->c_a_all + (size_t)(t + 1) * BA; }
+                if (t > 0) {
+                    jobs[1].h_keep = train->dec_keep + (size_t)(t - 1) * BD; jobs[1].h_scale = train->dec_scale;
+                    if (train->h_a_all) jobs[1].x[0].p = train->h_a_all + (size_t)t * BA;   // h_a(t-1)
+                    if (train->c_d_all) { jobs[1].c = train->c_d_all + (size_t)(t - 1) * BD; jobs[1].c_out = train->c_d_all + (size_t)t * BD; }
+                }
             }
             if (pa) {
                 HIP_TRY(launch_skinny_pa(jobs[0], t > 0 ? &jobs[1] : nullptr, st, m->pa_depth, pa_layout));
@@ -999,7 +1015,12 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         SkinnyJob job;
         fill_dec_job(m, job, T - 1, B, db);
         defer(job, T - 1, false);
-        if (train) { job.h_keep = train->dec_keep + (size_t)(T - 1) * B * D; job.h_scale = train->dec_scale; }
+        if (train) {
+            const size_t BA = (size_t)B * d.att_rnn_dim, BD = (size_t)B * D;
+            job.h_keep = train->dec_keep + (size_t)(T - 1) * BD; job.h_scale = train->dec_scale;
+            if (train->h_a_all) job.x[0].p = train->h_a_all + (size_t)T * BA;
+            if (train->c_d_all) { job.c = train->c_d_all + (size_t)(T - 1) * BD; job.c_out = train->c_d_all + (size_t)T * BD; }
+        }
         HIP_TRY(launch_skinny(&job, 1, SK_DECODER, st));
         ++launches;
         return GVX_OK;
@@ -1260,24 +1281,55 @@ int gvx_decoder_teacher_forced(gvx_model* m, const float* memory, const int32_t*
     return poison_if_timed_out(m, B, L, ws, wp, outs, counts, 3, (hipStream_t)stream);
 }
 
-int gvx_encoder_lstm_forward(gvx_model* m, const float* conv_out, const int32_t* lengths, int B, int L, float* memory_out, void* ws,
-                             size_t ws_bytes, void* stream) {
+int gvx_encoder_lstm_forward(gvx_model* m, const float* conv_out, const int32_t* lengths, int B, int L, float* memory_out,
+                             float* cell_states_out, float* input_preact_out, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_common(m, B, L, 1, ws, ws_bytes, WS_AUTOREGRESSIVE);
     if (rc != GVX_OK) return rc;
     if (!conv_out || !memory_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
-    return encoder_impl(m, nullptr, lengths, B, L, memory_out, ws, make_ws_plan(m, B, L, 1, WS_AUTOREGRESSIVE), (hipStream_t)stream, conv_out);
+    if (cell_states_out) HIP_TRY(zero_async(cell_states_out, (size_t)B * L * m->d.embed_dim * sizeof(float), (hipStream_t)stream));
+    return encoder_impl(m, nullptr, lengths, B, L, memory_out, ws, make_ws_plan(m, B, L, 1, WS_AUTOREGRESSIVE), (hipStream_t)stream, conv_out,
+                        cell_states_out, input_preact_out);
 }
 
 int gvx_decoder_teacher_forced_train(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
                                      const uint8_t* keep_masks, const uint8_t* att_keep, const uint8_t* dec_keep, float p_att, float p_dec,
-                                     float* mel_out, float* gate_out, float* align_out, void* ws, size_t ws_bytes, void* stream) {
+                                     float* mel_out, float* gate_out, float* align_out, float* att_hidden_all, float* att_cell_all,
+                                     float* dec_cell_all, float* dec_hidden_context_all, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_common(m, B, L, T, ws, ws_bytes);
     if (rc != GVX_OK) return rc;
     if (!memory || !mel_in || !keep_masks || !att_keep || !dec_keep || !mel_out || !gate_out || !align_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
     if (!(p_att >= 0.f && p_att < 1.f && p_dec >= 0.f && p_dec < 1.f)) return fail(GVX_ERR_INVALID_ARG, "dropout probabilities must be in [0, 1)");
-    const LstmDropout tr{att_keep, dec_keep, 1.f / (1.f - p_att), 1.f / (1.f - p_dec)};
-    return decoder_tf_impl(m, memory, lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws, make_ws_plan(m, B, L, T),
-                           (hipStream_t)stream, false, &tr);
+    hipStream_t s = (hipStream_t)stream;
+    const int A = m->d.att_rnn_dim, D = m->d.dec_rnn_dim, E = m->d.embed_dim;
+    const LstmDropout tr{att_keep, dec_keep, 1.f / (1.f - p_att), 1.f / (1.f - p_dec), att_hidden_all, att_cell_all, dec_cell_all};
+    if (att_hidden_all) HIP_TRY(zero_async(att_hidden_all, (size_t)B * A * sizeof(float), s));   // slot 0: the initial (zero) states
+    if (att_cell_all) HIP_TRY(zero_async(att_cell_all, (size_t)B * A * sizeof(float), s));
+    if (dec_cell_all) HIP_TRY(zero_async(dec_cell_all, (size_t)B * D * sizeof(float), s));
+    const WsPlan wp = make_ws_plan(m, B, L, T);
+    rc = decoder_tf_impl(m, memory, lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws, wp, s, false, &tr);
+    if (rc != GVX_OK) return rc;
+    if (dec_hidden_context_all)   // [T+1] slots of blocked [h_d ; ctx] vectors: slot t + 1 = after step t
+        HIP_TRY(hipMemcpyAsync(dec_hidden_context_all, ws_ptr<float>(ws, wp.hc), (size_t)(T + 1) * B * (D + E) * sizeof(float),
+                               hipMemcpyDeviceToDevice, s));
+    return GVX_OK;
+}
+
+int gvx_train_export(const gvx_model* m, const void* ws_c, size_t ws_bytes, int B, int L, int T, int what, float* dst, void* stream) {
+    void* ws = const_cast<void*>(ws_c);
+    if (!m || !ws || !dst) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    const WsPlan wp = make_ws_plan(m, B, L, T);
+    if (ws_bytes < wp.total) return fail(GVX_ERR_WORKSPACE, "workspace too small");
+    const gvx_dims& d = m->d;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = (size_t)(T + 1) * B;
+    switch (what) {
+        case 0: HIP_TRY(hipMemcpyAsync(dst, ws_ptr<float>(ws, wp.frames), rows * d.n_mels * sizeof(float), hipMemcpyDeviceToDevice, s)); break;
+        case 1: HIP_TRY(hipMemcpyAsync(dst, ws_ptr<float>(ws, wp.pre1), rows * d.prenet_dim * sizeof(float), hipMemcpyDeviceToDevice, s)); break;
+        case 2: return gvx_train_unblock(ws_ptr<float>(ws, wp.prenet), dst, T + 1, B, d.prenet_dim, stream);
+        case 3: HIP_TRY(hipMemcpyAsync(dst, ws_ptr<float>(ws, wp.pm), (size_t)B * L * d.att_dim * sizeof(float), hipMemcpyDeviceToDevice, s)); break;
+        default: return fail(GVX_ERR_INVALID_ARG, "gvx_train_export: unknown buffer %d", what);
+    }
+    return GVX_OK;
 }
 
 size_t gvx_postnet_workspace_bytes(const gvx_model* m, int B, int T) {

@@ -87,6 +87,9 @@ struct SkinnyJob {
     // training mode: dropout on the cell's hidden output (models/tts/tacotron2.py:341, :358): h' = keep ? h' * h_scale : 0
     // before anything consumes it (h_out, sequence output, query slab); keep [B][H] uint8, nullptr = no dropout
     const uint8_t* h_keep; float h_scale;
+    // training mode: where to write the new cell state (nullptr: in place, into c) and, for sequence jobs, the cell state of
+    // every position like seq_out (c_seq_out[b][t_b][j], same strides) - what back-propagation through time reads
+    float* c_out; float* c_seq_out;
     // attention query partial products: slab[tile][b][a] = sum_{j in tile} Wq[a][j] * h'[b][j]
     const float* Wq_t;      // [H/8][att_dim][8] (tile-major repack of query_layer.weight) or nullptr
     float* q_slab; int att_dim;

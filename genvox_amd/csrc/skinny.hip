@@ -542,8 +542,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                     const float c_new = sigmoidf_(pre[1]) * c_old + sigmoidf_(pre[0]) * tanhf_(pre[2]);
                     hval = sigmoidf_(pre[3]) * tanhf_(c_new);
                     if (J.h_keep) hval = J.h_keep[(long)b * H + j] ? hval * J.h_scale : 0.f;
-                    J.c[(long)b * H + j] = c_new;
+                    (J.c_out ? J.c_out : J.c)[(long)b * H + j] = c_new;
                     if (J.seq_out) J.seq_out[(long)b * J.seq_bs + (long)tb * J.seq_ts + j] = hval;
+                    if (J.c_seq_out) J.c_seq_out[(long)b * J.seq_bs + (long)tb * J.seq_ts + j] = c_new;
                 } else {
                     hval = J.h_prev[hoff];
                 }

@@ -376,3 +376,326 @@ int gvx_tacotron2_loss_backward(const float* mel_out, const float* mel_post_out,
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Back-propagation through time: generic primitives for the host side (genvox_amd/training.py), which walks the decoder
+// loop and the encoder BiLSTM backwards exactly as oracle/train_ref.py states it.  All tensors row-major fp32 with an
+// explicit leading dimension where slices are taken.  Correctness first (one fused kernel per formula group; the dense
+// products go through the exact-fp32 MFMA GEMM).
+// =====================================================================================================================
+namespace gvx {
+namespace {
+
+// ---- LSTM cell backward (torch gate order i, f, g, o in blocks of H along the row) -----------------------------------------
+// dh = dh_a[b][j] (+ dh_b[b][j]); h' = o tanh(c) * keep * scale.  pre = gate pre-activations [B][4H]; c_prev [B][H].
+// active (may be null): rows with active[b] == 0 pass (dh, dc) through: dgates = 0, dc_prev = dc_next, dh_pass = dh.
+__global__ void lstm_cell_bwd_kernel(const float* dh_a, long ld_a, const float* dh_b, long ld_b, const float* dc_next, const float* pre,
+                                     const float* c_prev, const uint8_t* keep, float scale, const uint8_t* active, int B, int H,
+                                     float* dgates, float* dc_prev, float* dh_pass) {
+    const long n = (long)B * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % H), b = (int)(i / H);
+        float dh = dh_a[(long)b * ld_a + j];
+        if (dh_b) dh += dh_b[(long)b * ld_b + j];
+        const float dcn = dc_next[i];
+        float* dg = dgates + (long)b * 4 * H;
+        if (active && !active[b]) {
+            dg[j] = dg[H + j] = dg[2 * H + j] = dg[3 * H + j] = 0.f;
+            dc_prev[i] = dcn;
+            if (dh_pass) dh_pass[i] = dh;
+            continue;
+        }
+        const float* p = pre + (long)b * 4 * H;
+        const float ig = 1.f / (1.f + expf(-p[j])), fg = 1.f / (1.f + expf(-p[H + j])), gg = tanhf(p[2 * H + j]), og = 1.f / (1.f + expf(-p[3 * H + j]));
+        const float cp = c_prev[i];
+        const float c = fg * cp + ig * gg, tc = tanhf(c);
+        if (keep) dh = keep[i] ? dh * scale : 0.f;
+        const float d_o = dh * tc;
+        const float dc = dh * og * (1.f - tc * tc) + dcn;
+        dg[j] = dc * gg * ig * (1.f - ig);
+        dg[H + j] = dc * cp * fg * (1.f - fg);
+        dg[2 * H + j] = dc * ig * (1.f - gg * gg);
+        dg[3 * H + j] = d_o * og * (1.f - og);
+        dc_prev[i] = dc * fg;
+        if (dh_pass) dh_pass[i] = 0.f;
+    }
+}
+
+// ---- attention step backward, part 1: one workgroup per batch row --------------------------------------------------------
+// dw[l] = dw_next[l] + G[l] + sum_e dctx[e] memory[l][e];  dmemory[l][:] += w[l] dctx;  de[l] = w[l] (dw[l] - sum_l' w dw)
+__global__ __launch_bounds__(256) void attn_bwd_weights_kernel(const float* dctx_a, long ld_a, const float* dctx_b, long ld_b, const float* dctx_c,
+                                                               long ld_c, const float* dw_next, const float* G, const float* memory,
+                                                               const float* w, int L, int E, float* dmemory, float* de, float* dctx_sum) {
+    extern __shared__ float sm[];   // dctx [E], dw [L], red [256]
+    float* dc = sm; float* dw = sm + E; float* red = dw + L;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < E; e += 256) {
+        float v = dctx_a[(long)b * ld_a + e];
+        if (dctx_b) v += dctx_b[(long)b * ld_b + e];
+        if (dctx_c) v += dctx_c[(long)b * ld_c + e];
+        dc[e] = v;
+        if (dctx_sum) dctx_sum[(long)b * E + e] = v;
+    }
+    __syncthreads();
+    const float* mb = memory + (long)b * L * E;
+    float* dmb = dmemory + (long)b * L * E;
+    const float* wb = w + (long)b * L;
+    for (int l = tid >> 5; l < L; l += 8) {   // 8 groups of 32 lanes, one position each
+        float acc = 0.f;
+        const float wl = wb[l];
+        for (int e = tid & 31; e < E; e += 32) {
+            acc += dc[e] * mb[(long)l * E + e];
+            dmb[(long)l * E + e] += wl * dc[e];
+        }
+        for (int o = 16; o > 0; o >>= 1) acc += __shfl_down(acc, o, 32);
+        if ((tid & 31) == 0) dw[l] = acc + dw_next[(long)b * L + l] + G[(long)b * L + l];
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int l = tid; l < L; l += 256) part += wb[l] * dw[l];
+    red[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float s = red[0];
+    for (int l = tid; l < L; l += 256) de[(long)b * L + l] = wb[l] * (dw[l] - s);
+}
+
+// location convolution forward, channels-last: locf[(b,l)][f] = sum_{c,k} in_c[b][l + k - pad] lw[f][c][k]   (in_0 = w_prev, in_1 = w_cum_prev)
+__global__ void loc_conv_fwd_kernel(const float* w_prev, const float* w_cum, const float* lw, int B, int L, int F, int k, float* locf) {
+    const int pad = (k - 1) / 2;
+    const long n = (long)B * L * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F);
+        const long bl = i / F;
+        const int l = (int)(bl % L), b = (int)(bl / L);
+        float acc = 0.f;
+        for (int c = 0; c < 2; ++c) {
+            const float* x = (c == 0 ? w_prev : w_cum) + (long)b * L;
+            for (int j = 0; j < k; ++j) {
+                const int p = l + j - pad;
+                if (p >= 0 && p < L) acc += x[p] * lw[((long)f * 2 + c) * k + j];
+            }
+        }
+        locf[i] = acc;
+    }
+}
+
+// u = q[b] + locd[(b,l)] + pm[(b,l)]; th = tanh(u); du = de v (1 - th^2); dpm += du; per (b): dq[a] = sum_l du, dv_acc[b][a] += sum_l de th
+__global__ __launch_bounds__(256) void attn_bwd_energy_kernel(const float* q, const float* locd, const float* pm, const float* v, const float* de,
+                                                              int L, int a, float* du, float* dpm, float* dq, float* dv_acc) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int d = tid; d < a; d += 256) {
+        const float qd = q[(long)b * a + d], vd = v[d];
+        float sq = 0.f, sv = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const long o = ((long)b * L + l) * a + d;
+            const float th = tanhf(qd + locd[o] + pm[o]);
+            const float e = de[(long)b * L + l];
+            const float g = e * vd * (1.f - th * th);
+            du[o] = g;
+            dpm[o] += g;
+            sq += g; sv += e * th;
+        }
+        dq[(long)b * a + d] = sq;
+        dv_acc[(long)b * a + d] += sv;
+    }
+}
+
+// location convolution backward: dloc_in[b][c][l] = sum_{f,j} dlocf[(b, l - j + pad)][f] lw[f][c][j];
+// dlw_acc[b][f][c][j] += sum_l dlocf[(b,l)][f] in_c[b][l + j - pad]     (per-row accumulators: fixed summation order)
+__global__ __launch_bounds__(256) void loc_conv_bwd_kernel(const float* dlocf, const float* w_prev, const float* w_cum, const float* lw, int L, int F,
+                                                           int k, float* dw_prev_out, float* G, float* dlw_acc) {
+    const int b = blockIdx.x, tid = threadIdx.x, pad = (k - 1) / 2;
+    const float* dl = dlocf + (long)b * L * F;
+    for (int i = tid; i < 2 * L; i += 256) {
+        const int c = i / L, l = i - c * L;
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int p = l - j + pad;
+            if (p < 0 || p >= L) continue;
+            for (int f = 0; f < F; ++f) acc += dl[(long)p * F + f] * lw[((long)f * 2 + c) * k + j];
+        }
+        if (c == 0) dw_prev_out[(long)b * L + l] = acc;
+        else G[(long)b * L + l] += acc;
+    }
+    for (int i = tid; i < F * 2 * k; i += 256) {
+        const int j = i % k, c = (i / k) % 2, f = i / (2 * k);
+        const float* x = (c == 0 ? w_prev : w_cum) + (long)b * L;
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const int p = l + j - pad;
+            if (p >= 0 && p < L) acc += dl[(long)l * F + f] * x[p];
+        }
+        dlw_acc[(long)b * F * 2 * k + i] += acc;
+    }
+}
+
+// generic elementwise: y[r][c] = alpha * a[r][c] + beta * b[r][c]   (b may be null), each with its own leading dimension
+__global__ void axpby_kernel(const float* a, long lda, float alpha, const float* b, long ldb, float beta, float* y, long ldy, long rows, int cols) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols);
+        const long r = i / cols;
+        float v = alpha * a[r * lda + c];
+        if (b) v += beta * b[r * ldb + c];
+        y[r * ldy + c] = v;
+    }
+}
+// dz = dy * keep * scale * (act_out > 0)      (Prenet: relu then dropout)
+__global__ void relu_drop_bwd_kernel(const float* dy, const float* act_out, const uint8_t* keep, float scale, long n, float* dz) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dz[i] = (keep[i] && act_out[i] > 0.f) ? dy[i] * scale : 0.f;
+}
+// k-group-blocked vector [K/8][B][8] -> row-major [B][K]  (slots: n_slots consecutive vectors)
+__global__ void unblock_kernel(const float* src, float* dst, long n_slots, int B, int K) {
+    const long n = n_slots * B * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const long sb = i / K;
+        const int b = (int)(sb % B);
+        const long s = sb / B;
+        dst[i] = src[s * B * K + (long)(k >> 3) * B * 8 + b * 8 + (k & 7)];
+    }
+}
+__global__ void embedding_bwd_kernel(const int64_t* tokens, const float* dx, long n_tok, int E, int n_rows, float* demb) {
+    const long n = n_tok * E;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long t = i / E;
+        const int e = (int)(i % E);
+        const int64_t id = tokens[t];
+        if (id >= 0 && id < n_rows) atomicAdd(demb + id * E + e, dx[i]);
+    }
+}
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* x, long n, double* acc) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += (double)x[i] * (double)x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+}
+// torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected), gradient pre-scaled by gscale (clipping)
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float gscale, float lr, float wd, float b1, float b2, float eps,
+                            float bc1, float bc2_sqrt) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale + wd * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+}  // namespace
+}  // namespace gvx
+
+extern "C" {
+
+// C[m][n] = sum_k A[m*lda + k] * W[n*ldw + k] (+ bias[n]);  K % 4 == 0
+int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K, const float* bias, void* stream) {
+    if (!A || !W || !C || M < 1 || N < 1 || K < 4 || (K & 3)) return tfail(GVX_ERR_INVALID_ARG, "gemm_nt: null argument or K not a positive multiple of 4");
+    GemmParams g{};
+    g.A = A; g.amap = RowMap{M, 0, lda};
+    g.W = W; g.ldw = ldw;
+    g.C = C; g.cmap = RowMap{M, 0, ldc};
+    g.bias = bias; g.M = M; g.N = N; g.K = K; g.act = ACT_NONE;
+    TR_TRY(launch_gemm(g, (hipStream_t)stream));
+    return GVX_OK;
+}
+// dst[c][r] = src[r * ld_src + c] for r < rows (0 for rows <= r < rows_p);  dst rows are rows_p long
+int gvx_train_transpose(const float* src, long ld_src, float* dst, long rows, int cols, long rows_p, void* stream) {
+    if (!src || !dst || rows < 1 || cols < 1 || rows_p < rows) return tfail(GVX_ERR_INVALID_ARG, "transpose: bad argument");
+    if (ld_src != cols) return tfail(GVX_ERR_UNSUPPORTED, "transpose: source must be dense (ld == cols)");
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(blocks_for((long)cols * rows_p)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, rows_p);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_colsum(const float* X, long rows, int C, float* out, void* stream) {
+    if (!X || !out || rows < 1 || C < 1) return tfail(GVX_ERR_INVALID_ARG, "colsum: bad argument");
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, rows, C, out, (float*)nullptr);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_axpby(const float* a, long lda, float alpha, const float* b, long ldb, float beta, float* y, long ldy, long rows, int cols, void* stream) {
+    if (!a || !y || rows < 1 || cols < 1) return tfail(GVX_ERR_INVALID_ARG, "axpby: bad argument");
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, a, lda, alpha, b, ldb, beta, y, ldy, rows, cols);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_lstm_cell_backward(const float* dh_a, long ld_a, const float* dh_b, long ld_b, const float* dc_next, const float* pre,
+                                 const float* c_prev, const uint8_t* keep, float scale, const uint8_t* active, int B, int H, float* dgates,
+                                 float* dc_prev, float* dh_pass, void* stream) {
+    if (!dh_a || !dc_next || !pre || !c_prev || !dgates || !dc_prev || B < 1 || H < 1) return tfail(GVX_ERR_INVALID_ARG, "lstm_cell_backward: bad argument");
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(blocks_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dh_a, ld_a, dh_b, ld_b, dc_next, pre,
+                       c_prev, keep, scale, active, B, H, dgates, dc_prev, dh_pass);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_attention_weights_backward(const float* dctx_a, long ld_a, const float* dctx_b, long ld_b, const float* dctx_c, long ld_c,
+                                         const float* dw_next, const float* G, const float* memory, const float* w, int B, int L, int E,
+                                         float* dmemory, float* de, float* dctx_sum, void* stream) {
+    if (!dctx_a || !dw_next || !G || !memory || !w || !dmemory || !de || B < 1 || L < 1 || E < 1) return tfail(GVX_ERR_INVALID_ARG, "attention_weights_backward: bad argument");
+    const size_t lds = (size_t)(E + L + 256) * sizeof(float);
+    if (lds > 64 * 1024) return tfail(GVX_ERR_UNSUPPORTED, "attention_weights_backward: L + E too large for one workgroup's LDS");
+    hipLaunchKernelGGL(attn_bwd_weights_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dctx_a, ld_a, dctx_b, ld_b, dctx_c, ld_c, dw_next, G,
+                       memory, w, L, E, dmemory, de, dctx_sum);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_location_conv_forward(const float* w_prev, const float* w_cum, const float* lw, int B, int L, int F, int k, float* locf, void* stream) {
+    if (!w_prev || !w_cum || !lw || !locf || B < 1 || L < 1 || F < 1 || k < 1 || !(k & 1)) return tfail(GVX_ERR_INVALID_ARG, "location_conv_forward: bad argument");
+    hipLaunchKernelGGL(loc_conv_fwd_kernel, dim3(blocks_for((long)B * L * F)), dim3(256), 0, (hipStream_t)stream, w_prev, w_cum, lw, B, L, F, k, locf);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_attention_energy_backward(const float* q, const float* locd, const float* pm, const float* v, const float* de, int B, int L, int a,
+                                        float* du, float* dpm, float* dq, float* dv_acc, void* stream) {
+    if (!q || !locd || !pm || !v || !de || !du || !dpm || !dq || !dv_acc || B < 1 || L < 1 || a < 1) return tfail(GVX_ERR_INVALID_ARG, "attention_energy_backward: bad argument");
+    hipLaunchKernelGGL(attn_bwd_energy_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, locd, pm, v, de, L, a, du, dpm, dq, dv_acc);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_location_conv_backward(const float* dlocf, const float* w_prev, const float* w_cum, const float* lw, int B, int L, int F, int k,
+                                     float* dw_prev_out, float* G, float* dlw_acc, void* stream) {
+    if (!dlocf || !w_prev || !w_cum || !lw || !dw_prev_out || !G || !dlw_acc || B < 1) return tfail(GVX_ERR_INVALID_ARG, "location_conv_backward: bad argument");
+    hipLaunchKernelGGL(loc_conv_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dlocf, w_prev, w_cum, lw, L, F, k, dw_prev_out, G, dlw_acc);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_relu_dropout_backward(const float* dy, const float* act_out, const uint8_t* keep, float scale, long n, float* dz, void* stream) {
+    if (!dy || !act_out || !keep || !dz || n < 1) return tfail(GVX_ERR_INVALID_ARG, "relu_dropout_backward: bad argument");
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dy, act_out, keep, scale, n, dz);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_unblock(const float* blocked, float* rows_out, long n_slots, int B, int K, void* stream) {
+    if (!blocked || !rows_out || n_slots < 1 || B < 1 || K < 8 || (K & 7)) return tfail(GVX_ERR_INVALID_ARG, "unblock: bad argument");
+    hipLaunchKernelGGL(unblock_kernel, dim3(blocks_for(n_slots * B * K)), dim3(256), 0, (hipStream_t)stream, blocked, rows_out, n_slots, B, K);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_embedding_backward(const int64_t* tokens, const float* dx, long n_tokens_in_batch, int E, int n_rows, float* demb, void* stream) {
+    if (!tokens || !dx || !demb || n_tokens_in_batch < 1 || E < 1 || n_rows < 1) return tfail(GVX_ERR_INVALID_ARG, "embedding_backward: bad argument");
+    TR_TRY(hipMemsetAsync(demb, 0, (size_t)n_rows * E * sizeof(float), (hipStream_t)stream));
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(blocks_for(n_tokens_in_batch * E)), dim3(256), 0, (hipStream_t)stream, tokens, dx, n_tokens_in_batch, E, n_rows, demb);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_sqnorm_accumulate(const float* x, long n, double* acc, void* stream) {
+    if (!x || !acc || n < 1) return tfail(GVX_ERR_INVALID_ARG, "sqnorm: bad argument");
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks_for(n) > 256 ? 256 : blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, acc);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+int gvx_train_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float grad_scale, float lr, float weight_decay,
+                        float beta1, float beta2, float eps, int step, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return tfail(GVX_ERR_INVALID_ARG, "adam_step: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, grad_scale, lr, weight_decay,
+                       beta1, beta2, eps, bc1, bc2s);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+
+}  // extern "C"

@@ -409,15 +409,26 @@ class Tacotron2(nn.Module):
         ws = self._get_workspace(B, L, T)
         st = self._stream()
         memory = torch.empty(B, L, E, device=dev)
+        enc_c = torch.empty(B, L, E, device=dev)
         _lib.check(lib.gvx_encoder_lstm_forward(self._handle, conv_out.data_ptr(), tok_len.data_ptr(), B, L, memory.data_ptr(),
-                                                ws.data_ptr(), ws.numel(), st))
+                                                enc_c.data_ptr(), None, ws.data_ptr(), ws.numel(), st))
         dec_mel = torch.empty(B, M, T, device=dev)
         gate = torch.empty(B, T, device=dev)
         align = torch.empty(B, T, L, device=dev)
+        ha_blk = torch.empty((T + 1) * B * A, device=dev)
+        c_a_all, c_d_all = torch.empty(T + 1, B, A, device=dev), torch.empty(T + 1, B, D, device=dev)
+        hc_blk = torch.empty((T + 1) * B * (D + E), device=dev)
         _lib.check(lib.gvx_decoder_teacher_forced_train(
             self._handle, memory.data_ptr(), tok_len.data_ptr(), B, L, mel_in.data_ptr(), T, masks.data_ptr(), att_keep.data_ptr(),
             dec_keep.data_ptr(), float(mc.p_attention_dropout), float(mc.p_decoder_dropout), dec_mel.data_ptr(), gate.data_ptr(),
-            align.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            align.data_ptr(), ha_blk.data_ptr(), c_a_all.data_ptr(), c_d_all.data_ptr(), hc_blk.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        # the rest of the tape: per-step vectors as plain rows, the Prenet activations and the processed memory
+        ops = training._Ops(dev)
+        export = lambda what, shape: (lambda t: (_lib.check(lib.gvx_train_export(self._handle, ws.data_ptr(), ws.numel(), B, L, T, what, t.data_ptr(), st)), t)[1])(torch.empty(*shape, device=dev))
+        dec_tape = {"h_a_all": training._unblock(ops, ha_blk, T + 1, B, A), "hc_all": training._unblock(ops, hc_blk, T + 1, B, D + E),
+                    "c_a_all": c_a_all, "c_d_all": c_d_all, "frames": export(0, (T + 1, B, M)), "p1": export(1, (T + 1, B, P)),
+                    "p2": export(2, (T + 1, B, P)), "pm": export(3, (B, L, mc.attention_dim)), "att_keep": att_keep, "dec_keep": dec_keep,
+                    "prenet_keep": masks.reshape(2, T + 1, B, P), "enc_conv_out": conv_out, "enc_cell_states": enc_c}
         post_y, post_tape = training.convstack_train_forward(self, "postnet.convolutions", training.postnet_acts(self), dec_mel, post_keep)
         mel_out, mel_post = dec_mel.clone(), dec_mel + post_y
         if mc.mask_padding:
@@ -426,7 +437,7 @@ class Tacotron2(nn.Module):
             mel_post.masked_fill_(pad[:, None, :], 0.0)
             gate.masked_fill_(pad, 1e3)
         outputs = {"mel_outputs": mel_out, "mel_outputs_postnet": mel_post, "gate_outputs": gate, "alignments": align}
-        tape = {"encoder": enc_tape, "postnet": post_tape, "decoder_mel_unmasked": dec_mel, "memory": memory}
+        tape = {"encoder": enc_tape, "postnet": post_tape, "decoder_mel_unmasked": dec_mel, "memory": memory, **dec_tape}
         # the HIP kernels updated the BatchNorm running statistics through raw pointers (no tensor version bump): the packed
         # blob - whose eval-mode convolutions have those statistics folded in - is stale now
         self._packed_key = None
@@ -596,11 +607,36 @@ class Tacotron2(nn.Module):
             config_map={"text_config": TextConfig, "audio_config": AudioConfig, "model_config": Tacotron2Config})
         return Tacotron2(**configs)
 
-    def train_step(self, *args, **kwargs):
-        raise NotImplementedError("genvox_amd.Tacotron2.train_step: the backward through the LSTMs and the attention (BPTT) and the "
-                                  "optimiser step are not built; what exists of the training step - the training-mode convolution "
-                                  "stacks, the criterion backward and the Postnet / encoder-convolution gradients - is in "
-                                  "genvox_amd.training.  Train with the reference and load the checkpoint here.")
+    def get_optimizer(self) -> Dict:
+        """Reference: tacotron2.py:506-513 (torch.optim.Adam over all parameters with the config's learning rate and weight
+        decay); here genvox_amd.training.Adam, the same update as one HIP kernel per tensor."""
+        from . import training
+
+        return {"optimizer": training.Adam(self, lr=self.model_config.learning_rate, weight_decay=self.model_config.weight_decay)}
+
+    def train_step(self, batch: Dict, criterion: Optional[Dict] = None, optimizer: Optional[Dict] = None) -> None:
+        """One training step (reference: tacotron2.py:515-522): training-mode forward, Tacotron2Loss, backward through the whole
+        model, clip_grad_norm_, Adam.  No autograd: the backward is explicit (genvox_amd.training.train_backward, HIP kernels
+        behind the C ABI; the formulas are pinned to the reference's loss.backward() through oracle/train_ref.py).  Fills
+        ``loss_items`` and ``grad_norm_val`` like the reference.  First version: correct, not tuned (the decoder loop is
+        walked back with ~20 small launches per step); at most 32 rows per call."""
+        from . import training
+
+        if optimizer is None:
+            raise ValueError("train_step needs the optimizer dict of get_optimizer()")
+        self.train()
+        outputs, tape = self._forward_train(batch)
+        loss = (criterion or self.get_criterion())["loss"](batch, outputs)
+        self.loss_items = {key: val.item() for key, val in loss.items()}
+        grads = training.train_backward(self, batch, outputs, tape)
+        self.grad_norm_val, scale = training.clip_grad_norm(grads, self.model_config.grad_clip_thresh)
+        optimizer["optimizer"].step(grads, scale)
+        self._packed_key = None
+        self.last_grads = grads   # (kept for inspection / tests; the reference keeps them in .grad)
+
+    def get_train_step_logs(self) -> Dict:
+        """Reference: tacotron2.py:553-560."""
+        return {**self.loss_items, "grad_norm": self.grad_norm_val}
 
     def get_criterion(self) -> Dict:
         """Reference: tacotron2.py:501-504."""

@@ -147,3 +147,310 @@ def postnet_train_step_slice(model, decoder_mel: torch.Tensor, batch: Dict[str, 
     # convolution is that storage, so its weight gradient is computed from the masked tensor
     dx, grads = convstack_train_backward(tape, dpost, first_layer_wgrad_input=mel)
     return outputs, grads, dmel + dpost + dx, dgate
+
+
+# =====================================================================================================================
+# The whole backward of the training step (loss.backward() of the reference, models/tts/tacotron2.py:519): host side.
+# Walks the decoder loop and the encoder BiLSTM backwards exactly as oracle/train_ref.py::train_backward states it; every
+# formula runs in a HIP kernel behind the C ABI (csrc/train.hip: gvx_train_*), torch only allocates, slices and reshapes.
+# =====================================================================================================================
+class _Ops:
+    """Thin wrappers over the gvx_train_* primitives (row-major fp32 tensors whose last stride is 1)."""
+
+    def __init__(self, dev):
+        self.lib = _lib.load()
+        self.dev = dev
+        self.st = torch.cuda.current_stream(dev).cuda_stream
+
+    @staticmethod
+    def _ld(t: torch.Tensor) -> int:
+        assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32, (t.shape, t.stride(), t.dtype)
+        return t.stride(0)
+
+    def new(self, *shape):
+        return torch.empty(*shape, device=self.dev)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, device=self.dev)
+
+    def gemm_nt(self, A, W, bias=None, out=None):
+        """out[m][n] = sum_k A[m][k] W[n][k] (+ bias[n]);  K % 4 == 0."""
+        M, K = A.shape
+        N, K2 = W.shape
+        assert K == K2 and K % 4 == 0, (A.shape, W.shape)
+        out = self.new(M, N) if out is None else out
+        _lib.check(self.lib.gvx_train_gemm_nt(_p(A), self._ld(A), _p(W), self._ld(W), _p(out), self._ld(out), M, N, K, _p(bias), self.st))
+        return out
+
+    def transpose(self, X, pad_to: int = 4):
+        """X [R, C] (dense) -> [C, R_p] with R_p = R rounded up to a multiple of pad_to (zero filled)."""
+        X = X.contiguous()
+        R, Cc = X.shape
+        Rp = -(-R // pad_to) * pad_to
+        out = self.new(Cc, Rp)
+        _lib.check(self.lib.gvx_train_transpose(_p(X), Cc, _p(out), R, Cc, Rp, self.st))
+        return out
+
+    def mm_tn(self, A, Bm):
+        """A^T @ Bm for A [R, M], Bm [R, N] -> [M, N] (the weight-gradient form: both operands made row-contiguous in R)."""
+        return self.gemm_nt(self.transpose(A), self.transpose(Bm))
+
+    def colsum(self, X):
+        X = X.contiguous()
+        out = self.new(X.shape[1])
+        _lib.check(self.lib.gvx_train_colsum(_p(X), X.shape[0], X.shape[1], _p(out), self.st))
+        return out
+
+    def axpby(self, a, alpha=1.0, b=None, beta=1.0, out=None):
+        rows, cols = a.shape
+        out = self.new(rows, cols) if out is None else out
+        _lib.check(self.lib.gvx_train_axpby(_p(a), self._ld(a), float(alpha), _p(b), self._ld(b) if b is not None else 0, float(beta),
+                                            _p(out), self._ld(out), rows, cols, self.st))
+        return out
+
+    def pad_cols(self, A, Kp):
+        """[M, K] -> dense [M, Kp] with zero columns appended."""
+        out = self.zeros(A.shape[0], Kp)
+        self.axpby(A, out=out[:, :A.shape[1]])
+        return out
+
+    def lstm_cell_backward(self, dh_a, dh_b, dc_next, pre, c_prev, keep, scale, active=None, want_pass=False):
+        B, H4 = pre.shape
+        H = H4 // 4
+        dgates, dc_prev = self.new(B, H4), self.new(B, H)
+        dh_pass = self.new(B, H) if want_pass else None
+        _lib.check(self.lib.gvx_train_lstm_cell_backward(
+            _p(dh_a), self._ld(dh_a), _p(dh_b), self._ld(dh_b) if dh_b is not None else 0, _p(dc_next), _p(pre.contiguous()),
+            _p(c_prev.contiguous()), _p(keep), float(scale), _p(active), B, H, _p(dgates), _p(dc_prev), _p(dh_pass), self.st))
+        return dgates, dc_prev, dh_pass
+
+
+def _unblock(ops: _Ops, blocked: torch.Tensor, n_slots: int, B: int, K: int) -> torch.Tensor:
+    out = ops.new(n_slots, B, K)
+    _lib.check(ops.lib.gvx_train_unblock(_p(blocked), _p(out), n_slots, B, K, ops.st))
+    return out
+
+
+def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, torch.Tensor], tape: dict) -> Dict[str, torch.Tensor]:
+    """Gradients of loss = Tacotron2Loss(batch, outputs) w.r.t. every parameter (keys = the reference's state_dict names),
+    from the tape of ``Tacotron2._forward_train``."""
+    mc = model.model_config
+    dev = outputs["mel_outputs"].device
+    ops = _Ops(dev)
+    lib, st = ops.lib, ops.st
+    P_ = dict(model.named_parameters())
+    W = lambda name: P_[name].data
+    att = "decoder.attention_layer."
+    tok = batch["token_padded"].to(device=dev, dtype=torch.int64).contiguous()
+    tl = batch["token_lengths"].to(device=dev, dtype=torch.int64)
+    B, L = tok.shape
+    M, T = outputs["mel_outputs"].shape[1], outputs["mel_outputs"].shape[2]
+    A, D, E, Pn, a = mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.encoder_embedding_dim, mc.prenet_dim, mc.attention_dim
+    F_, kl = mc.attention_location_n_filters, mc.attention_location_kernel_size
+    g: Dict[str, torch.Tensor] = {}
+
+    # ---- criterion and Postnet
+    dmel_direct, dpost, dgate = loss_backward(batch, outputs)
+    dx, pg = convstack_train_backward(tape["postnet"], dpost, first_layer_wgrad_input=outputs["mel_outputs"])
+    g.update(pg)
+    dmel = ops.axpby(dmel_direct.reshape(B * M, T), 1.0, dpost.reshape(B * M, T), 1.0)
+    dmel = ops.axpby(dmel, 1.0, dx.reshape(B * M, T), 1.0).reshape(B, M, T)
+    # ---- projection: rows (t, b); [dmel | dgate | 0-pad] [T B, Mp] x [Wp ; Wg]
+    Mp = -(-(M + 1) // 4) * 4
+    dmg = ops.zeros(T * B, Mp)
+    dmg[:, :M] = dmel.permute(2, 0, 1).reshape(T * B, M)          # (torch: layout plumbing only)
+    dmg[:, M] = dgate.t().reshape(T * B)
+    hc = tape["hc_all"]                                           # [T+1, B, D+E] rows: slot t + 1 = [h_d(t) ; ctx(t)]
+    hc_t = hc[1:].reshape(T * B, D + E)
+    Wpg = ops.zeros(Mp, D + E)
+    Wpg[:M] = W("decoder.linear_projection.linear_layer.weight")
+    Wpg[M] = W("decoder.gate_layer.linear_layer.weight")[0]
+    dWpg = ops.mm_tn(dmg, hc_t)                                   # [Mp, D+E]
+    g["decoder.linear_projection.linear_layer.weight"], g["decoder.gate_layer.linear_layer.weight"] = dWpg[:M].contiguous(), dWpg[M:M + 1].contiguous()
+    db = ops.colsum(dmg)
+    g["decoder.linear_projection.linear_layer.bias"], g["decoder.gate_layer.linear_layer.bias"] = db[:M].contiguous(), db[M:M + 1].contiguous()
+    dhc_all = ops.gemm_nt(dmg, ops.transpose(Wpg)).reshape(T, B, D + E)       # d loss / d [h_d(t) ; ctx(t)] through the projection
+
+    # ---- operands of every step, hoisted: inputs and gate pre-activations of both cells, the attention queries
+    p2 = tape["p2"]                                               # [T+1, B, P]
+    ha = tape["h_a_all"]                                          # [T+1, B, A]  slot t + 1 = dropped h_a(t)
+    ctx_prev = hc[:T, :, D:]                                      # ctx(t-1), slot t
+    xa = torch.cat((p2[:T], ctx_prev), dim=2).reshape(T * B, Pn + E).contiguous()
+    ha_prev = ha[:T].reshape(T * B, A)
+    Wia, Wha = W("decoder.attention_rnn.weight_ih"), W("decoder.attention_rnn.weight_hh")
+    Wid, Whd = W("decoder.decoder_rnn.weight_ih"), W("decoder.decoder_rnn.weight_hh")
+    ba = ops.axpby(W("decoder.attention_rnn.bias_ih")[None, :], 1.0, W("decoder.attention_rnn.bias_hh")[None, :], 1.0)[0]
+    bd = ops.axpby(W("decoder.decoder_rnn.bias_ih")[None, :], 1.0, W("decoder.decoder_rnn.bias_hh")[None, :], 1.0)[0]
+    pre_a = ops.gemm_nt(xa, Wia, bias=ba)
+    pre_a = ops.axpby(pre_a, 1.0, ops.gemm_nt(ha_prev, Wha), 1.0).reshape(T, B, 4 * A)
+    xd = torch.cat((ha[1:], hc[1:, :, D:]), dim=2).reshape(T * B, A + E).contiguous()   # [h_a(t) ; ctx(t)]
+    hd_prev = hc[:T, :, :D].reshape(T * B, D).contiguous()
+    pre_d = ops.gemm_nt(xd, Wid, bias=bd)
+    pre_d = ops.axpby(pre_d, 1.0, ops.gemm_nt(hd_prev, Whd), 1.0).reshape(T, B, 4 * D)
+    wq, v = W(att + "query_layer.linear_layer.weight"), W(att + "v.linear_layer.weight")
+    lw, ld = W(att + "location_layer.location_conv.conv.weight").contiguous(), W(att + "location_layer.location_dense.linear_layer.weight")
+    wm = W(att + "memory_layer.linear_layer.weight")
+    q_all = ops.gemm_nt(ha[1:].reshape(T * B, A), wq).reshape(T, B, a)
+    Fp = -(-F_ // 4) * 4                                          # location filters padded to the GEMM's K granularity
+    ld_p = ops.pad_cols(ld, Fp)                                   # [a, Fp]
+    ldT = ops.transpose(ld)                                       # [F, a]
+    WiaT, WhaT, WidT, WhdT, wqT = ops.transpose(Wia), ops.transpose(Wha), ops.transpose(Wid), ops.transpose(Whd), ops.transpose(wq)
+    memory, pm = tape["memory"], tape["pm"]
+    w_all = outputs["alignments"].permute(1, 0, 2).contiguous()   # [T, B, L]
+    # cumulative weights BEFORE step t: wcum_prev[t] = sum_{s < t} w[s]; built with the axpby primitive, ascending like the forward
+    wcum_prev = ops.zeros(T, B, L)
+    for t in range(1, T):
+        ops.axpby(wcum_prev[t - 1], 1.0, w_all[t - 1], 1.0, out=wcum_prev[t])
+    w_prev_all = torch.cat((ops.zeros(1, B, L), w_all[:T - 1]), dim=0)
+    ka, kd = tape["att_keep"], tape["dec_keep"]
+    sa, sd_ = 1.0 / (1.0 - mc.p_attention_dropout), 1.0 / (1.0 - mc.p_decoder_dropout)
+    c_a, c_d = tape["c_a_all"], tape["c_d_all"]                   # [T+1, B, H]
+
+    # ---- back-propagation through the decoder loop
+    dga_all, dgd_all = ops.new(T, B, 4 * A), ops.new(T, B, 4 * D)
+    dq_all = ops.new(T, B, a)
+    dmemory, dpm = ops.zeros(B, L, E), ops.zeros(B, L, a)
+    dv_acc, dld_acc, dlw_acc = ops.zeros(B, a), ops.zeros(a, Fp), ops.zeros(B, F_ * 2 * kl)
+    dh_a_n, dc_a_n, dh_d_n, dc_d_n = ops.zeros(B, A), ops.zeros(B, A), ops.zeros(B, D), ops.zeros(B, D)
+    dctx_n, dw_n, G = ops.zeros(B, E), ops.zeros(B, L), ops.zeros(B, L)
+    dp2 = ops.zeros(T + 1, B, Pn)
+    locf, locf_p = ops.new(B * L, F_), ops.zeros(B * L, Fp)
+    du, de = ops.new(B * L, a), ops.new(B, L)
+    for t in reversed(range(T)):
+        dhc = dhc_all[t]
+        # decoder LSTM: dh_d = dhc[:, :D] + dh_d(next step's recurrence)
+        dgd, dc_d_n, _ = ops.lstm_cell_backward(dhc[:, :D], dh_d_n, dc_d_n, pre_d[t], c_d[t], kd[t], sd_)
+        dgd_all[t] = dgd
+        dxd = ops.gemm_nt(dgd, WidT)                              # [B, A + E]
+        dh_d_n = ops.gemm_nt(dgd, WhdT)
+        # attention: context gradient = projection part + decoder-cell input part + next step's attention-cell input part
+        dctx_sum = ops.new(B, E)
+        _lib.check(lib.gvx_train_attention_weights_backward(
+            _p(dhc[:, D:]), ops._ld(dhc), _p(dxd[:, A:]), ops._ld(dxd), _p(dctx_n), ops._ld(dctx_n), _p(dw_n), _p(G), _p(memory), _p(w_all[t]),
+            B, L, E, _p(dmemory), _p(de), _p(dctx_sum), st))
+        _lib.check(lib.gvx_train_location_conv_forward(_p(w_prev_all[t]), _p(wcum_prev[t]), _p(lw), B, L, F_, kl, _p(locf), st))
+        ops.axpby(locf, out=locf_p[:, :F_])
+        locd = ops.gemm_nt(locf_p, ld_p)                          # [B L, a]
+        _lib.check(lib.gvx_train_attention_energy_backward(_p(q_all[t]), _p(locd), _p(pm), _p(v), _p(de), B, L, a, _p(du), _p(dpm), _p(dq_all[t]),
+                                                           _p(dv_acc), st))
+        dld_acc = ops.axpby(dld_acc, 1.0, ops.mm_tn(du, locf_p), 1.0)          # [a, Fp] += du^T locf
+        dlocf = ops.gemm_nt(du, ldT)                              # [B L, F]
+        _lib.check(lib.gvx_train_location_conv_backward(_p(dlocf), _p(w_prev_all[t]), _p(wcum_prev[t]), _p(lw), B, L, F_, kl, _p(dw_n), _p(G),
+                                                        _p(dlw_acc), st))
+        # attention LSTM: dh_a = decoder-cell input part + next step's recurrence + query part
+        dh_a = ops.axpby(dxd[:, :A], 1.0, dh_a_n, 1.0)
+        dh_q = ops.gemm_nt(dq_all[t], wqT)                        # dq @ Wq
+        dga, dc_a_n, _ = ops.lstm_cell_backward(dh_a, dh_q, dc_a_n, pre_a[t], c_a[t], ka[t], sa)
+        dga_all[t] = dga
+        dxa = ops.gemm_nt(dga, WiaT)                              # [B, P + E]
+        dh_a_n = ops.gemm_nt(dga, WhaT)
+        ops.axpby(dxa[:, :Pn], out=dp2[t])
+        dctx_n = dxa[:, Pn:]
+    # ---- weight gradients of the loop, one product over all (t, b) rows each
+    dga2, dgd2 = dga_all.reshape(T * B, 4 * A), dgd_all.reshape(T * B, 4 * D)
+    g["decoder.attention_rnn.weight_ih"], g["decoder.attention_rnn.weight_hh"] = ops.mm_tn(dga2, xa), ops.mm_tn(dga2, ha_prev.contiguous())
+    g["decoder.attention_rnn.bias_ih"] = ops.colsum(dga2)
+    g["decoder.attention_rnn.bias_hh"] = g["decoder.attention_rnn.bias_ih"].clone()
+    g["decoder.decoder_rnn.weight_ih"], g["decoder.decoder_rnn.weight_hh"] = ops.mm_tn(dgd2, xd), ops.mm_tn(dgd2, hd_prev)
+    g["decoder.decoder_rnn.bias_ih"] = ops.colsum(dgd2)
+    g["decoder.decoder_rnn.bias_hh"] = g["decoder.decoder_rnn.bias_ih"].clone()
+    g[att + "query_layer.linear_layer.weight"] = ops.mm_tn(dq_all.reshape(T * B, a), ha[1:].reshape(T * B, A).contiguous())
+    g[att + "v.linear_layer.weight"] = ops.colsum(dv_acc)[None, :].contiguous()
+    g[att + "location_layer.location_dense.linear_layer.weight"] = dld_acc[:, :F_].contiguous()
+    g[att + "location_layer.location_conv.conv.weight"] = ops.colsum(dlw_acc).reshape(F_, 2, kl)
+    dpm2 = dpm.reshape(B * L, a)
+    g[att + "memory_layer.linear_layer.weight"] = ops.mm_tn(dpm2, memory.reshape(B * L, E))
+    dmemory = ops.axpby(dmemory.reshape(B * L, E), 1.0, ops.gemm_nt(dpm2, ops.transpose(wm)), 1.0).reshape(B, L, E)
+    # ---- Prenet (relu then dropout, twice; models/tts/tacotron2.py:140-144)
+    pk = tape["prenet_keep"]                                      # [2, T+1, B, P] uint8
+    p1 = tape["p1"]
+    w0, w1 = W("decoder.prenet.layers.0.linear_layer.weight"), W("decoder.prenet.layers.1.linear_layer.weight")
+    n_rows = (T + 1) * B
+    dz2 = ops.new(n_rows, Pn)
+    _lib.check(lib.gvx_train_relu_dropout_backward(_p(dp2), _p(p2.contiguous()), _p(pk[1].contiguous()), 2.0, n_rows * Pn, _p(dz2), st))
+    g["decoder.prenet.layers.1.linear_layer.weight"] = ops.mm_tn(dz2, p1.reshape(n_rows, Pn).contiguous())
+    dp1 = ops.gemm_nt(dz2, ops.transpose(w1))
+    dz1 = ops.new(n_rows, Pn)
+    _lib.check(lib.gvx_train_relu_dropout_backward(_p(dp1), _p(p1.contiguous()), _p(pk[0].contiguous()), 2.0, n_rows * Pn, _p(dz1), st))
+    g["decoder.prenet.layers.0.linear_layer.weight"] = ops.mm_tn(dz1, tape["frames"].reshape(n_rows, M).contiguous())
+    # ---- encoder BiLSTM, packed-sequence semantics (models/tts/tacotron2.py:239-245)
+    H = E // 2
+    x = tape["enc_conv_out"].permute(0, 2, 1).contiguous()        # [B, L, E]
+    c_enc = tape["enc_cell_states"]                               # [B, L, E] (forward direction in channels [0, H))
+    dx_enc = ops.zeros(B * L, E)
+    for d_, sfx in enumerate(("", "_reverse")):
+        w_ih, w_hh = W("encoder.lstm.weight_ih_l0" + sfx), W("encoder.lstm.weight_hh_l0" + sfx)
+        bsum = ops.axpby(W("encoder.lstm.bias_ih_l0" + sfx)[None, :], 1.0, W("encoder.lstm.bias_hh_l0" + sfx)[None, :], 1.0)[0]
+        xg = ops.gemm_nt(x.reshape(B * L, E), w_ih, bias=bsum).reshape(B, L, 4 * H)
+        w_hhT = ops.transpose(w_hh)
+        dg_pos = ops.zeros(B, L, 4 * H)                           # gate gradients filed under the POSITION they belong to
+        hprev_pos = ops.zeros(B, L, H)
+        dh, dc = ops.zeros(B, H), ops.zeros(B, H)
+        rows = torch.arange(B, device=dev)
+        mem_d, c_d_ = memory[:, :, d_ * H:(d_ + 1) * H], c_enc[:, :, d_ * H:(d_ + 1) * H]
+        dmem_d = dmemory[:, :, d_ * H:(d_ + 1) * H]
+        for s in reversed(range(L)):
+            active = (s < tl)
+            t_idx = torch.full((B,), s, dtype=torch.long, device=dev) if d_ == 0 else (tl - 1 - s).clamp(min=0)
+            p_idx = (t_idx - 1) if d_ == 0 else (t_idx + 1)       # position of the previous step's state
+            has_prev = active & (s > 0)
+            # (index gathers of rows: layout plumbing; the arithmetic is in the kernels)
+            h_prev = torch.where(has_prev[:, None], mem_d[rows, p_idx.clamp(0, L - 1)], torch.zeros((), device=dev)).contiguous()
+            c_prev = torch.where(has_prev[:, None], c_d_[rows, p_idx.clamp(0, L - 1)], torch.zeros((), device=dev)).contiguous()
+            pre = ops.axpby(xg[rows, t_idx].contiguous(), 1.0, ops.gemm_nt(h_prev, w_hh), 1.0)
+            dmem_rows = torch.where(active[:, None], dmem_d[rows, t_idx], torch.zeros((), device=dev)).contiguous()
+            act8 = active.to(torch.uint8).contiguous()
+            dgt, dc, dh_pass = ops.lstm_cell_backward(dh, dmem_rows, dc, pre, c_prev, None, 1.0, active=act8, want_pass=True)
+            dh = ops.axpby(ops.gemm_nt(dgt, w_hhT), 1.0, dh_pass, 1.0)   # inactive rows: dgt = 0, the state gradient passes through
+            sel = rows[active]
+            dg_pos[sel, t_idx[active]] = dgt[active]
+            hprev_pos[sel, t_idx[active]] = h_prev[active]
+        dg2 = dg_pos.reshape(B * L, 4 * H)
+        g["encoder.lstm.weight_ih_l0" + sfx] = ops.mm_tn(dg2, x.reshape(B * L, E))
+        g["encoder.lstm.weight_hh_l0" + sfx] = ops.mm_tn(dg2, hprev_pos.reshape(B * L, H))
+        g["encoder.lstm.bias_ih_l0" + sfx] = ops.colsum(dg2)
+        g["encoder.lstm.bias_hh_l0" + sfx] = g["encoder.lstm.bias_ih_l0" + sfx].clone()
+        dx_enc = ops.axpby(dx_enc, 1.0, ops.gemm_nt(dg2, ops.transpose(w_ih)), 1.0)
+    # ---- encoder convolution stack and embedding
+    dconv, eg = convstack_train_backward(tape["encoder"], dx_enc.reshape(B, L, E).permute(0, 2, 1).contiguous())
+    g.update(eg)
+    demb = torch.empty_like(W("embedding.weight"))
+    dtok = dconv.permute(0, 2, 1).contiguous()                    # [B, L, E]
+    _lib.check(lib.gvx_train_embedding_backward(_p(tok), _p(dtok), B * L, E, demb.shape[0], _p(demb), st))
+    g["embedding.weight"] = demb
+    return g
+
+
+def clip_grad_norm(grads: Dict[str, torch.Tensor], max_norm: float) -> Tuple[float, float]:
+    """torch.nn.utils.clip_grad_norm_ (models/tts/tacotron2.py:521): returns (total norm, scale to apply to every gradient)."""
+    lib = _lib.load()
+    any_g = next(iter(grads.values()))
+    acc = torch.zeros(1, dtype=torch.float64, device=any_g.device)
+    st = torch.cuda.current_stream(any_g.device).cuda_stream
+    for v in grads.values():
+        _lib.check(lib.gvx_train_sqnorm_accumulate(_p(v.contiguous()), v.numel(), _p(acc), st))
+    total = float(acc.sqrt().item())
+    coef = max_norm / (total + 1e-6)
+    return total, (coef if coef < 1.0 else 1.0)
+
+
+class Adam:
+    """torch.optim.Adam as the reference configures it (models/tts/tacotron2.py:506-513), one HIP kernel per tensor."""
+
+    def __init__(self, model, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
+        self.step_count = 0
+        self.state: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    def step(self, grads: Dict[str, torch.Tensor], grad_scale: float = 1.0) -> None:
+        lib = _lib.load()
+        self.step_count += 1
+        for name, p in self.model.named_parameters():
+            gk = grads[name].contiguous()
+            if name not in self.state:
+                self.state[name] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+            m, v = self.state[name]
+            _lib.check(lib.gvx_train_adam_step(_p(p.data), _p(gk), _p(m), _p(v), p.numel(), float(grad_scale), float(self.lr), float(self.wd),
+                                               float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count,
+                                               torch.cuda.current_stream(p.device).cuda_stream))
+            p.data.add_(0)   # bump the tensor version: the packed blob is re-built before the next forward

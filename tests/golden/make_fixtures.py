@@ -147,6 +147,8 @@ def make_train_case(case):
         drawn.append((keep.to(torch.uint8), out))
         return out
 
+    optimizer = model.get_optimizer()["optimizer"]   # torch.optim.Adam(lr, weight_decay of the config): models/tts/tacotron2.py:506-513
+    optimizer.zero_grad()
     taps = {}
     hook = model.decoder.register_forward_hook(lambda m, i, o: taps.__setitem__("dec_mel", o[0].detach().clone()))
     torch.manual_seed(case["mask_seed"])
@@ -164,7 +166,11 @@ def make_train_case(case):
     assert len(drawn) == ne + 2 + 2 * T + npn, len(drawn)
     enc, pre, steps, post = drawn[:ne], drawn[ne:ne + 2], drawn[ne + 2:ne + 2 + 2 * T], drawn[ne + 2 + 2 * T:]
     pack = lambda ms: np.packbits(np.stack([m.numpy().reshape(-1) for m in ms]), axis=1)
-    grads = {("grad." + k): v.grad.numpy() for k, v in model.named_parameters()}
+    grads = {("grad." + k): v.grad.numpy().copy() for k, v in model.named_parameters()}   # before clipping
+    # the rest of train_step (models/tts/tacotron2.py:521-522): clip_grad_norm_, Adam.step
+    grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), model.model_config.grad_clip_thresh).item()
+    optimizer.step()
+    after = {("after." + k): v.detach().numpy().copy() for k, v in model.named_parameters()}
     bn_stats = {("state." + k): v.detach().numpy() for k, v in model.state_dict().items() if "running_" in k}
     np.savez_compressed(
         os.path.join(HERE, "train_small.npz"),
@@ -183,7 +189,7 @@ def make_train_case(case):
         grad_gate_outputs=np.zeros(0, np.float32),
         grad_enc_conv_out=enc[-1][1].grad.numpy(),               # d loss / d (output of the encoder's convolution stack) [B, E, L]
         grad_post_out=post[-1][1].grad.numpy(),                  # d loss / d (Postnet output before the residual add)
-        **grads, **bn_stats,
+        grad_norm=np.float32(grad_norm), **grads, **bn_stats, **after,
     )
     print(f"train_small: loss {loss['loss'].item():.5f}  dropouts {len(drawn)}  |grad mel| max {dec_mel.grad.abs().max():.4e}")
 

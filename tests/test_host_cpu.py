@@ -54,8 +54,8 @@ def test_state_dict_layout_and_checkpoint_dict():
     assert torch.equal(m.get_checkpoint_statedicts(None)["model_statedict"]["embedding.weight"], ref["embedding.weight"])
     with pytest.raises(RuntimeError, match="MI355X"):
         m.forward({})  # CPU device: must fail loudly, never fall back
-    with pytest.raises(NotImplementedError):
-        m.train_step({}, {}, {})
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m.train_step({}, m.get_criterion(), {"optimizer": None})   # the training step exists, and it too runs on the GPU only
 
 
 def test_weight_generator_is_deterministic():

@@ -184,14 +184,15 @@ int gvx_tacotron2_loss(const float* mel_out, const float* mel_post_out, const fl
                        void* stream);
 
 /* =====================================================================================================
- * Training, first slice: the convolution layers of the encoder and Postnet stacks as the
+ * Training: the convolution layers of the encoder and Postnet stacks as the
  * reference runs them under .train() - nn.Conv1d + nn.BatchNorm1d with BATCH statistics + activation + F.dropout
  * (models/tts/tacotron2.py:149-199, :207-220, :234-235) - forward and backward, and the backward of Tacotron2Loss
  * (:598-615).  Parameters are taken in the reference's own layout (conv weight [Cout, Cin, k]); activations in its
  * [B, C, T] layout.  act: 0 none, 1 relu, 2 tanh.  keep: uint8 {0,1} [B, Cout, T] (the dropout's keep mask; NULL = no
  * dropout); kept values are scaled by 1 / (1 - p).  Channels must be multiples of 8, k odd.
  * `saved` carries what the backward needs (gvx_conv_train_saved_bytes); both buffers 256-byte aligned.
- * The LSTM / attention backward (BPTT) and the optimiser step are not built yet: Tacotron2.train_step still raises.
+ * Together with the BPTT primitives further down these make up Tacotron2.train_step of the host mirror
+ * (genvox_amd/tacotron2.py, genvox_amd/training.py), which is pinned to the reference's own train_step.
  * ===================================================================================================== */
 /* The rest of the training-mode FORWARD (models/tts/tacotron2.py:231-246, :333-363 under .train()): the encoder's BiLSTM on
  * the output of its training-mode convolution stack (conv_out [B, embed_dim, L], reference layout), and the teacher-forced

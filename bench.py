@@ -28,7 +28,7 @@ Rank 0 prints ONE JSON line.
                 same Prenet-mask seed bit for bit.
   extra         (N = 1) the other BASELINE configurations, each timed like the headline (warm-up, then K runs bracketed by
                 synchronize) with its own roofline fraction and CPU-oracle figure: c1_b1x568 (configs[0]), tf_b64x800,
-                ar_b64_1000, ar_b1_1000, postnet_b256x800, gl_60it_b256x800.
+                ar_b64_1000, ar_b1_1000, postnet_b256x800, train_step_b32x200, gl_60it_b256x800.
                 (N > 1) ar_b64_1000_per_rank: every rank decodes 64 rows autoregressively at the same time.
 """
 import argparse
@@ -338,7 +338,7 @@ def main():
     # ---- the other BASELINE configurations (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_extra:
         want = set(filter(None, args.only_extra.split(","))) or {"c1_b1x568", "tf_b64x800", "ar_b64_1000", "ar_b1_1000", "postnet_b256x800",
-                                                                  "gl_60it_b256x800"}
+                                                                  "train_step_b32x200", "gl_60it_b256x800"}
         with_cpu = not args.no_cpu_baseline
         extra = {"host_cpu": cpu_model, "cpu_threads": n_thr}
         if with_cpu:
@@ -418,6 +418,37 @@ def main():
                 e["cpu_baseline"] = {"frames_per_s": round(4 * T / cs, 1), "cores": n_thr, "kind": "port", "sample": f"oracle Postnet on 4 x {T} frames"}
             extra["postnet_b256x800"] = e
             del mel
+        if "train_step_b32x200" in want:   # the reference's train_step (forward, loss, backward, clip, Adam)
+            log("extra: training step, batch 32 x 200 frames")
+            Tt = 200
+            tb = {k: torch.from_numpy(v).to(dev) for k, v in gw.synthetic_inputs(B, L, Tt, tc.n_tokens, ac.n_mels, seed=3).items()}
+            sd_keep = {k: v.detach().clone() for k, v in model.state_dict().items()}   # the legs after this one use the original weights
+            opt = model.get_optimizer()
+            dt = timed(torch, lambda: model.train_step(tb, model.get_criterion(), opt), 1, 3)
+            model.check_status()
+            e = {"s_per_step": round(dt, 4), "mel_frames_per_s": round(B * Tt / dt, 1), "loss_after": round(model.loss_items["loss"], 4),
+                 "grad_norm": round(model.grad_norm_val, 4),
+                 "note": "first version: explicit backward on HIP primitives, ~20 small launches per decoder step from the host, blob re-packed on the host every step - correct (pinned to the reference's own train_step), not tuned"}
+            if with_cpu:
+                from oracle import train_ref
+                Bc, Lc, Tc2 = 4, 64, 24
+                cb = {k: torch.from_numpy(v) for k, v in gw.synthetic_inputs(Bc, Lc, Tc2, tc.n_tokens, ac.n_mels, seed=3).items()}
+                gen = torch.Generator().manual_seed(1)
+                bern = lambda shape, p: (torch.rand(shape, generator=gen) >= p).to(torch.uint8)
+                E_, A_, D_, P_, C_, n_ = mc.encoder_embedding_dim, mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.prenet_dim, mc.postnet_embedding_dim, mc.postnet_n_convolutions
+                cm = {"encoder": [bern((Bc, E_, Lc), 0.5) for _ in range(mc.encoder_n_convolutions)], "prenet": bern((2, Tc2 + 1, Bc, P_), 0.5),
+                      "attention_rnn": bern((Tc2, Bc, A_), 0.1), "decoder_rnn": bern((Tc2, Bc, D_), 0.1),
+                      "postnet": [bern((Bc, C_ if i < n_ - 1 else ac.n_mels, Tc2), 0.5) for i in range(n_)]}
+                c0 = time.perf_counter()
+                co, ct = train_ref.train_forward(sd_cpu, cb, cm, mc)
+                train_ref.train_backward(sd_cpu, cb, cm, mc, co, ct)
+                cs = time.perf_counter() - c0
+                e["cpu_baseline"] = {"mel_frames_per_s": round(Bc * Tc2 / cs, 1), "cores": n_thr, "kind": "port",
+                                     "sample": f"oracle train_forward + train_backward (explicit formulas, torch CPU), batch {Bc} x {Tc2} frames x {Lc} tokens, {cs:.1f} s"}
+            extra["train_step_b32x200"] = e
+            model.load_state_dict(sd_keep)
+            model.eval()
+            del tb
         if "gl_60it_b256x800" in want:
             from genvox_amd.audio import AudioProcessor
 

@@ -50,6 +50,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int n_tiles = (p.N + BN - 1) / BN;
     const int mt = blockIdx.x / n_tiles, nt = blockIdx.x % n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
+    // split-K: this workgroup's k range and partial output (the whole K and C itself when splitk == 1)
+    const int k_begin = p.splitk > 1 ? (int)blockIdx.y * p.kchunk : 0;
+    const int k_end = p.splitk > 1 ? min(p.K, k_begin + p.kchunk) : p.K;
+    float* const Cout = p.C + (p.splitk > 1 ? (long)blockIdx.y * p.c_split : 0);
 
     // global -> register staging assignments
     const int ld_row = tid >> 3, ld_c4 = tid & 7;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #define GEMM_LOAD_TILE(K0)                                                                                  \
     {                                                                                                       \
         const int k_ = (K0) + 4 * ld_c4;                                                                    \
-        const bool k_ok_ = k_ < p.K;                                                                        \
+        const bool k_ok_ = k_ < k_end;                                                                      \
         const long a_koff_ = (long)(k_ >> 3) * p.a_kblk + (k_ & 7);                                         \
         _Pragma("unroll") for (int i = 0; i < A_V4; ++i) {                                                  \
             const float4 v_ = *reinterpret_cast<const float4*>(a_ptr[i] + (k_ok_ ? a_koff_ : 0));           \
@@ -124,14 +128,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     // rows that do not exist read row 0 / weight row 0 (in bounds) and are zeroed by the select above
-    const int nkt = (p.K + BK - 1) / BK;
-    GEMM_LOAD_TILE(0)
+    const int nkt = (k_end - k_begin + BK - 1) / BK;
+    GEMM_LOAD_TILE(k_begin)
     GEMM_STORE_TILE(0)
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nkt; ++kt) {            // steady state: prefetch tile kt+1 while computing tile kt (no branches inside)
         const int cur = kt & 1;
-        GEMM_LOAD_TILE((kt + 1) * BK)
+        GEMM_LOAD_TILE(k_begin + (kt + 1) * BK)
         GEMM_COMPUTE_TILE(cur)
         GEMM_STORE_TILE(cur ^ 1)
         __syncthreads();
@@ -165,9 +169,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 else if (p.act == ACT_TANH) v = tanhf(v);
                 if (p.keep) v = p.keep[(long)m * p.keep_ld + n] ? 2.f * v : 0.f;
                 const long col = (long)(n >> 3) * p.c_nblk + (n & 7);
-                p.C[c_off + col] = live ? v : 0.f;
-                if (halo_front) p.C[c_off - halo_step + col] = 0.f;
-                if (halo_back) p.C[c_off + halo_step + col] = 0.f;
+                Cout[c_off + col] = live ? v : 0.f;
+                if (halo_front) Cout[c_off - halo_step + col] = 0.f;
+                if (halo_back) Cout[c_off + halo_step + col] = 0.f;
             }
         }
     }
@@ -196,7 +200,7 @@ template <int WR, int WC, int TM, int TN>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
     const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    gemm_f32_kernel<WR, WC, TM, TN><<<dim3(grid), dim3(256), lds_bytes_cfg<WR, WC, TM, TN>(), s>>>(p);
+    gemm_f32_kernel<WR, WC, TM, TN><<<dim3(grid, p.splitk > 1 ? p.splitk : 1), dim3(256), lds_bytes_cfg<WR, WC, TM, TN>(), s>>>(p);
     return hipGetLastError();
 }
 
@@ -210,6 +214,37 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     if (tiles128 < 384) return launch_cfg<2, 2, 1, 2>(p, s);
     return launch_cfg<2, 2, 2, 2>(p, s);
+}
+
+// out[m][n] = sum_s part[s][m][n] (+ bias[n]), splits added in index order
+__global__ void splitk_reduce_kernel(const float* part, int splitk, long MN, int N, const float* bias, float* out, long ldc) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
+        float v = part[i];
+        for (int s = 1; s < splitk; ++s) v += part[(long)s * MN + i];
+        const int n = (int)(i % N);
+        if (bias) v += bias[n];
+        out[(i / N) * ldc + n] = v;
+    }
+}
+
+hipError_t launch_gemm_splitk(const GemmParams& p0, int splitk, float* scratch, hipStream_t s) {
+    if (splitk <= 1) return launch_gemm(p0, s);
+    if (p0.act != ACT_NONE || p0.keep || p0.row_len || p0.c_halo || p0.c_nblk != 8 || p0.cmap.s1 != 0 || p0.cmap.R < p0.M || !scratch)
+        return hipErrorInvalidValue;   // plain row-major outputs only
+    GemmParams p = p0;
+    const int kc = ((p.K + splitk - 1) / splitk + BK - 1) / BK * BK;
+    p.splitk = (p.K + kc - 1) / kc;
+    p.kchunk = kc;
+    p.C = scratch; p.cmap = RowMap{p.M, 0, (long)p.N};
+    p.c_split = (long)p.M * p.N;
+    p.bias = nullptr;
+    hipError_t e = launch_gemm(p, s);
+    if (e != hipSuccess) return e;
+    const long MN = (long)p.M * p.N;
+    long blocks = (MN + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    splitk_reduce_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(scratch, p.splitk, MN, p.N, p0.bias, p0.C, p0.cmap.s0);
+    return hipGetLastError();
 }
 
 }  // namespace gvx

@@ -51,12 +51,18 @@ struct GemmParams {
     int M, N, K;                       // K % 4 == 0
     int act;
     // conv-output extras (rows grouped by cmap.R = frames per sequence):
+    // split-K (few output tiles, long K: the small-batch products of the training backward): grid.y = splitk workgroups per
+    // tile, split s sums k in [s * kchunk, (s + 1) * kchunk) and writes its partial tile at C + s * c_split; no bias /
+    // activation / mask then (launch_gemm_splitk adds the partials in split order and the bias)
+    int splitk = 1; int kchunk = 0; long c_split = 0;
     const int32_t* row_len = nullptr;  // [M / cmap.R] valid rows per group: rows at or past it are written as zeros
     int c_halo = 0;                    // > 0: C has c_halo halo rows before and after each group's cmap.R rows (C points at
                                        // the first interior row); the tile that owns an edge row also zeroes "its" halo row
                                        // (requires cmap.R >= c_halo)
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+// plain row-major C [M][N] (ldc) = A W^T (+ bias) with K split over `splitk` workgroups per tile; partials [splitk][M][N] in scratch
+hipError_t launch_gemm_splitk(const GemmParams& p, int splitk, float* scratch, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Skinny recurrent GEMM (batch rows <= 64): one workgroup = 32 packed output rows x all batch rows,

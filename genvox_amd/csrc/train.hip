@@ -593,14 +593,24 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
 extern "C" {
 
 // C[m][n] = sum_k A[m*lda + k] * W[n*ldw + k] (+ bias[n]);  K % 4 == 0
-int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K, const float* bias, void* stream) {
+int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K, const float* bias,
+                      float* scratch, size_t scratch_bytes, void* stream) {
     if (!A || !W || !C || M < 1 || N < 1 || K < 4 || (K & 3)) return tfail(GVX_ERR_INVALID_ARG, "gemm_nt: null argument or K not a positive multiple of 4");
     GemmParams g{};
     g.A = A; g.amap = RowMap{M, 0, lda};
     g.W = W; g.ldw = ldw;
     g.C = C; g.cmap = RowMap{M, 0, ldc};
     g.bias = bias; g.M = M; g.N = N; g.K = K; g.act = ACT_NONE;
-    TR_TRY(launch_gemm(g, (hipStream_t)stream));
+    // few output tiles and a long K (the per-step products of the backward: 32 rows x thousands of columns): split K over
+    // enough workgroups to fill the chip, partial tiles in the caller's scratch, added in split order (deterministic)
+    const long tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
+    int splitk = 1;
+    if (scratch && tiles < 128 && K >= 512) {
+        splitk = (int)((256 + tiles - 1) / tiles);
+        if (splitk > K / 128) splitk = K / 128;
+        while (splitk > 1 && (size_t)splitk * M * N * sizeof(float) > scratch_bytes) --splitk;
+    }
+    TR_TRY(launch_gemm_splitk(g, splitk, scratch, (hipStream_t)stream));
     return GVX_OK;
 }
 // dst[c][r] = src[r * ld_src + c] for r < rows (0 for rows <= r < rows_p);  dst rows are rows_p long

@@ -165,6 +165,7 @@ class _Ops:
         self.lib = _lib.load()
         self.dev = dev
         self.st = torch.cuda.current_stream(dev).cuda_stream
+        self.scratch = torch.empty(8 << 20, device=dev)   # 32 MB of split-K partial tiles for the small-batch products
 
     @staticmethod
     def _ld(t: torch.Tensor) -> int:
@@ -183,7 +184,8 @@ class _Ops:
         N, K2 = W.shape
         assert K == K2 and K % 4 == 0, (A.shape, W.shape)
         out = self.new(M, N) if out is None else out
-        _lib.check(self.lib.gvx_train_gemm_nt(_p(A), self._ld(A), _p(W), self._ld(W), _p(out), self._ld(out), M, N, K, _p(bias), self.st))
+        _lib.check(self.lib.gvx_train_gemm_nt(_p(A), self._ld(A), _p(W), self._ld(W), _p(out), self._ld(out), M, N, K, _p(bias),
+                                              _p(self.scratch), self.scratch.numel() * 4, self.st))
         return out
 
     def transpose(self, X, pad_to: int = 4):

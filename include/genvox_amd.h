@@ -242,7 +242,10 @@ int gvx_tacotron2_loss_backward(const float* mel_out, const float* mel_post_out,
 /* ---- Back-propagation through time: primitives the host mirror (genvox_amd/training.py) strings together exactly as
  * oracle/train_ref.py states the training step (the reference: loss.backward(), clip_grad_norm_, Adam.step,
  * models/tts/tacotron2.py:515-522).  Row-major fp32 with explicit leading dimensions; LSTM gates in torch order i, f, g, o. */
-int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K, const float* bias, void* stream);
+/* C[m][n] = sum_k A[m * lda + k] W[n * ldw + k] (+ bias[n]), K % 4 == 0.  scratch (may be NULL): device scratch for split-K
+ * partial tiles, used when the product has few output tiles and a long K. */
+int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K, const float* bias,
+                      float* scratch, size_t scratch_bytes, void* stream);
 int gvx_train_transpose(const float* src, long ld_src, float* dst, long rows, int cols, long rows_padded, void* stream);
 int gvx_train_colsum(const float* X, long rows, int C, float* out, void* stream);
 int gvx_train_axpby(const float* a, long lda, float alpha, const float* b, long ldb, float beta, float* y, long ldy, long rows, int cols, void* stream);

@@ -27,6 +27,17 @@ class gvx_weight_desc(C.Structure):
 
 _vp, _i, _sz, _f, _l = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_long
 
+
+class gvx_bptt_decoder_args(C.Structure):
+    """Argument block of gvx_train_decoder_bptt (include/genvox_amd.h)."""
+    _fields_ = ([(n, C.c_int32) for n in ("B", "L", "T", "A", "D", "E", "P", "a", "F", "kl")]
+                + [("att_scale", C.c_float), ("dec_scale", C.c_float)]
+                + [(n, C.c_void_p) for n in ("dhc_all", "pre_a", "pre_d", "c_a_all", "c_d_all", "att_keep", "dec_keep", "q_all", "ctx_all")]
+                + [("ctx_ts", C.c_int64), ("ctx_bs", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("w_all", "memory", "pm", "w_ih_a", "w_hh_a", "w_ih_d", "w_hh_d", "wq", "v", "loc_conv", "loc_dense",
+                                             "dga_all", "dgd_all", "dq_all", "dctx_all", "dpm", "dmemory", "dv", "dloc_dense", "dloc_conv")])
+
+
 # name -> (restype, argtypes); every symbol include/genvox_amd.h declares
 SIGNATURES = {
     "gvx_last_error": (C.c_char_p, []),
@@ -69,6 +80,10 @@ SIGNATURES = {
     "gvx_train_embedding_backward": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp]),
     "gvx_train_sqnorm_accumulate": (_i, [_vp, _l, _vp, _vp]),
     "gvx_train_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _i, _vp]),
+    "gvx_train_decoder_bptt_workspace_bytes": (_sz, [C.POINTER(gvx_bptt_decoder_args)]),
+    "gvx_train_decoder_bptt": (_i, [C.POINTER(gvx_bptt_decoder_args), _vp, _sz, _vp]),
+    "gvx_train_encoder_lstm_bptt_workspace_bytes": (_sz, [_i, _i]),
+    "gvx_train_encoder_lstm_bptt": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gvx_prenet_masks_generate": (_i, [_vp, _sz, C.c_uint64, _vp]),
     "gvx_stage_timing_enable": (_i, [_vp, _i]),
     "gvx_stage_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),

@@ -129,7 +129,7 @@ struct LocJob {
     float* loc_out;                         // [B][L][a]
     int B, L, a, kl, G;                     // G position chunks per row (0 = no location job in this launch)
 };
-enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_AR = 2 };  // kernel name only; same code
+enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_AR = 2, SK_TRAIN = 3 };  // kernel name only; same code (up to 4 jobs)
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc = nullptr);
 // teacher-forced step beside the persistent attention kernel: attention-LSTM (+ decoder-LSTM of the previous step) dealt to
 // 96 (224) workgroups of equal weight (skinny.hip); default layer sizes, B <= 32

@@ -46,10 +46,11 @@ constexpr int SK_WAVES = SK_NWAVES;
 constexpr int SK_THREADS = SK_WAVES * 64;
 
 struct SkinnyJobs {
-    SkinnyJob job[3];
+    SkinnyJob job[4];
     int njobs;
     int tiles0;   // tiles of job 0
     int tiles1;   // tiles of job 1
+    int tiles2;   // tiles of job 2 (only read when njobs == 4)
     int tiles;    // tiles of all jobs; blocks >= tiles are location-feature workgroups
     LocJob loc;
     int pa_layout;   // teacher-forced step beside the persistent attention kernel: 224 (96) workgroups, see skinny_body
@@ -200,7 +201,10 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         else { jsel = 1; tile = bid - 96; }
     } else if (jobs.njobs > 1 && tile >= jobs.tiles0) {
         jsel = 1; tile -= jobs.tiles0;
-        if (jobs.njobs > 2 && tile >= jobs.tiles1) { jsel = 2; tile -= jobs.tiles1; }
+        if (jobs.njobs > 2 && tile >= jobs.tiles1) {
+            jsel = 2; tile -= jobs.tiles1;
+            if (jobs.njobs > 3 && tile >= jobs.tiles2) { jsel = 3; tile -= jobs.tiles2; }
+        }
     }
     const bool has_x = XH && xt >= 0;   // workgroup-uniform
     const SkinnyJob& J = jobs.job[jsel];
@@ -719,6 +723,8 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_ker
 }
 // autoregressive launch C beside the resident attention kernel: the context of the step arrives inside the launch (deferred segment)
 __global__ __launch_bounds__(SK_THREADS) void ar_lstm_defer_kernel(SkinnyJobs jobs) { skinny_body<1, SK_DEPTH1, false, true>(jobs); }
+// training step, back-propagation through the decoder loop: dgates x transposed recurrent matrices as partial sums (mode 2 jobs, train.hip)
+__global__ __launch_bounds__(SK_THREADS) void train_bptt_products_kernel(SkinnyJobs jobs) { skinny_body<1, SK_DEPTH1>(jobs); }
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_step_kernel(SkinnyJobs jobs) { skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs); }
 
 static size_t skinny_lds(int MT) { return (size_t)(SK_WAVES * MT * 16 * 64 + MT * 32 * 8) * sizeof(float); }
@@ -746,6 +752,7 @@ hipError_t skinny_init() {
     if ((e = set_lds(decoder_lstm_step_pa192_kernel, 2)) != hipSuccess) return e;
     if ((e = set_lds(decoder_lstm_step_pa64_kernel, 2)) != hipSuccess) return e;
     if ((e = set_lds(ar_lstm_defer_kernel, 1)) != hipSuccess) return e;
+    if ((e = set_lds(train_bptt_products_kernel, 1)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
     return set_lds(encoder_lstm_step_kernel<2>, 2);
 }
@@ -758,8 +765,8 @@ hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStrea
         if ((att.att_dim + 31) / 32 > SK_WAVES) return hipErrorInvalidValue;
         SkinnyJobs js;
         js.njobs = dec ? 2 : 1;
-        js.job[0] = att; js.job[1] = dec ? *dec : att; js.job[2] = js.job[1];
-        js.tiles0 = 128; js.tiles1 = dec ? 128 : 0; js.tiles = js.tiles0 + js.tiles1;
+        js.job[0] = att; js.job[1] = dec ? *dec : att; js.job[2] = js.job[1]; js.job[3] = js.job[1];
+        js.tiles0 = 128; js.tiles1 = dec ? 128 : 0; js.tiles2 = 0; js.tiles = js.tiles0 + js.tiles1;
         js.loc = LocJob{};
         js.pa_layout = 2; js.rot = sk_rot();
         decoder_lstm_step_pa192_kernel<<<dim3(dec ? 192 : 64), dim3(SK_THREADS), skinny_lds(2), s>>>(js);
@@ -767,8 +774,8 @@ hipError_t launch_skinny_pa(const SkinnyJob& att, const SkinnyJob* dec, hipStrea
     }
     SkinnyJobs js;
     js.njobs = dec ? 2 : 1;
-    js.job[0] = att; js.job[1] = dec ? *dec : att; js.job[2] = js.job[1];
-    js.tiles0 = 128; js.tiles1 = dec ? 128 : 0; js.tiles = js.tiles0 + js.tiles1;
+    js.job[0] = att; js.job[1] = dec ? *dec : att; js.job[2] = js.job[1]; js.job[3] = js.job[1];
+    js.tiles0 = 128; js.tiles1 = dec ? 128 : 0; js.tiles2 = 0; js.tiles = js.tiles0 + js.tiles1;
     js.loc = LocJob{};
     js.pa_layout = 1; js.rot = sk_rot();
     if (depth == 6) decoder_lstm_step_pa_kernel<6><<<dim3(dec ? 224 : 96), dim3(SK_THREADS), skinny_pa_lds(), s>>>(js);
@@ -783,23 +790,24 @@ hipError_t launch_skinny_pa64(const SkinnyJob* jobs, int njobs, hipStream_t s) {
     js.pa_layout = 0;   // ordinary block -> (job, tile) mapping; one slab per attention-LSTM tile
     js.rot = sk_rot();
     js.loc = LocJob{};
-    for (int i = 0; i < 3; ++i) js.job[i] = jobs[i < njobs ? i : njobs - 1];
+    for (int i = 0; i < 4; ++i) js.job[i] = jobs[i < njobs ? i : njobs - 1];
     for (int i = 0; i < njobs; ++i)
         if (jobs[i].N != 4096 || jobs[i].B != jobs[0].B || jobs[i].B <= 32 || jobs[i].B > 64) return hipErrorInvalidValue;
-    js.tiles0 = 128; js.tiles1 = njobs > 1 ? 128 : 0; js.tiles = 128 * njobs;
+    js.tiles0 = 128; js.tiles1 = njobs > 1 ? 128 : 0; js.tiles2 = 0; js.tiles = 128 * njobs;
     decoder_lstm_step_pa64_kernel<<<dim3(js.tiles), dim3(SK_THREADS), skinny_lds(2), s>>>(js);
     return hipGetLastError();
 }
 
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc) {
-    if (njobs < 1 || njobs > 3) return hipErrorInvalidValue;
+    if (njobs < 1 || njobs > 4) return hipErrorInvalidValue;
     SkinnyJobs js;
     js.njobs = njobs;
     js.pa_layout = 0; js.rot = sk_rot();
-    for (int i = 0; i < 3; ++i) js.job[i] = jobs[i < njobs ? i : njobs - 1];
+    for (int i = 0; i < 4; ++i) js.job[i] = jobs[i < njobs ? i : njobs - 1];
     js.tiles0 = (jobs[0].N + 31) / 32;
     js.tiles1 = njobs > 1 ? (jobs[1].N + 31) / 32 : 0;
-    js.tiles = js.tiles0 + js.tiles1 + (njobs > 2 ? (jobs[2].N + 31) / 32 : 0);
+    js.tiles2 = njobs > 2 ? (jobs[2].N + 31) / 32 : 0;
+    js.tiles = js.tiles0 + js.tiles1 + js.tiles2 + (njobs > 3 ? (jobs[3].N + 31) / 32 : 0);
     const int B = jobs[0].B;
     for (int i = 1; i < njobs; ++i)
         if (jobs[i].B != B) return hipErrorInvalidValue;
@@ -816,6 +824,7 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
         extra = loc->B * loc->G;
     }
     const int MT = B > 32 ? 2 : 1;
+    if (kind == SK_TRAIN && MT != 1) return hipErrorInvalidValue;
     size_t lds = skinny_lds(MT);
     if (extra) {
         const size_t need = (size_t)loc_lds_floats(loc->L, loc->G, loc->kl) * sizeof(float);
@@ -831,6 +840,9 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
         if (kind == SK_DECODER && jobs[0].defer_seg) {
             if (B > 32 || extra) return hipErrorInvalidValue;
             decoder_lstm_drain_pa_kernel<<<grid, block, lds, s>>>(js);
+        } else if (kind == SK_TRAIN) {
+            if (extra) return hipErrorInvalidValue;
+            train_bptt_products_kernel<<<grid, block, lds, s>>>(js);
         } else if (kind == SK_DECODER) decoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
         else if (kind == SK_ENCODER) encoder_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
         else if (jobs[0].defer_seg) {

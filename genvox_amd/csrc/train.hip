@@ -14,6 +14,7 @@
 #include "gvx_kernels.h"
 
 #include <cstdio>
+#include <cstring>
 
 namespace gvx {
 namespace {
@@ -704,6 +705,651 @@ int gvx_train_adam_step(float* param, const float* grad, float* exp_avg, float* 
     const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, grad_scale, lr, weight_decay,
                        beta1, beta2, eps, bc1, bc2s);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Back-propagation through the decoder loop in ONE call (gvx_train_decoder_bptt): three launches per step, issued from
+// here - not ~20 primitives per step strung together by the host mirror (round 3, first version: 2.2 ms per step of
+// launch overhead and small-kernel time).  Step t, walking down from T - 1:
+//   A  bptt_attention_kernel  (G position chunks x B rows): gradient of the context -> attention weights -> energies ->
+//      query / processed memory / location layers, and through the location convolution into the previous and cumulative
+//      weights.  Everything of a row is local to its positions except a few sums over positions, which leave the kernel as
+//      per-chunk partials that their consumers add in chunk order (deterministic, no atomics).
+//   B  bptt_cells_kernel: attention-LSTM cell of step t and decoder-LSTM cell of step t - 1 backwards (the decoder cell of
+//      step t - 1 only needs the decoder cell of step t: the two recurrences overlap exactly like in the forward loop).
+//   C  the two products dgates x [W_ih | W_hh] on the weight-streaming skinny kernel of the forward path (skinny.hip,
+//      mode 2) with the matrices transposed and packed in MFMA-fragment order on the device at the start of the call; K
+//      is cut in two so that the default layer sizes give 256 equal tiles (48 + 80 row tiles x 2 K halves, 256 KB each).
+// The softmax term sum_l w_l dw_l is taken as  w . (dw_next + G) + dctx . ctx(t)  (ctx(t) = sum_l w_l memory_l is on the
+// tape): a chunk does not need the other chunks' dw.  The context path of the memory gradient, sum_t w_t (x) dctx_t, is one
+// kernel after the loop.  What is not on the recurrence - the Prenet columns of the attention LSTM, all weight gradients -
+// stays with the host mirror as whole-sequence GEMMs.
+// =====================================================================================================================
+namespace gvx {
+namespace {
+
+constexpr int BP_THREADS = 256;
+constexpr int BP_GMAX = 8;   // position chunks per batch row
+
+inline int bptt_chunks(int L) { int g = (L + 3) / 4; return g < 1 ? 1 : (g > BP_GMAX ? BP_GMAX : g); }
+inline int round32(int x) { return (x + 31) / 32 * 32; }
+
+struct BpttAttn {
+    int B, L, E, a, F, kl, G;
+    const float* dhc_ctx; long dhc_ld;        // d loss / d ctx(t) through the projection: row b at dhc_ctx + b * dhc_ld
+    const float* yd0; const float* yd1; int yd_ld, yd_ctx;   // decoder-cell products of step t (two K halves): context columns at yd_ctx
+    const float* ya0; const float* ya1; int ya_ld;           // attention-cell products of step t + 1 (nullptr at t = T - 1): context columns at 0
+    const float* ctx; long ctx_bs;            // ctx(t), row b at ctx + b * ctx_bs
+    const float* w; const float* w_prev; const float* wcum;   // alignments of step t, t - 1 (nullptr at t = 0), cumulative before t: [B][L]
+    const float* q;                           // [B][a] query of step t
+    const float* memory; const float* pm; const float* v; const float* lw; const float* ld;
+    const float* dw_in; const float* gc_in;   // [B][G][L] partials written by step t + 1
+    float* dw_out; float* gc_out;             // [B][G][L] partials of this step
+    float* dq_part;                           // [B][G][a]
+    float* dctx_out;                          // [B][E] (dctx_all[t])
+    float* dpm;                               // [B][L][a]  accumulated
+    float* dv_acc; float* dld_acc; float* dlw_acc;   // [B][G][a], [B][G][a][F], [B][G][F * 2 * kl]  accumulated
+};
+
+inline size_t bptt_attn_lds_floats(int L, int E, int a, int F, int kl, int G) {
+    const int CH = (L + G - 1) / G;
+    return (size_t)E + L + BP_THREADS + 2 * (CH + kl - 1) + (size_t)2 * kl * F + (size_t)a * (F + 1) + (size_t)CH * F + CH + (size_t)2 * CH * a +
+           (size_t)CH * F + (size_t)CH * 2 * kl + 8;
+}
+
+__global__ __launch_bounds__(BP_THREADS) void bptt_attention_kernel(BpttAttn p) {
+    extern __shared__ float sm[];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int L = p.L, E = p.E, a = p.a, F = p.F, kl = p.kl, G = p.G, pad = (kl - 1) / 2, LDF = F + 1;
+    const int CH = (L + G - 1) / G, l0 = g * CH;
+    const int n = max(0, min(L, l0 + CH) - l0);   // positions of this chunk (0: the chunk only passes its partial buffers on)
+    const int LW = CH + kl - 1;
+    float* dc = sm;                    // [E]
+    float* dwg = dc + E;               // [L]   dw_next + G of the whole row
+    float* red = dwg + L;              // [256]
+    float* win = red + BP_THREADS;     // [2][LW] previous / cumulative weights at positions l0 - pad ...
+    float* lws = win + 2 * LW;         // [2][kl][F]
+    float* lds_ = lws + 2 * kl * F;    // [a][F + 1]
+    float* locf = lds_ + a * LDF;      // [CH][F]
+    float* des = locf + CH * F;        // [CH]
+    float* du = des + CH;              // [CH][a]
+    float* dvt = du + CH * a;          // [CH][a]
+    float* dlocf = dvt + CH * a;       // [CH][F]
+    float* t1 = dlocf + CH * F;        // [CH][2][kl]
+
+    for (int e = tid; e < E; e += BP_THREADS) {
+        float v = p.dhc_ctx[(long)b * p.dhc_ld + e] + p.yd0[(long)b * p.yd_ld + p.yd_ctx + e] + p.yd1[(long)b * p.yd_ld + p.yd_ctx + e];
+        if (p.ya0) v += p.ya0[(long)b * p.ya_ld + e] + p.ya1[(long)b * p.ya_ld + e];
+        dc[e] = v;
+        if (g == 0) p.dctx_out[(long)b * E + e] = v;
+    }
+    for (int l = tid; l < L; l += BP_THREADS) {
+        float s = 0.f;
+        for (int gg = 0; gg < G; ++gg) s += p.dw_in[((long)b * G + gg) * L + l] + p.gc_in[((long)b * G + gg) * L + l];
+        dwg[l] = s;
+    }
+    for (int i = tid; i < 2 * LW; i += BP_THREADS) {
+        const int c = i / LW, ii = i - c * LW, l = l0 + ii - pad;
+        float v = 0.f;
+        if (l >= 0 && l < L) v = c == 0 ? (p.w_prev ? p.w_prev[(long)b * L + l] : 0.f) : p.wcum[(long)b * L + l];
+        win[i] = v;
+    }
+    for (int i = tid; i < 2 * kl * F; i += BP_THREADS) {   // lw [F][2][kl] -> [c][j][f]
+        const int f = i % F, cj = i / F;
+        lws[i] = p.lw[(long)f * 2 * kl + cj];
+    }
+    for (int i = tid; i < a * F; i += BP_THREADS) lds_[(i / F) * LDF + (i % F)] = p.ld[i];
+    __syncthreads();
+    // s = sum_l w_l dw_l = w . (dw_next + G) + dctx . ctx(t)
+    {
+        float part = 0.f;
+        for (int e = tid; e < E; e += BP_THREADS) part += dc[e] * p.ctx[(long)b * p.ctx_bs + e];
+        for (int l = tid; l < L; l += BP_THREADS) part += p.w[(long)b * L + l] * dwg[l];
+        red[tid] = part;
+        __syncthreads();
+        for (int o = BP_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    }
+    const float ssum = red[0];
+    // dw and de of the chunk's positions: one wave per position, lanes over the memory channels
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int li = wave; li < n; li += BP_THREADS / 64) {
+            const float* mrow = p.memory + ((long)b * L + l0 + li) * E;
+            float acc = 0.f;
+            for (int e = lane; e < E; e += 64) acc += dc[e] * mrow[e];
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+            if (lane == 0) des[li] = p.w[(long)b * L + l0 + li] * (acc + dwg[l0 + li] - ssum);
+        }
+    }
+    // location features of the chunk (recomputed): locf[l][f] = sum_{c,j} in_c[l + j - pad] lw[f][c][j]
+    for (int i = tid; i < n * F; i += BP_THREADS) {
+        const int li = i / F, f = i - li * F;
+        float acc = 0.f;
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < kl; ++j) acc += win[c * LW + li + j] * lws[(c * kl + j) * F + f];
+        locf[i] = acc;
+    }
+    __syncthreads();
+    // energies backwards: u = q + locf ld^T + pm, th = tanh(u), du = de v (1 - th^2)
+    for (int i = tid; i < n * a; i += BP_THREADS) {
+        const int li = i / a, d = i - li * a;
+        float locd = 0.f;
+        for (int f = 0; f < F; ++f) locd += locf[li * F + f] * lds_[d * LDF + f];
+        const long o = ((long)b * L + l0 + li) * a + d;
+        const float th = tanhf(p.q[(long)b * a + d] + locd + p.pm[o]);
+        const float e_ = des[li];
+        const float gq = e_ * p.v[d] * (1.f - th * th);
+        du[i] = gq;
+        dvt[i] = e_ * th;
+        p.dpm[o] += gq;
+    }
+    __syncthreads();
+    for (int d = tid; d < a; d += BP_THREADS) {
+        float sq = 0.f, sv = 0.f;
+        for (int li = 0; li < n; ++li) { sq += du[li * a + d]; sv += dvt[li * a + d]; }
+        p.dq_part[((long)b * G + g) * a + d] = sq;
+        p.dv_acc[((long)b * G + g) * a + d] += sv;
+    }
+    for (int i = tid; i < a * F; i += BP_THREADS) {   // d location_dense[d][f] += sum_l du[l][d] locf[l][f]
+        const int d = i / F, f = i - d * F;
+        float acc = 0.f;
+        for (int li = 0; li < n; ++li) acc += du[li * a + d] * locf[li * F + f];
+        p.dld_acc[((long)b * G + g) * a * F + i] += acc;
+    }
+    for (int i = tid; i < n * F; i += BP_THREADS) {   // dlocf[l][f] = sum_d du[l][d] ld[d][f]
+        const int li = i / F, f = i - li * F;
+        float acc = 0.f;
+        for (int d = 0; d < a; ++d) acc += du[li * a + d] * lds_[d * LDF + f];
+        dlocf[i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < n * 2 * kl; i += BP_THREADS) {   // t1[l][c][j] = sum_f dlocf[l][f] lw[f][c][j]
+        const int li = i / (2 * kl), cj = i - li * 2 * kl;
+        float acc = 0.f;
+        for (int f = 0; f < F; ++f) acc += dlocf[li * F + f] * lws[cj * F + f];
+        t1[i] = acc;
+    }
+    for (int i = tid; i < F * 2 * kl; i += BP_THREADS) {   // d location_conv[f][c][j] += sum_l dlocf[l][f] in_c[l + j - pad]
+        const int f = i / (2 * kl), cj = i - f * 2 * kl, c = cj / kl, j = cj - c * kl;
+        float acc = 0.f;
+        for (int li = 0; li < n; ++li) acc += dlocf[li * F + f] * win[c * LW + li + j];
+        p.dlw_acc[((long)b * G + g) * F * 2 * kl + i] += acc;
+    }
+    __syncthreads();
+    // d in_c[l'] = sum over the chunk's l of t1[l][c][l' - l + pad]: c = 0 -> previous weights (next step's dw_next),
+    // c = 1 -> cumulative weights (added to G for all earlier steps)
+    for (int i = tid; i < 2 * L; i += BP_THREADS) {
+        const int c = i / L, lt = i - c * L;
+        float acc = 0.f;
+        for (int li = 0; li < n; ++li) {
+            const int j = lt - (l0 + li) + pad;
+            if (j >= 0 && j < kl) acc += t1[(li * 2 + c) * kl + j];
+        }
+        const long o = ((long)b * G + g) * L + lt;
+        if (c == 0) p.dw_out[o] = acc;
+        else p.gc_out[o] = p.gc_in[o] + acc;
+    }
+}
+
+struct BpttCells {
+    int B, A, D, E, a, G;
+    // attention cell of step t (att == 0: skipped)
+    int att;
+    const float* yd0; const float* yd1; int yd_ld;      // decoder-cell products of step t: h_a columns at 0, h_d columns at A + E
+    const float* ya0; const float* ya1; int ya_ld;      // attention-cell products of step t + 1 (nullptr at t = T - 1): h_a columns at E
+    const float* dq_part; const float* wq;              // [B][G][a], [a][A]
+    const float* pre_a; const float* c_a; const uint8_t* keep_a; float scale_a;   // step t: [B][4A], [B][A], [B][A]
+    float* dc_a;                                        // [B][A] state
+    float* dga; float* xa_blk; float* dq_out;           // dga_all[t] [B][4A], blocked copy, dq_all[t] [B][a]
+    // decoder cell of step t - 1 (dec == 0: skipped)
+    int dec; int have_yd;                               // have_yd == 0: no later step (t - 1 = T - 1)
+    const float* dhc_hd; long dhc_ld;                   // dhc_all[t - 1], h_d columns at 0
+    const float* pre_d; const float* c_d; const uint8_t* keep_d; float scale_d;
+    float* dc_d;
+    float* dgd; float* xd_blk;
+};
+
+__device__ __forceinline__ void lstm_cell_bwd_one(float dh, float dcn, float pi, float pf, float pg, float po, float cp, float& gi, float& gf,
+                                                  float& gg_, float& go, float& dc_prev) {
+    const float ig = 1.f / (1.f + expf(-pi)), fg = 1.f / (1.f + expf(-pf)), gg = tanhf(pg), og = 1.f / (1.f + expf(-po));
+    const float c = fg * cp + ig * gg, tc = tanhf(c);
+    const float d_o = dh * tc;
+    const float dc = dh * og * (1.f - tc * tc) + dcn;
+    gi = dc * gg * ig * (1.f - ig);
+    gf = dc * cp * fg * (1.f - fg);
+    gg_ = dc * ig * (1.f - gg * gg);
+    go = d_o * og * (1.f - og);
+    dc_prev = dc * fg;
+}
+
+__global__ __launch_bounds__(BP_THREADS) void bptt_cells_kernel(BpttCells p) {
+    __shared__ float dq[256];
+    const int b = blockIdx.y, tid = threadIdx.x, j = blockIdx.x * BP_THREADS + tid;
+    const int A = p.A, D = p.D, B = p.B;
+    const bool att_block = p.att && (int)blockIdx.x * BP_THREADS < A;   // block-uniform
+    if (att_block) {
+        for (int d = tid; d < p.a; d += BP_THREADS) {
+            float s = 0.f;
+            for (int g = 0; g < p.G; ++g) s += p.dq_part[((long)b * p.G + g) * p.a + d];
+            dq[d] = s;
+            if (blockIdx.x == 0) p.dq_out[(long)b * p.a + d] = s;
+        }
+        __syncthreads();
+    }
+    if (j < A) {
+        if (!p.att) return;
+        float dh = p.yd0[(long)b * p.yd_ld + j] + p.yd1[(long)b * p.yd_ld + j];
+        if (p.ya0) dh += p.ya0[(long)b * p.ya_ld + p.E + j] + p.ya1[(long)b * p.ya_ld + p.E + j];
+        float hq = 0.f;
+        for (int d = 0; d < p.a; ++d) hq += dq[d] * p.wq[(long)d * A + j];
+        dh += hq;
+        dh = p.keep_a[(long)b * A + j] ? dh * p.scale_a : 0.f;
+        const float* pr = p.pre_a + (long)b * 4 * A;
+        float gi, gf, gg, go, dcp;
+        lstm_cell_bwd_one(dh, p.dc_a[(long)b * A + j], pr[j], pr[A + j], pr[2 * A + j], pr[3 * A + j], p.c_a[(long)b * A + j], gi, gf, gg, go, dcp);
+        p.dc_a[(long)b * A + j] = dcp;
+        const float gv[4] = {gi, gf, gg, go};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = q * A + j;
+            p.dga[(long)b * 4 * A + k] = gv[q];
+            p.xa_blk[(long)(k >> 3) * B * 8 + b * 8 + (k & 7)] = gv[q];
+        }
+    } else if (j < A + D) {
+        if (!p.dec) return;
+        const int jd = j - A;
+        float dh = p.dhc_hd[(long)b * p.dhc_ld + jd];
+        if (p.have_yd) dh += p.yd0[(long)b * p.yd_ld + A + p.E + jd] + p.yd1[(long)b * p.yd_ld + A + p.E + jd];
+        dh = p.keep_d[(long)b * D + jd] ? dh * p.scale_d : 0.f;
+        const float* pr = p.pre_d + (long)b * 4 * D;
+        float gi, gf, gg, go, dcp;
+        lstm_cell_bwd_one(dh, p.dc_d[(long)b * D + jd], pr[jd], pr[D + jd], pr[2 * D + jd], pr[3 * D + jd], p.c_d[(long)b * D + jd], gi, gf, gg, go, dcp);
+        p.dc_d[(long)b * D + jd] = dcp;
+        const float gv[4] = {gi, gf, gg, go};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = q * D + jd;
+            p.dgd[(long)b * 4 * D + k] = gv[q];
+            p.xd_blk[(long)(k >> 3) * B * 8 + b * 8 + (k & 7)] = gv[q];
+        }
+    }
+}
+
+// Transposed recurrent matrix in MFMA-fragment order: logical row n (< N, zero rows up to Np) = column col0 + n of
+// [W_ih | W_hh] ([K][Kin], [K][H]), logical column k = gate row k (torch order).  out [Np/32][K/8][64][4]
+__global__ void pack_transposed_frag_kernel(const float* w_ih, int Kin, const float* w_hh, int H, int col0, int N, int Np, int K, float* out) {
+    const long total = (long)(Np / 32) * (K / 8) * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long tk = i >> 6;
+        const int kg = (int)(tk % (K / 8)), tile = (int)(tk / (K / 8));
+        const int n = tile * 32 + (lane & 31), k0 = 8 * kg + 4 * (lane >> 5);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) {
+            const int col = col0 + n;
+            const float* src = col < Kin ? w_ih + col : w_hh + (col - Kin);
+            const long ld = col < Kin ? Kin : H;
+            v.x = src[(long)(k0 + 0) * ld]; v.y = src[(long)(k0 + 1) * ld]; v.z = src[(long)(k0 + 2) * ld]; v.w = src[(long)(k0 + 3) * ld];
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+// wcum[t][b][l] = sum_{s < t} w[s][b][l], added in ascending order like the forward loop does
+__global__ void cumulative_weights_kernel(const float* w, int T, long BL, float* wcum) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < BL; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) { wcum[(long)t * BL + i] = s; s += w[(long)t * BL + i]; }
+    }
+}
+
+// dmemory[b][l][e] = sum_t w[t][b][l] dctx[t][b][e]   (8 positions per workgroup)
+__global__ __launch_bounds__(BP_THREADS) void memory_context_grad_kernel(const float* w, const float* dctx, int T, int B, int L, int E, float* dmemory) {
+    const int b = blockIdx.y, l0 = blockIdx.x * 8, tid = threadIdx.x;
+    for (int e = tid; e < E; e += BP_THREADS) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) {
+            const float dv = dctx[((long)t * B + b) * E + e];
+            const float* wr = w + ((long)t * B + b) * L;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += wr[min(l0 + i, L - 1)] * dv;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (l0 + i < L) dmemory[((long)b * L + l0 + i) * E + e] = acc[i];
+    }
+}
+
+struct BpttPlan {   // float offsets into the workspace
+    size_t wa_t, wd_t, xa, xd, ya, yd, dc_a, dc_d, dwp, gcp, dqp, wcum, dv_acc, dld_acc, dlw_acc, total;
+    int Na, Nd, G;
+};
+BpttPlan bptt_plan(const gvx_bptt_decoder_args& a) {
+    BpttPlan p{};
+    p.Na = round32(a.E + a.A); p.Nd = round32(a.A + a.E + a.D); p.G = bptt_chunks(a.L);
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o += (floats + 63) / 64 * 64; return r; };
+    p.wa_t = take((size_t)p.Na * 4 * a.A);
+    p.wd_t = take((size_t)p.Nd * 4 * a.D);
+    p.xa = take((size_t)a.B * 4 * a.A);
+    p.xd = take((size_t)a.B * 4 * a.D);
+    p.ya = take((size_t)2 * a.B * p.Na);
+    p.yd = take((size_t)2 * a.B * p.Nd);
+    p.dc_a = take((size_t)a.B * a.A);
+    p.dc_d = take((size_t)a.B * a.D);
+    p.dwp = take((size_t)2 * a.B * p.G * a.L);
+    p.gcp = take((size_t)2 * a.B * p.G * a.L);
+    p.dqp = take((size_t)a.B * p.G * a.a);
+    p.wcum = take((size_t)a.T * a.B * a.L);
+    p.dv_acc = take((size_t)a.B * p.G * a.a);
+    p.dld_acc = take((size_t)a.B * p.G * a.a * a.F);
+    p.dlw_acc = take((size_t)a.B * p.G * a.F * 2 * a.kl);
+    p.total = o;
+    return p;
+}
+
+int check_bptt_args(const gvx_bptt_decoder_args* a) {
+    if (!a) return tfail(GVX_ERR_INVALID_ARG, "decoder_bptt: null argument block");
+    if (a->B < 1 || a->B > 32 || a->L < 1 || a->T < 1) return tfail(GVX_ERR_UNSUPPORTED, "decoder_bptt: 1 <= B <= 32, L >= 1, T >= 1");
+    if (a->A < 8 || a->D < 8 || (a->A % 8) || (a->D % 8) || (a->E % 8) || (a->P % 4) || a->a < 1 || a->a > 256 || a->F < 1 || a->F > 32 || a->kl < 1 || !(a->kl & 1))
+        return tfail(GVX_ERR_UNSUPPORTED, "decoder_bptt: unsupported layer sizes");
+    const void* need[] = {a->dhc_all, a->pre_a, a->pre_d, a->c_a_all, a->c_d_all, a->att_keep, a->dec_keep, a->q_all, a->ctx_all, a->w_all, a->memory, a->pm,
+                          a->w_ih_a, a->w_hh_a, a->w_ih_d, a->w_hh_d, a->wq, a->v, a->loc_conv, a->loc_dense, a->dga_all, a->dgd_all, a->dq_all,
+                          a->dctx_all, a->dpm, a->dmemory, a->dv, a->dloc_dense, a->dloc_conv};
+    for (const void* q : need)
+        if (!q) return tfail(GVX_ERR_INVALID_ARG, "decoder_bptt: null pointer in the argument block");
+    const size_t lds = bptt_attn_lds_floats(a->L, a->E, a->a, a->F, a->kl, bptt_chunks(a->L)) * sizeof(float);
+    if (lds > 160 * 1024) return tfail(GVX_ERR_UNSUPPORTED, "decoder_bptt: a row's attention chunk does not fit the LDS (L or E too large)");
+    return GVX_OK;
+}
+
+}  // namespace
+}  // namespace gvx
+
+extern "C" {
+
+size_t gvx_train_decoder_bptt_workspace_bytes(const gvx_bptt_decoder_args* a) {
+    if (check_bptt_args(a) != GVX_OK) return 0;
+    return bptt_plan(*a).total * sizeof(float);
+}
+
+int gvx_train_decoder_bptt(const gvx_bptt_decoder_args* ap, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_bptt_args(ap);
+    if (rc != GVX_OK) return rc;
+    const gvx_bptt_decoder_args& a = *ap;
+    const BpttPlan pl = bptt_plan(a);
+    if (!workspace || workspace_bytes < pl.total * sizeof(float)) return tfail(GVX_ERR_WORKSPACE, "decoder_bptt: workspace too small");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return tfail(GVX_ERR_WORKSPACE, "decoder_bptt: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = reinterpret_cast<float*>(workspace);
+    const int B = a.B, L = a.L, T = a.T, A = a.A, D = a.D, E = a.E, P = a.P, G = pl.G, Na = pl.Na, Nd = pl.Nd;
+    const int Ka = 4 * A, Kd = 4 * D;
+    static bool lds_set = false;
+    if (!lds_set) {
+        TR_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bptt_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_set = true;
+    }
+    const size_t lds_attn = bptt_attn_lds_floats(L, E, a.a, a.F, a.kl, G) * sizeof(float);
+
+    // ---- before the loop: transposed matrices in fragment order, cumulative weights, cleared state and accumulators
+    float* wa_t = ws + pl.wa_t; float* wd_t = ws + pl.wd_t;
+    hipLaunchKernelGGL(pack_transposed_frag_kernel, dim3(blocks_for((long)(Na / 32) * (Ka / 8) * 64)), dim3(256), 0, s, a.w_ih_a, P + E, a.w_hh_a, A, P,
+                       E + A, Na, Ka, wa_t);
+    hipLaunchKernelGGL(pack_transposed_frag_kernel, dim3(blocks_for((long)(Nd / 32) * (Kd / 8) * 64)), dim3(256), 0, s, a.w_ih_d, A + E, a.w_hh_d, D, 0,
+                       A + E + D, Nd, Kd, wd_t);
+    float* wcum = ws + pl.wcum;
+    hipLaunchKernelGGL(cumulative_weights_kernel, dim3(blocks_for((long)B * L)), dim3(256), 0, s, a.w_all, T, (long)B * L, wcum);
+    TR_TRY(hipMemsetAsync(ws + pl.dc_a, 0, (pl.dqp - pl.dc_a) * sizeof(float), s));               // dc_a, dc_d, dw / G partials (both parities)
+    TR_TRY(hipMemsetAsync(ws + pl.dv_acc, 0, (pl.total - pl.dv_acc) * sizeof(float), s));         // dv, dld, dlw accumulators
+    TR_TRY(hipMemsetAsync(a.dpm, 0, (size_t)B * L * a.a * sizeof(float), s));
+    float* ya0 = ws + pl.ya; float* ya1 = ya0 + (size_t)B * Na;
+    float* yd0 = ws + pl.yd; float* yd1 = yd0 + (size_t)B * Nd;
+    float* xa = ws + pl.xa; float* xd = ws + pl.xd;
+    const size_t part = (size_t)B * G * L;
+
+    // ---- slot t = T ... 0: attention chain of step t (t < T) and decoder cell of step t - 1 (t > 0)
+    for (int t = T; t >= 0; --t) {
+        const bool att = t < T, dec = t > 0;
+        const int par = t & 1;   // partial buffers: step t reads parity (t + 1) & 1, writes parity t & 1
+        if (att) {
+            BpttAttn q{};
+            q.B = B; q.L = L; q.E = E; q.a = a.a; q.F = a.F; q.kl = a.kl; q.G = G;
+            q.dhc_ctx = a.dhc_all + (size_t)t * B * (D + E) + D; q.dhc_ld = D + E;
+            q.yd0 = yd0; q.yd1 = yd1; q.yd_ld = Nd; q.yd_ctx = A;
+            q.ya0 = t < T - 1 ? ya0 : nullptr; q.ya1 = ya1; q.ya_ld = Na;
+            q.ctx = a.ctx_all + (long)t * (long)a.ctx_ts; q.ctx_bs = (long)a.ctx_bs;
+            q.w = a.w_all + (size_t)t * B * L;
+            q.w_prev = t > 0 ? a.w_all + (size_t)(t - 1) * B * L : nullptr;
+            q.wcum = wcum + (size_t)t * B * L;
+            q.q = a.q_all + (size_t)t * B * a.a;
+            q.memory = a.memory; q.pm = a.pm; q.v = a.v; q.lw = a.loc_conv; q.ld = a.loc_dense;
+            q.dw_in = ws + pl.dwp + (size_t)(par ^ 1) * part; q.gc_in = ws + pl.gcp + (size_t)(par ^ 1) * part;
+            q.dw_out = ws + pl.dwp + (size_t)par * part; q.gc_out = ws + pl.gcp + (size_t)par * part;
+            q.dq_part = ws + pl.dqp;
+            q.dctx_out = a.dctx_all + (size_t)t * B * E;
+            q.dpm = a.dpm; q.dv_acc = ws + pl.dv_acc; q.dld_acc = ws + pl.dld_acc; q.dlw_acc = ws + pl.dlw_acc;
+            hipLaunchKernelGGL(bptt_attention_kernel, dim3(G, B), dim3(BP_THREADS), lds_attn, s, q);
+        }
+        {
+            BpttCells c{};
+            c.B = B; c.A = A; c.D = D; c.E = E; c.a = a.a; c.G = G;
+            c.att = att ? 1 : 0; c.dec = dec ? 1 : 0;
+            c.yd0 = yd0; c.yd1 = yd1; c.yd_ld = Nd;
+            c.ya0 = t < T - 1 ? ya0 : nullptr; c.ya1 = ya1; c.ya_ld = Na;
+            c.dq_part = ws + pl.dqp; c.wq = a.wq;
+            c.dc_a = ws + pl.dc_a; c.xa_blk = xa; c.scale_a = a.att_scale;
+            if (att) {
+                c.pre_a = a.pre_a + (size_t)t * B * Ka; c.c_a = a.c_a_all + (size_t)t * B * A; c.keep_a = a.att_keep + (size_t)t * B * A;
+                c.dga = a.dga_all + (size_t)t * B * Ka; c.dq_out = a.dq_all + (size_t)t * B * a.a;
+            }
+            c.have_yd = t < T ? 1 : 0;
+            c.dc_d = ws + pl.dc_d; c.xd_blk = xd; c.scale_d = a.dec_scale;
+            if (dec) {
+                c.dhc_hd = a.dhc_all + (size_t)(t - 1) * B * (D + E); c.dhc_ld = D + E;
+                c.pre_d = a.pre_d + (size_t)(t - 1) * B * Kd; c.c_d = a.c_d_all + (size_t)(t - 1) * B * D; c.keep_d = a.dec_keep + (size_t)(t - 1) * B * D;
+                c.dgd = a.dgd_all + (size_t)(t - 1) * B * Kd;
+            }
+            hipLaunchKernelGGL(bptt_cells_kernel, dim3((A + D + BP_THREADS - 1) / BP_THREADS, B), dim3(BP_THREADS), 0, s, c);
+        }
+        if (t == 0) break;   // the products of step 0's attention cell feed nothing on the recurrence
+        {
+            SkinnyJob jobs[4];
+            std::memset(jobs, 0, sizeof jobs);
+            int nj = 0;
+            auto add = [&](const float* wt, const float* x, int K, int N, float* y0, float* y1) {
+                const int nkg = K / 8, h0 = (nkg / 2 + 0), h1 = nkg - h0;
+                const int kg0[2] = {0, h0}, nk[2] = {h0, h1};
+                float* ys[2] = {y0, y1};
+                for (int hh = 0; hh < 2; ++hh) {
+                    SkinnyJob& J = jobs[nj++];
+                    J.Wp = wt; J.N = N; J.nkg = nk[hh]; J.kg0 = kg0[hh]; J.nkg_w = nkg; J.mode = 2; J.B = B;
+                    J.x[0] = XSeg{x + (size_t)kg0[hh] * B * 8, nk[hh] * 8};
+                    J.y = ys[hh];
+                }
+            };
+            if (att) add(wa_t, xa, Ka, Na, ya0, ya1);
+            add(wd_t, xd, Kd, Nd, yd0, yd1);
+            TR_TRY(launch_skinny(jobs, nj, SK_TRAIN, s));
+        }
+    }
+    TR_TRY(hipGetLastError());
+    // ---- after the loop: per-chunk accumulators summed in (row, chunk) order; context path of the memory gradient
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((a.a + 31) / 32), dim3(256), 0, s, ws + pl.dv_acc, (const float*)nullptr, (long)B * G, a.a, a.dv, (float*)nullptr);
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((a.a * a.F + 31) / 32), dim3(256), 0, s, ws + pl.dld_acc, (const float*)nullptr, (long)B * G, a.a * a.F,
+                       a.dloc_dense, (float*)nullptr);
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((a.F * 2 * a.kl + 31) / 32), dim3(256), 0, s, ws + pl.dlw_acc, (const float*)nullptr, (long)B * G,
+                       a.F * 2 * a.kl, a.dloc_conv, (float*)nullptr);
+    hipLaunchKernelGGL(memory_context_grad_kernel, dim3((L + 7) / 8, B), dim3(BP_THREADS), 0, s, a.w_all, a.dctx_all, T, B, L, E, a.dmemory);
+    TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Back-propagation through the encoder BiLSTM in one call (gvx_train_encoder_lstm_bptt): one launch per time step for both
+// directions, packed-sequence semantics as in the forward (a row takes part in step s while s < its length; the reverse
+// direction walks each row from its own last token).  Workgroup = (4 hidden units, direction); thread = (batch row, lane
+// r of 8) - the 8 lanes of a row split the K of every dot product and combine with DPP-free shuffles.  Launch s first
+// finishes dh(s) = dgates(s + 1) W_hh + pass-through for its units (the previous launch wrote dgates(s + 1)), recomputes
+// the gate pre-activations from the tape (x-projection + h_prev W_hh^T) and runs the cell backwards.
+// =====================================================================================================================
+namespace gvx {
+namespace {
+
+constexpr int EB_UJ = 4;   // hidden units per workgroup
+
+struct EncBptt {
+    int B, L, H, s;
+    const float* xg;         // [2][B][L][4H]  W_ih x + b_ih + b_hh per direction, torch gate order
+    const float* memory;     // [B][L][2H]     BiLSTM outputs (forward direction in channels [0, H))
+    const float* c_enc;      // [B][L][2H]     cell states
+    const float* dmemory;    // [B][L][2H]     d loss / d memory
+    const float* w_hh;       // [2][4H][H]
+    const float* w_hh_t;     // [2][H][4H]
+    const int32_t* lengths;  // [B]
+    const float* dg_in; const float* dpass_in;   // [2][B][4H], [2][B][H] written by step s + 1
+    float* dg_out; float* dpass_out;
+    float* dc;               // [2][B][H] state
+    float* dg_pos;           // [2][B][L][4H]  gate gradients filed under the position they belong to (zeros elsewhere)
+    float* hprev_pos;        // [2][B][L][H]   the previous hidden state of that position
+};
+
+__global__ __launch_bounds__(256) void encoder_bptt_step_kernel(EncBptt p) {
+    extern __shared__ float sm[];
+    const int H = p.H, H4 = 4 * H, L = p.L, B = p.B;
+    const int dir = blockIdx.y, j0 = blockIdx.x * EB_UJ, tid = threadIdx.x;
+    float* wcol = sm;                    // [UJ][4H]  column j of W_hh = row j of its transpose
+    float* wrow = sm + EB_UJ * H4;       // [4][UJ][H] rows (q H + j) of W_hh
+    const float* whh = p.w_hh + (size_t)dir * H4 * H;
+    const float* whht = p.w_hh_t + (size_t)dir * H * H4;
+    for (int i = tid; i < EB_UJ * H4; i += 256) { const int jl = i / H4, n = i - jl * H4; wcol[i] = j0 + jl < H ? whht[(size_t)(j0 + jl) * H4 + n] : 0.f; }
+    for (int i = tid; i < 4 * EB_UJ * H; i += 256) {
+        const int k = i % H, qj = i / H, jl = qj % EB_UJ, q = qj / EB_UJ;
+        wrow[i] = j0 + jl < H ? whh[((size_t)q * H + j0 + jl) * H + k] : 0.f;
+    }
+    __syncthreads();
+    const int r = tid & 7;
+    for (int b = tid >> 3; b < B; b += 32) {
+        const int len = p.lengths[b];
+        const bool active = p.s < len;
+        const int t_idx = dir == 0 ? p.s : max(len - 1 - p.s, 0);
+        const int p_idx = dir == 0 ? t_idx - 1 : t_idx + 1;
+        const bool has_prev = active && p.s > 0;
+        const float* hp = p.memory + ((size_t)b * L + min(max(p_idx, 0), L - 1)) * 2 * H + dir * H;
+        const float* dgi = p.dg_in + ((size_t)dir * B + b) * H4;
+        float my_dh = 0.f, my_pre[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jl = 0; jl < EB_UJ; ++jl) {
+            float sdh = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int n = r; n < H4; n += 8) sdh += dgi[n] * wcol[jl * H4 + n];
+            if (has_prev)
+                for (int k = r; k < H; k += 8) {
+                    const float hv = hp[k];
+                    s0 += hv * wrow[(0 * EB_UJ + jl) * H + k]; s1 += hv * wrow[(1 * EB_UJ + jl) * H + k];
+                    s2 += hv * wrow[(2 * EB_UJ + jl) * H + k]; s3 += hv * wrow[(3 * EB_UJ + jl) * H + k];
+                }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                sdh += __shfl_xor(sdh, o, 64); s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64); s3 += __shfl_xor(s3, o, 64);
+            }
+            if (r == jl) { my_dh = sdh; my_pre[0] = s0; my_pre[1] = s1; my_pre[2] = s2; my_pre[3] = s3; }
+        }
+        const int j = j0 + r;
+        if (r < EB_UJ && j < H) {
+            const size_t sj = ((size_t)dir * B + b) * H + j;
+            float dh = my_dh + p.dpass_in[sj];
+            if (active) dh += p.dmemory[((size_t)b * L + t_idx) * 2 * H + dir * H + j];
+            float* dgo = p.dg_out + ((size_t)dir * B + b) * H4;
+            if (!active) {
+                dgo[j] = dgo[H + j] = dgo[2 * H + j] = dgo[3 * H + j] = 0.f;
+                p.dpass_out[sj] = dh;   // (dc stays)
+            } else {
+                const float* xg = p.xg + (((size_t)dir * B + b) * L + t_idx) * H4;
+                const float cp = has_prev ? p.c_enc[((size_t)b * L + p_idx) * 2 * H + dir * H + j] : 0.f;
+                float gi, gf, gg, go, dcp;
+                lstm_cell_bwd_one(dh, p.dc[sj], xg[j] + my_pre[0], xg[H + j] + my_pre[1], xg[2 * H + j] + my_pre[2], xg[3 * H + j] + my_pre[3], cp,
+                                  gi, gf, gg, go, dcp);
+                p.dc[sj] = dcp;
+                p.dpass_out[sj] = 0.f;
+                dgo[j] = gi; dgo[H + j] = gf; dgo[2 * H + j] = gg; dgo[3 * H + j] = go;
+                float* dgp = p.dg_pos + (((size_t)dir * B + b) * L + t_idx) * H4;
+                dgp[j] = gi; dgp[H + j] = gf; dgp[2 * H + j] = gg; dgp[3 * H + j] = go;
+                p.hprev_pos[(((size_t)dir * B + b) * L + t_idx) * H + j] = has_prev ? hp[j] : 0.f;
+            }
+        }
+    }
+}
+
+// dst[d][c][r] = src[d][r][c]
+__global__ void transpose_batched_kernel(const float* src, float* dst, int n, int rows, int cols) {
+    const long per = (long)rows * cols, total = per * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long d = i / per, rc = i - d * per;
+        const int c = (int)(rc / rows), r = (int)(rc - (long)c * rows);
+        dst[i] = src[d * per + (long)r * cols + c];
+    }
+}
+
+struct EncBpttPlan { size_t wt, dg, dpass, dc, total; };
+EncBpttPlan enc_bptt_plan(int B, int H) {
+    EncBpttPlan p{};
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o += (floats + 63) / 64 * 64; return r; };
+    p.wt = take((size_t)2 * H * 4 * H);
+    p.dg = take((size_t)2 * 2 * B * 4 * H);      // two parities
+    p.dpass = take((size_t)2 * 2 * B * H);
+    p.dc = take((size_t)2 * B * H);
+    p.total = o;
+    return p;
+}
+
+}  // namespace
+}  // namespace gvx
+
+extern "C" {
+
+size_t gvx_train_encoder_lstm_bptt_workspace_bytes(int B, int H) {
+    if (B < 1 || H < 1) return 0;
+    return enc_bptt_plan(B, H).total * sizeof(float);
+}
+
+int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const float* cell_states, const float* dmemory, const float* w_hh,
+                                const int32_t* lengths, int B, int L, int H, float* dg_pos, float* hprev_pos, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (!xg || !memory || !cell_states || !dmemory || !w_hh || !lengths || !dg_pos || !hprev_pos || !workspace)
+        return tfail(GVX_ERR_INVALID_ARG, "encoder_lstm_bptt: null argument");
+    if (B < 1 || L < 1 || H < 8 || (H % 8)) return tfail(GVX_ERR_UNSUPPORTED, "encoder_lstm_bptt: B, L >= 1, H a positive multiple of 8");
+    const EncBpttPlan pl = enc_bptt_plan(B, H);
+    if (workspace_bytes < pl.total * sizeof(float)) return tfail(GVX_ERR_WORKSPACE, "encoder_lstm_bptt: workspace too small");
+    const size_t lds = (size_t)(EB_UJ * 4 * H * 2) * sizeof(float);
+    if (lds > 160 * 1024) return tfail(GVX_ERR_UNSUPPORTED, "encoder_lstm_bptt: H too large for the LDS");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = reinterpret_cast<float*>(workspace);
+    static bool lds_set = false;
+    if (!lds_set) {
+        TR_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_bptt_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_set = true;
+    }
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(blocks_for((long)2 * 4 * H * H)), dim3(256), 0, s, w_hh, ws + pl.wt, 2, 4 * H, H);
+    TR_TRY(hipMemsetAsync(ws + pl.dg, 0, (pl.total - pl.dg) * sizeof(float), s));
+    TR_TRY(hipMemsetAsync(dg_pos, 0, (size_t)2 * B * L * 4 * H * sizeof(float), s));
+    TR_TRY(hipMemsetAsync(hprev_pos, 0, (size_t)2 * B * L * H * sizeof(float), s));
+    for (int st = L - 1; st >= 0; --st) {
+        EncBptt q{};
+        q.B = B; q.L = L; q.H = H; q.s = st;
+        q.xg = xg; q.memory = memory; q.c_enc = cell_states; q.dmemory = dmemory; q.w_hh = w_hh; q.w_hh_t = ws + pl.wt; q.lengths = lengths;
+        const int par = st & 1;
+        q.dg_in = ws + pl.dg + (size_t)(par ^ 1) * 2 * B * 4 * H; q.dg_out = ws + pl.dg + (size_t)par * 2 * B * 4 * H;
+        q.dpass_in = ws + pl.dpass + (size_t)(par ^ 1) * 2 * B * H; q.dpass_out = ws + pl.dpass + (size_t)par * 2 * B * H;
+        q.dc = ws + pl.dc; q.dg_pos = dg_pos; q.hprev_pos = hprev_pos;
+        hipLaunchKernelGGL(encoder_bptt_step_kernel, dim3((H + EB_UJ - 1) / EB_UJ, 2), dim3(256), lds, s, q);
+    }
     TR_TRY(hipGetLastError());
     return GVX_OK;
 }

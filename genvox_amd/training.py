@@ -297,61 +297,40 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     lw, ld = W(att + "location_layer.location_conv.conv.weight").contiguous(), W(att + "location_layer.location_dense.linear_layer.weight")
     wm = W(att + "memory_layer.linear_layer.weight")
     q_all = ops.gemm_nt(ha[1:].reshape(T * B, A), wq).reshape(T, B, a)
-    Fp = -(-F_ // 4) * 4                                          # location filters padded to the GEMM's K granularity
-    ld_p = ops.pad_cols(ld, Fp)                                   # [a, Fp]
-    ldT = ops.transpose(ld)                                       # [F, a]
-    WiaT, WhaT, WidT, WhdT, wqT = ops.transpose(Wia), ops.transpose(Wha), ops.transpose(Wid), ops.transpose(Whd), ops.transpose(wq)
     memory, pm = tape["memory"], tape["pm"]
     w_all = outputs["alignments"].permute(1, 0, 2).contiguous()   # [T, B, L]
-    # cumulative weights BEFORE step t: wcum_prev[t] = sum_{s < t} w[s]; built with the axpby primitive, ascending like the forward
-    wcum_prev = ops.zeros(T, B, L)
-    for t in range(1, T):
-        ops.axpby(wcum_prev[t - 1], 1.0, w_all[t - 1], 1.0, out=wcum_prev[t])
-    w_prev_all = torch.cat((ops.zeros(1, B, L), w_all[:T - 1]), dim=0)
-    ka, kd = tape["att_keep"], tape["dec_keep"]
-    sa, sd_ = 1.0 / (1.0 - mc.p_attention_dropout), 1.0 / (1.0 - mc.p_decoder_dropout)
     c_a, c_d = tape["c_a_all"], tape["c_d_all"]                   # [T+1, B, H]
-
-    # ---- back-propagation through the decoder loop
+    # ---- back-propagation through the decoder loop: one C-ABI call (three launches per step, csrc/train.hip)
     dga_all, dgd_all = ops.new(T, B, 4 * A), ops.new(T, B, 4 * D)
-    dq_all = ops.new(T, B, a)
-    dmemory, dpm = ops.zeros(B, L, E), ops.zeros(B, L, a)
-    dv_acc, dld_acc, dlw_acc = ops.zeros(B, a), ops.zeros(a, Fp), ops.zeros(B, F_ * 2 * kl)
-    dh_a_n, dc_a_n, dh_d_n, dc_d_n = ops.zeros(B, A), ops.zeros(B, A), ops.zeros(B, D), ops.zeros(B, D)
-    dctx_n, dw_n, G = ops.zeros(B, E), ops.zeros(B, L), ops.zeros(B, L)
+    dq_all, dctx_all = ops.new(T, B, a), ops.new(T, B, E)
+    dpm, dmemory = ops.new(B, L, a), ops.new(B, L, E)
+    dv, dld, dlw = ops.new(a), ops.new(a, F_), ops.new(F_, 2, kl)
+    ba_ = _lib.gvx_bptt_decoder_args()
+    ba_.B, ba_.L, ba_.T, ba_.A, ba_.D, ba_.E, ba_.P, ba_.a, ba_.F, ba_.kl = B, L, T, A, D, E, Pn, a, F_, kl
+    ba_.att_scale, ba_.dec_scale = 1.0 / (1.0 - mc.p_attention_dropout), 1.0 / (1.0 - mc.p_decoder_dropout)
+    keep = []   # (tensors whose only reference would be the raw pointer in the argument block)
+    def ptr(t):
+        t = t.contiguous()
+        keep.append(t)
+        return t.data_ptr()
+    ba_.dhc_all, ba_.pre_a, ba_.pre_d = ptr(dhc_all), ptr(pre_a), ptr(pre_d)
+    ba_.c_a_all, ba_.c_d_all = ptr(c_a), ptr(c_d)
+    ba_.att_keep, ba_.dec_keep, ba_.q_all = ptr(tape["att_keep"]), ptr(tape["dec_keep"]), ptr(q_all)
+    ba_.ctx_all = hc.data_ptr() + 4 * (B * (D + E) + D)          # ctx(t) = hc[t + 1, b, D:]
+    ba_.ctx_ts, ba_.ctx_bs = B * (D + E), D + E
+    ba_.w_all, ba_.memory, ba_.pm = ptr(w_all), ptr(memory), ptr(pm)
+    ba_.w_ih_a, ba_.w_hh_a, ba_.w_ih_d, ba_.w_hh_d = ptr(Wia), ptr(Wha), ptr(Wid), ptr(Whd)
+    ba_.wq, ba_.v, ba_.loc_conv, ba_.loc_dense = ptr(wq), ptr(v), ptr(lw), ptr(ld)
+    ba_.dga_all, ba_.dgd_all, ba_.dq_all, ba_.dctx_all = dga_all.data_ptr(), dgd_all.data_ptr(), dq_all.data_ptr(), dctx_all.data_ptr()
+    ba_.dpm, ba_.dmemory, ba_.dv, ba_.dloc_dense, ba_.dloc_conv = dpm.data_ptr(), dmemory.data_ptr(), dv.data_ptr(), dld.data_ptr(), dlw.data_ptr()
+    wsb = lib.gvx_train_decoder_bptt_workspace_bytes(C.byref(ba_))
+    if wsb == 0:
+        _lib.check(1)
+    ws_bptt = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.gvx_train_decoder_bptt(C.byref(ba_), ws_bptt.data_ptr(), wsb, st))
+    # the Prenet columns of the attention LSTM are not on the recurrence: one product over all steps
     dp2 = ops.zeros(T + 1, B, Pn)
-    locf, locf_p = ops.new(B * L, F_), ops.zeros(B * L, Fp)
-    du, de = ops.new(B * L, a), ops.new(B, L)
-    for t in reversed(range(T)):
-        dhc = dhc_all[t]
-        # decoder LSTM: dh_d = dhc[:, :D] + dh_d(next step's recurrence)
-        dgd, dc_d_n, _ = ops.lstm_cell_backward(dhc[:, :D], dh_d_n, dc_d_n, pre_d[t], c_d[t], kd[t], sd_)
-        dgd_all[t] = dgd
-        dxd = ops.gemm_nt(dgd, WidT)                              # [B, A + E]
-        dh_d_n = ops.gemm_nt(dgd, WhdT)
-        # attention: context gradient = projection part + decoder-cell input part + next step's attention-cell input part
-        dctx_sum = ops.new(B, E)
-        _lib.check(lib.gvx_train_attention_weights_backward(
-            _p(dhc[:, D:]), ops._ld(dhc), _p(dxd[:, A:]), ops._ld(dxd), _p(dctx_n), ops._ld(dctx_n), _p(dw_n), _p(G), _p(memory), _p(w_all[t]),
-            B, L, E, _p(dmemory), _p(de), _p(dctx_sum), st))
-        _lib.check(lib.gvx_train_location_conv_forward(_p(w_prev_all[t]), _p(wcum_prev[t]), _p(lw), B, L, F_, kl, _p(locf), st))
-        ops.axpby(locf, out=locf_p[:, :F_])
-        locd = ops.gemm_nt(locf_p, ld_p)                          # [B L, a]
-        _lib.check(lib.gvx_train_attention_energy_backward(_p(q_all[t]), _p(locd), _p(pm), _p(v), _p(de), B, L, a, _p(du), _p(dpm), _p(dq_all[t]),
-                                                           _p(dv_acc), st))
-        dld_acc = ops.axpby(dld_acc, 1.0, ops.mm_tn(du, locf_p), 1.0)          # [a, Fp] += du^T locf
-        dlocf = ops.gemm_nt(du, ldT)                              # [B L, F]
-        _lib.check(lib.gvx_train_location_conv_backward(_p(dlocf), _p(w_prev_all[t]), _p(wcum_prev[t]), _p(lw), B, L, F_, kl, _p(dw_n), _p(G),
-                                                        _p(dlw_acc), st))
-        # attention LSTM: dh_a = decoder-cell input part + next step's recurrence + query part
-        dh_a = ops.axpby(dxd[:, :A], 1.0, dh_a_n, 1.0)
-        dh_q = ops.gemm_nt(dq_all[t], wqT)                        # dq @ Wq
-        dga, dc_a_n, _ = ops.lstm_cell_backward(dh_a, dh_q, dc_a_n, pre_a[t], c_a[t], ka[t], sa)
-        dga_all[t] = dga
-        dxa = ops.gemm_nt(dga, WiaT)                              # [B, P + E]
-        dh_a_n = ops.gemm_nt(dga, WhaT)
-        ops.axpby(dxa[:, :Pn], out=dp2[t])
-        dctx_n = dxa[:, Pn:]
+    ops.gemm_nt(dga_all.reshape(T * B, 4 * A), ops.transpose(Wia)[:Pn], out=dp2[:T].reshape(T * B, Pn))
     # ---- weight gradients of the loop, one product over all (t, b) rows each
     dga2, dgd2 = dga_all.reshape(T * B, 4 * A), dgd_all.reshape(T * B, 4 * D)
     g["decoder.attention_rnn.weight_ih"], g["decoder.attention_rnn.weight_hh"] = ops.mm_tn(dga2, xa), ops.mm_tn(dga2, ha_prev.contiguous())
@@ -361,9 +340,9 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     g["decoder.decoder_rnn.bias_ih"] = ops.colsum(dgd2)
     g["decoder.decoder_rnn.bias_hh"] = g["decoder.decoder_rnn.bias_ih"].clone()
     g[att + "query_layer.linear_layer.weight"] = ops.mm_tn(dq_all.reshape(T * B, a), ha[1:].reshape(T * B, A).contiguous())
-    g[att + "v.linear_layer.weight"] = ops.colsum(dv_acc)[None, :].contiguous()
-    g[att + "location_layer.location_dense.linear_layer.weight"] = dld_acc[:, :F_].contiguous()
-    g[att + "location_layer.location_conv.conv.weight"] = ops.colsum(dlw_acc).reshape(F_, 2, kl)
+    g[att + "v.linear_layer.weight"] = dv[None, :]
+    g[att + "location_layer.location_dense.linear_layer.weight"] = dld
+    g[att + "location_layer.location_conv.conv.weight"] = dlw
     dpm2 = dpm.reshape(B * L, a)
     g[att + "memory_layer.linear_layer.weight"] = ops.mm_tn(dpm2, memory.reshape(B * L, E))
     dmemory = ops.axpby(dmemory.reshape(B * L, E), 1.0, ops.gemm_nt(dpm2, ops.transpose(wm)), 1.0).reshape(B, L, E)
@@ -384,39 +363,25 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     x = tape["enc_conv_out"].permute(0, 2, 1).contiguous()        # [B, L, E]
     c_enc = tape["enc_cell_states"]                               # [B, L, E] (forward direction in channels [0, H))
     dx_enc = ops.zeros(B * L, E)
-    for d_, sfx in enumerate(("", "_reverse")):
-        w_ih, w_hh = W("encoder.lstm.weight_ih_l0" + sfx), W("encoder.lstm.weight_hh_l0" + sfx)
+    sfxs = ("", "_reverse")
+    w_ih2 = [W("encoder.lstm.weight_ih_l0" + sfx) for sfx in sfxs]
+    w_hh2 = torch.stack([W("encoder.lstm.weight_hh_l0" + sfx) for sfx in sfxs]).contiguous()        # [2, 4H, H]
+    xg = torch.empty(2, B * L, 4 * H, device=dev)
+    for d_, sfx in enumerate(sfxs):
         bsum = ops.axpby(W("encoder.lstm.bias_ih_l0" + sfx)[None, :], 1.0, W("encoder.lstm.bias_hh_l0" + sfx)[None, :], 1.0)[0]
-        xg = ops.gemm_nt(x.reshape(B * L, E), w_ih, bias=bsum).reshape(B, L, 4 * H)
-        w_hhT = ops.transpose(w_hh)
-        dg_pos = ops.zeros(B, L, 4 * H)                           # gate gradients filed under the POSITION they belong to
-        hprev_pos = ops.zeros(B, L, H)
-        dh, dc = ops.zeros(B, H), ops.zeros(B, H)
-        rows = torch.arange(B, device=dev)
-        mem_d, c_d_ = memory[:, :, d_ * H:(d_ + 1) * H], c_enc[:, :, d_ * H:(d_ + 1) * H]
-        dmem_d = dmemory[:, :, d_ * H:(d_ + 1) * H]
-        for s in reversed(range(L)):
-            active = (s < tl)
-            t_idx = torch.full((B,), s, dtype=torch.long, device=dev) if d_ == 0 else (tl - 1 - s).clamp(min=0)
-            p_idx = (t_idx - 1) if d_ == 0 else (t_idx + 1)       # position of the previous step's state
-            has_prev = active & (s > 0)
-            # (index gathers of rows: layout plumbing; the arithmetic is in the kernels)
-            h_prev = torch.where(has_prev[:, None], mem_d[rows, p_idx.clamp(0, L - 1)], torch.zeros((), device=dev)).contiguous()
-            c_prev = torch.where(has_prev[:, None], c_d_[rows, p_idx.clamp(0, L - 1)], torch.zeros((), device=dev)).contiguous()
-            pre = ops.axpby(xg[rows, t_idx].contiguous(), 1.0, ops.gemm_nt(h_prev, w_hh), 1.0)
-            dmem_rows = torch.where(active[:, None], dmem_d[rows, t_idx], torch.zeros((), device=dev)).contiguous()
-            act8 = active.to(torch.uint8).contiguous()
-            dgt, dc, dh_pass = ops.lstm_cell_backward(dh, dmem_rows, dc, pre, c_prev, None, 1.0, active=act8, want_pass=True)
-            dh = ops.axpby(ops.gemm_nt(dgt, w_hhT), 1.0, dh_pass, 1.0)   # inactive rows: dgt = 0, the state gradient passes through
-            sel = rows[active]
-            dg_pos[sel, t_idx[active]] = dgt[active]
-            hprev_pos[sel, t_idx[active]] = h_prev[active]
-        dg2 = dg_pos.reshape(B * L, 4 * H)
+        ops.gemm_nt(x.reshape(B * L, E), w_ih2[d_], bias=bsum, out=xg[d_])
+    dg_pos, hprev_pos = torch.empty(2, B * L, 4 * H, device=dev), torch.empty(2, B * L, H, device=dev)
+    wse = torch.empty(lib.gvx_train_encoder_lstm_bptt_workspace_bytes(B, H), dtype=torch.uint8, device=dev)
+    tl32 = tl.to(torch.int32).contiguous()
+    _lib.check(lib.gvx_train_encoder_lstm_bptt(_p(xg), _p(memory.contiguous()), _p(c_enc.contiguous()), _p(dmemory.contiguous()), _p(w_hh2), _p(tl32),
+                                               B, L, H, _p(dg_pos), _p(hprev_pos), _p(wse), wse.numel(), st))
+    for d_, sfx in enumerate(sfxs):
+        dg2 = dg_pos[d_]
         g["encoder.lstm.weight_ih_l0" + sfx] = ops.mm_tn(dg2, x.reshape(B * L, E))
-        g["encoder.lstm.weight_hh_l0" + sfx] = ops.mm_tn(dg2, hprev_pos.reshape(B * L, H))
+        g["encoder.lstm.weight_hh_l0" + sfx] = ops.mm_tn(dg2, hprev_pos[d_])
         g["encoder.lstm.bias_ih_l0" + sfx] = ops.colsum(dg2)
         g["encoder.lstm.bias_hh_l0" + sfx] = g["encoder.lstm.bias_ih_l0" + sfx].clone()
-        dx_enc = ops.axpby(dx_enc, 1.0, ops.gemm_nt(dg2, ops.transpose(w_ih)), 1.0)
+        dx_enc = ops.axpby(dx_enc, 1.0, ops.gemm_nt(dg2, ops.transpose(w_ih2[d_])), 1.0)
     # ---- encoder convolution stack and embedding
     dconv, eg = convstack_train_backward(tape["encoder"], dx_enc.reshape(B, L, E).permute(0, 2, 1).contiguous())
     g.update(eg)

@@ -270,6 +270,57 @@ int gvx_train_sqnorm_accumulate(const float* x, long n, double* acc, void* strea
 int gvx_train_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float grad_scale, float lr, float weight_decay,
                         float beta1, float beta2, float eps, int step, void* stream);
 
+/* ---- Back-propagation through the decoder loop in one call (three launches per step issued by the library instead of ~20
+ * primitives per step strung together by the host): d loss / d of both LSTM cells' gates at every step, of the attention
+ * queries, of the processed memory, of the memory through the contexts, and of v / location_dense / location_conv
+ * (Decoder.forward backwards, models/tts/tacotron2.py:365-388 with :333-363 and Attention :89-129).  What is not on the
+ * recurrence (weight gradients as whole-sequence products, the Prenet columns of the attention LSTM) stays with the caller.
+ * All pointers device, fp32 row-major, gates in torch order i, f, g, o. */
+typedef struct gvx_bptt_decoder_args {
+    int32_t B, L, T;                    /* B <= 32 */
+    int32_t A, D, E, P, a, F, kl;       /* att_rnn_dim, dec_rnn_dim, embed_dim, prenet_dim, att_dim, location filters / kernel size */
+    float att_scale, dec_scale;         /* 1 / (1 - p) of the dropout on each cell's hidden output */
+    const float* dhc_all;               /* [T][B][D+E]  d loss / d [h_d(t) ; ctx(t)] through the mel / gate projection */
+    const float* pre_a;                 /* [T][B][4A]   gate pre-activations of the attention LSTM */
+    const float* pre_d;                 /* [T][B][4D]   ... of the decoder LSTM */
+    const float* c_a_all;               /* [T+1][B][A]  cell states, slot t = before step t */
+    const float* c_d_all;               /* [T+1][B][D] */
+    const uint8_t* att_keep;            /* [T][B][A]    keep masks of the hidden-output dropouts */
+    const uint8_t* dec_keep;            /* [T][B][D] */
+    const float* q_all;                 /* [T][B][a]    attention queries W_q h_a(t) */
+    const float* ctx_all;               /* context of (step t, row b) at ctx_all + t * ctx_ts + b * ctx_bs, E floats */
+    int64_t ctx_ts, ctx_bs;
+    const float* w_all;                 /* [T][B][L]    alignments, time-major */
+    const float* memory;                /* [B][L][E] */
+    const float* pm;                    /* [B][L][a]    processed memory */
+    const float* w_ih_a; const float* w_hh_a;   /* attention_rnn.weight_ih [4A][P+E], weight_hh [4A][A] */
+    const float* w_ih_d; const float* w_hh_d;   /* decoder_rnn.weight_ih [4D][A+E], weight_hh [4D][D] */
+    const float* wq;                    /* query_layer weight [a][A] */
+    const float* v;                     /* [a] */
+    const float* loc_conv;              /* location_conv weight [F][2][kl] */
+    const float* loc_dense;             /* location_dense weight [a][F] */
+    float* dga_all;                     /* out [T][B][4A]  d loss / d gate pre-activations of the attention LSTM */
+    float* dgd_all;                     /* out [T][B][4D] */
+    float* dq_all;                      /* out [T][B][a] */
+    float* dctx_all;                    /* out [T][B][E]   total d loss / d ctx(t) */
+    float* dpm;                         /* out [B][L][a] */
+    float* dmemory;                     /* out [B][L][E]   context path only: sum_t w_t (x) dctx_t */
+    float* dv;                          /* out [a] */
+    float* dloc_dense;                  /* out [a][F] */
+    float* dloc_conv;                   /* out [F][2][kl] */
+} gvx_bptt_decoder_args;
+size_t gvx_train_decoder_bptt_workspace_bytes(const gvx_bptt_decoder_args* args);
+int gvx_train_decoder_bptt(const gvx_bptt_decoder_args* args, void* workspace, size_t workspace_bytes, void* stream);
+/* Back-propagation through the encoder BiLSTM (Encoder.forward, models/tts/tacotron2.py:239-245, packed-sequence semantics),
+ * one launch per time step for both directions.  xg [2][B][L][4H] = W_ih x + b_ih + b_hh per direction; memory / cell_states /
+ * dmemory [B][L][2H] (forward direction in the first H channels); w_hh [2][4H][H].  Outputs, filed under the POSITION a step
+ * belongs to (zeros past a row's length): dg_pos [2][B][L][4H] gate gradients, hprev_pos [2][B][L][H] the step's previous
+ * hidden state - the operands of the weight gradients and of d loss / d x. */
+size_t gvx_train_encoder_lstm_bptt_workspace_bytes(int B, int H);
+int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const float* cell_states, const float* dmemory, const float* w_hh,
+                                const int32_t* lengths, int B, int L, int H, float* dg_pos, float* hprev_pos, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
 /* ---- Prenet keep-mask generator for callers that do not supply masks (the reference draws them from
  * torch's RNG inside F.dropout, models/tts/tacotron2.py:143).  Writes n bytes of Bernoulli(0.5) {0,1}. */
 int gvx_prenet_masks_generate(uint8_t* masks_out, size_t n, uint64_t seed, void* stream);

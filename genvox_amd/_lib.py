@@ -47,6 +47,7 @@ SIGNATURES = {
     "gvx_model_blob_bytes": (_sz, [_vp]),
     "gvx_model_pack_weights": (_i, [_vp, C.POINTER(gvx_weight_desc), _i, _vp]),
     "gvx_model_bind_blob": (_i, [_vp, _vp]),
+    "gvx_model_pack_weights_device": (_i, [_vp, C.POINTER(gvx_weight_desc), _i, _vp, _vp]),
     "gvx_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "gvx_workspace_bytes_autoregressive": (_sz, [_vp, _i, _i, _i]),
     "gvx_workspace_status": (_i, [_vp, _vp, _sz, _vp, _vp]),

@@ -146,6 +146,12 @@ struct gvx_model {
                                        // wait of the loop runs into its limit (test of the time-out reporting only)
     hipStream_t pa_stream = nullptr;
     hipEvent_t pa_fork = nullptr, pa_join = nullptr;
+    // device-side re-packing (gvx_model_pack_weights_device): where every float of the blob comes from, built once per
+    // state_dict layout by running the HOST packer over index-coded stand-ins of the tensors
+    std::vector<std::string> gather_names;
+    std::vector<int64_t> gather_numel;
+    int32_t* gather_off = nullptr;     // [blob.total] offset inside the source tensor (device)
+    uint8_t* gather_tid = nullptr;     // [blob.total] source tensor + 1, 0 = constant zero (device)
     void drop_graphs() {
         for (auto* c : {&ar_graphs, &loop_graphs, &enc_graphs}) {
             for (auto& gs : *c)
@@ -440,6 +446,10 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
 }
 
 void gvx_model_destroy(gvx_model* m) {
+    if (m) {
+        if (m->gather_off) (void)hipFree(m->gather_off);
+        if (m->gather_tid) (void)hipFree(m->gather_tid);
+    }
     if (!m) return;
     if (m->ev_valid)
         for (auto& e : m->ev) (void)hipEventDestroy(e);
@@ -568,6 +578,159 @@ int gvx_model_pack_weights(gvx_model* m, const gvx_weight_desc* table, int n, vo
         rc = pack_conv(wt, "postnet.convolutions." + std::to_string(i), cout, cin, d.postnet_kernel, out + bl.post_w[i], out + bl.post_b[i]);
         if (rc != GVX_OK) return rc;
     }
+    return GVX_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+constexpr int PACK_MAX_TENSORS = 192;
+struct PackSources { const float* p[PACK_MAX_TENSORS]; };
+
+__global__ void pack_gather_kernel(PackSources src, const int32_t* off, const uint8_t* tid, long n, float* blob) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int t = tid[i];
+        if (t == 255) continue;   // written by the fold / bias kernels below
+        blob[i] = t ? src.p[t - 1][off[i]] : 0.f;
+    }
+}
+// pack_conv on the device: [Cout][Cin][k] -> [Cout][k][Cin] with the eval-mode BatchNorm scale folded in (double, like the host)
+__global__ void pack_conv_fold_kernel(const float* w, const float* b, const float* g, const float* beta, const float* mu, const float* var,
+                                      int cout, int cin, int k, float* w_out, float* b_out) {
+    const long n = (long)cout * cin * k;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin), kk = (int)((i / cin) % k), co = (int)(i / ((long)cin * k));
+        const double scale = (double)g[co] / sqrt((double)var[co] + BN_EPS);
+        w_out[i] = (float)((double)w[((long)co * cin + ci) * k + kk] * scale);
+        if (ci == 0 && kk == 0) b_out[co] = (float)(((double)b[co] - (double)mu[co]) * scale + (double)beta[co]);
+    }
+}
+// bias of an LSTM in packed row order: out[4 j + q] = b_ih[q H + j] + b_hh[q H + j]
+__global__ void pack_lstm_bias_kernel(const float* bih, const float* bhh, int Hd, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * Hd) { const int j = i >> 2, q = i & 3; out[i] = bih[q * Hd + j] + bhh[q * Hd + j]; }
+}
+
+struct DevTable {
+    std::unordered_map<std::string, int> idx;
+    const gvx_weight_desc* t;
+    const float* get(const std::string& name, int64_t numel, int* rc) const {
+        auto it = idx.find(name);
+        if (it == idx.end()) { *rc = fail(GVX_ERR_MISSING_WEIGHT, "missing weight '%s'", name.c_str()); return nullptr; }
+        if (t[it->second].numel != numel) { *rc = fail(GVX_ERR_SHAPE, "weight '%s' has %lld elements, expected %lld", name.c_str(), (long long)t[it->second].numel, (long long)numel); return nullptr; }
+        return t[it->second].data;
+    }
+};
+
+// Build (or re-use) the gather map of `table`'s layout.  Two runs of the host packer over stand-ins whose floats carry the
+// low / high 12 bits of their own index tell where each blob float comes from; the regions the packer COMPUTES (BatchNorm
+// folds, bias sums) are marked 255 and written by their own kernels.
+int ensure_gather_map(gvx_model* m, const gvx_weight_desc* table, int n) {
+    bool same = m->gather_off && (int)m->gather_names.size() == n;
+    for (int i = 0; same && i < n; ++i) same = m->gather_names[i] == table[i].name && m->gather_numel[i] == table[i].numel;
+    if (same) return GVX_OK;
+    if (n > PACK_MAX_TENSORS || n > 254) return fail(GVX_ERR_UNSUPPORTED, "pack_weights_device: more than %d tensors", 254);
+    const size_t total = m->blob.total;
+    std::vector<std::vector<float>> lo(n), hi(n);
+    std::vector<gvx_weight_desc> tl(n), th(n);
+    for (int i = 0; i < n; ++i) {
+        if (table[i].numel < 0 || table[i].numel >= (int64_t)1 << 31) return fail(GVX_ERR_UNSUPPORTED, "pack_weights_device: tensor too large");
+        lo[i].resize((size_t)table[i].numel); hi[i].resize((size_t)table[i].numel);
+        for (int64_t e = 0; e < table[i].numel; ++e) { lo[i][e] = (float)((e & 4095) + 1); hi[i][e] = (float)((e >> 12) * 256 + i + 1); }
+        tl[i] = gvx_weight_desc{table[i].name, lo[i].data(), table[i].numel};
+        th[i] = gvx_weight_desc{table[i].name, hi[i].data(), table[i].numel};
+    }
+    std::vector<float> bl(total), bh(total);
+    int rc = gvx_model_pack_weights(m, tl.data(), n, bl.data());
+    if (rc != GVX_OK) return rc;
+    rc = gvx_model_pack_weights(m, th.data(), n, bh.data());
+    if (rc != GVX_OK) return rc;
+    std::vector<int32_t> off(total);
+    std::vector<uint8_t> tid(total);
+    for (size_t i = 0; i < total; ++i) {
+        if (bl[i] == 0.f && bh[i] == 0.f) { off[i] = 0; tid[i] = 0; continue; }
+        const long h = (long)bh[i] - 1, l = (long)bl[i] - 1;
+        const int t = (int)(h % 256);
+        off[i] = (int32_t)((h / 256) * 4096 + l);
+        tid[i] = (uint8_t)(t + 1);
+    }
+    // computed regions
+    const gvx_dims& d = m->d;
+    const Blob& b = m->blob;
+    auto mark = [&](size_t o, size_t cnt) { std::fill(tid.begin() + o, tid.begin() + o + cnt, (uint8_t)255); };
+    const int E = d.embed_dim, H = E / 2, M = d.n_mels;
+    for (int i = 0; i < d.enc_n_conv; ++i) { mark(b.enc_w[i], (size_t)E * d.enc_kernel * E); mark(b.enc_b[i], E); }
+    for (int i = 0; i < d.postnet_n_conv; ++i) {
+        const int cin = i == 0 ? M : d.postnet_dim, cout = i == d.postnet_n_conv - 1 ? M : d.postnet_dim;
+        mark(b.post_w[i], (size_t)cout * d.postnet_kernel * cin); mark(b.post_b[i], cout);
+    }
+    mark(b.enc_bih, (size_t)8 * H); mark(b.att_bias, (size_t)4 * d.att_rnn_dim); mark(b.dec_bias, (size_t)4 * d.dec_rnn_dim);
+    // sanity: every gathered float points inside its tensor
+    for (size_t i = 0; i < total; ++i)
+        if (tid[i] && tid[i] != 255 && (tid[i] > n || off[i] < 0 || off[i] >= table[tid[i] - 1].numel))
+            return fail(GVX_ERR_UNSUPPORTED, "pack_weights_device: gather map is inconsistent at blob float %zu", i);
+    if (m->gather_off) { (void)hipFree(m->gather_off); m->gather_off = nullptr; }
+    if (m->gather_tid) { (void)hipFree(m->gather_tid); m->gather_tid = nullptr; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->gather_off), total * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->gather_tid), total));
+    HIP_TRY(hipMemcpy(m->gather_off, off.data(), total * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->gather_tid, tid.data(), total, hipMemcpyHostToDevice));
+    m->gather_names.clear(); m->gather_numel.clear();
+    for (int i = 0; i < n; ++i) { m->gather_names.push_back(table[i].name); m->gather_numel.push_back(table[i].numel); }
+    return GVX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gvx_model_pack_weights_device(gvx_model* m, const gvx_weight_desc* table, int n, void* device_blob, void* stream) {
+    if (!m || !table || !device_blob || n < 1) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    if (reinterpret_cast<uintptr_t>(device_blob) & 255) return fail(GVX_ERR_INVALID_ARG, "blob must be 256-byte aligned");
+    int rc = ensure_gather_map(m, table, n);
+    if (rc != GVX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    float* out = reinterpret_cast<float*>(device_blob);
+    PackSources src{};
+    for (int i = 0; i < n; ++i) src.p[i] = table[i].data;
+    const long total = (long)m->blob.total;
+    hipLaunchKernelGGL(pack_gather_kernel, dim3(4096), dim3(256), 0, s, src, m->gather_off, m->gather_tid, total, out);
+    DevTable dt; dt.t = table;
+    for (int i = 0; i < n; ++i) dt.idx[table[i].name] = i;
+    const gvx_dims& d = m->d;
+    const Blob& bl = m->blob;
+    const int E = d.embed_dim, H = E / 2, M = d.n_mels;
+    auto conv = [&](const std::string& prefix, int cout, int cin, int k, size_t w_off, size_t b_off) -> int {
+        int r = GVX_OK;
+        const float* w = dt.get(prefix + ".0.conv.weight", (int64_t)cout * cin * k, &r); if (!w) return r;
+        const float* b = dt.get(prefix + ".0.conv.bias", cout, &r); if (!b) return r;
+        const float* g = dt.get(prefix + ".1.weight", cout, &r); if (!g) return r;
+        const float* beta = dt.get(prefix + ".1.bias", cout, &r); if (!beta) return r;
+        const float* mu = dt.get(prefix + ".1.running_mean", cout, &r); if (!mu) return r;
+        const float* var = dt.get(prefix + ".1.running_var", cout, &r); if (!var) return r;
+        const long cnt = (long)cout * cin * k;
+        hipLaunchKernelGGL(pack_conv_fold_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, w, b, g, beta, mu, var, cout, cin, k, out + w_off, out + b_off);
+        return GVX_OK;
+    };
+    for (int i = 0; i < d.enc_n_conv; ++i)
+        if ((rc = conv("encoder.convolutions." + std::to_string(i), E, E, d.enc_kernel, bl.enc_w[i], bl.enc_b[i])) != GVX_OK) return rc;
+    for (int i = 0; i < d.postnet_n_conv; ++i) {
+        const int cin = i == 0 ? M : d.postnet_dim, cout = i == d.postnet_n_conv - 1 ? M : d.postnet_dim;
+        if ((rc = conv("postnet.convolutions." + std::to_string(i), cout, cin, d.postnet_kernel, bl.post_w[i], bl.post_b[i])) != GVX_OK) return rc;
+    }
+    auto bias = [&](const std::string& bih_n, const std::string& bhh_n, int Hd, size_t o) -> int {
+        int r = GVX_OK;
+        const float* bih = dt.get(bih_n, 4 * Hd, &r); if (!bih) return r;
+        const float* bhh = dt.get(bhh_n, 4 * Hd, &r); if (!bhh) return r;
+        hipLaunchKernelGGL(pack_lstm_bias_kernel, dim3((4 * Hd + 255) / 256), dim3(256), 0, s, bih, bhh, Hd, out + o);
+        return GVX_OK;
+    };
+    if ((rc = bias("encoder.lstm.bias_ih_l0", "encoder.lstm.bias_hh_l0", H, bl.enc_bih)) != GVX_OK) return rc;
+    if ((rc = bias("encoder.lstm.bias_ih_l0_reverse", "encoder.lstm.bias_hh_l0_reverse", H, bl.enc_bih + (size_t)4 * H)) != GVX_OK) return rc;
+    if ((rc = bias("decoder.attention_rnn.bias_ih", "decoder.attention_rnn.bias_hh", d.att_rnn_dim, bl.att_bias)) != GVX_OK) return rc;
+    if ((rc = bias("decoder.decoder_rnn.bias_ih", "decoder.decoder_rnn.bias_hh", d.dec_rnn_dim, bl.dec_bias)) != GVX_OK) return rc;
+    HIP_TRY(hipGetLastError());
     return GVX_OK;
 }
 

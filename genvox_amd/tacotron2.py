@@ -17,6 +17,7 @@ Differences from the reference, on purpose:
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, Optional
 
@@ -87,6 +88,7 @@ class Tacotron2(nn.Module):
         self._handle: Optional[int] = None
         self._key_tensors = None
         self._blob: Optional[torch.Tensor] = None
+        self._host_repack = os.environ.get("GVX_HOST_REPACK") == "1"   # A/B knob: every re-pack through the host packer
         self._packed_key = None
         self._workspace: Optional[torch.Tensor] = None
         self._lane_ws = [None, None]     # workspaces of the two concurrent chunk lanes
@@ -166,13 +168,35 @@ class Tacotron2(nn.Module):
         _lib.check(lib.gvx_model_pack_weights(h, table, len(host), blob_host.data_ptr()))
         return blob_host
 
+    def pack_weights_device(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same blob built on the device from the parameters where they are (gvx_model_pack_weights_device): what the
+        training loop calls after every optimizer step - bit-identical to ``pack_weights_host`` (tests/test_training_gpu.py)."""
+        dev = self._require_gpu()
+        lib = _lib.load()
+        h = self._ensure_handle()
+        srcs = {k: v.detach() for k, v in self.state_dict().items() if v.is_floating_point()}
+        for k, v in srcs.items():
+            if v.device != dev or v.dtype != torch.float32 or not v.is_contiguous():
+                srcs[k] = v.to(device=dev, dtype=torch.float32).contiguous()
+        table = (_lib.gvx_weight_desc * len(srcs))()
+        for i, (k, v) in enumerate(srcs.items()):
+            table[i] = _lib.gvx_weight_desc(k.encode(), v.data_ptr(), v.numel())
+        blob = torch.empty(self.blob_numel(), dtype=torch.float32, device=dev) if out is None else out
+        _lib.check(lib.gvx_model_pack_weights_device(h, table, len(srcs), blob.data_ptr(), self._stream()))
+        return blob
+
     def _ensure_packed(self) -> None:
-        """Make the device blob match the current state_dict (once per weight version)."""
+        """Make the device blob match the current state_dict (once per weight version).  The first blob of a model comes from
+        the host packer (which needs no GPU state); later versions - a training loop re-packs after every optimizer step -
+        are re-built in place on the device."""
         dev = self._require_gpu()
         key = self._weights_key()
         if self._packed_key == key:
             return
-        self._bind(self.pack_weights_host().to(dev))
+        if self._blob is not None and self._blob.device == dev and self._blob.numel() == self.blob_numel() and not self._host_repack:
+            self.pack_weights_device(out=self._blob)   # same storage: the handles' binding and cached graphs stay valid
+        else:
+            self._bind(self.pack_weights_host().to(dev))
         self._packed_key = key
 
     def _bind(self, blob: torch.Tensor) -> None:

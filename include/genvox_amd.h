@@ -66,7 +66,7 @@ typedef struct gvx_dims {
 /* One named fp32 tensor of the reference's state_dict (models/tts/tacotron2.py:574-584). */
 typedef struct gvx_weight_desc {
     const char* name;      /* e.g. "decoder.attention_rnn.weight_ih"                      */
-    const float* data;     /* HOST pointer, contiguous row-major                          */
+    const float* data;     /* HOST pointer (DEVICE for gvx_model_pack_weights_device), contiguous row-major */
     int64_t numel;
 } gvx_weight_desc;
 
@@ -86,6 +86,12 @@ void gvx_model_destroy(gvx_model* model);
 size_t gvx_model_blob_bytes(const gvx_model* model);
 int gvx_model_pack_weights(gvx_model* model, const gvx_weight_desc* table, int n, void* host_blob);
 int gvx_model_bind_blob(gvx_model* model, const void* device_blob);
+/* The same packing on the device: `table` holds DEVICE pointers (the parameters where training updates them in place),
+ * device_blob receives exactly the bytes gvx_model_pack_weights would produce.  The first call with a given list of
+ * (name, numel) builds a gather map - by running the host packer over index-coded stand-ins - and keeps it in device
+ * memory owned by the handle (5 bytes per blob float); later calls are one gather launch plus the BatchNorm folds and
+ * bias sums.  This is what a training loop calls after every optimizer step (the host packer takes 80 ms per call). */
+int gvx_model_pack_weights_device(gvx_model* model, const gvx_weight_desc* table, int n, void* device_blob, void* stream);
 
 /* Bytes of scratch the calls below need for batch B, L tokens and up to T frames.  gvx_workspace_bytes covers every call;
  * gvx_workspace_bytes_autoregressive is the (smaller) amount gvx_encoder_forward + gvx_decoder_autoregressive +

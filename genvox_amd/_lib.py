@@ -60,7 +60,7 @@ SIGNATURES = {
     "gvx_tacotron2_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_tacotron2_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "gvx_encoder_lstm_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "gvx_decoder_teacher_forced_train": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_decoder_teacher_forced_train": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_train_export": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp, _vp]),
     "gvx_conv_train_saved_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "gvx_conv_train_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
@@ -71,11 +71,6 @@ SIGNATURES = {
     "gvx_train_transpose": (_i, [_vp, _l, _vp, _l, _i, _l, _vp]),
     "gvx_train_colsum": (_i, [_vp, _l, _i, _vp, _vp]),
     "gvx_train_axpby": (_i, [_vp, _l, _f, _vp, _l, _f, _vp, _l, _l, _i, _vp]),
-    "gvx_train_lstm_cell_backward": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _vp]),
-    "gvx_train_attention_weights_backward": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "gvx_train_location_conv_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "gvx_train_attention_energy_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "gvx_train_location_conv_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gvx_train_relu_dropout_backward": (_i, [_vp, _vp, _vp, _f, _l, _vp, _vp]),
     "gvx_train_unblock": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "gvx_train_embedding_backward": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp]),

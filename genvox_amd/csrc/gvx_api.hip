@@ -1059,6 +1059,7 @@ struct LstmDropout {
     // tape for back-propagation through time (all may be nullptr): the attention LSTM's (dropped) hidden state of every step as
     // blocked vectors [T+1][A/8][B][8] (slot t + 1 = after step t, slot 0 = zeros) and both cells' states [T+1][B][H] row-major
     float* h_a_all; float* c_a_all; float* c_d_all;
+    float* pre_a_all; float* pre_d_all;   // gate pre-activations of every step [T][B][H][4] (gates of a unit together)
 };
 
 int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
@@ -1156,7 +1157,9 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
                     jobs[0].x[2].p = train->h_a_all + (size_t)t * BA; jobs[0].h_out = train->h_a_all + (size_t)(t + 1) * BA;
                 }
                 if (train->c_a_all) { jobs[0].c = train->c_a_all + (size_t)t * BA; jobs[0].c_out = train->c_a_all + (size_t)(t + 1) * BA; }
+                if (train->pre_a_all) jobs[0].pre_out = train->pre_a_all + (size_t)t * 4 * BA;
                 if (t > 0) {
+                    if (train->pre_d_all) jobs[1].pre_out = train->pre_d_all + (size_t)(t - 1) * 4 * BD;
                     jobs[1].h_keep = train->dec_keep + (size_t)(t - 1) * BD; jobs[1].h_scale = train->dec_scale;
                     if (train->h_a_all) jobs[1].x[0].p = train->h_a_all + (size_t)t * BA;   // h_a(t-1)
                     if (train->c_d_all) { jobs[1].c = train->c_d_all + (size_t)(t - 1) * BD; jobs[1].c_out = train->c_d_all + (size_t)t * BD; }
@@ -1183,6 +1186,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
             job.h_keep = train->dec_keep + (size_t)(T - 1) * BD; job.h_scale = train->dec_scale;
             if (train->h_a_all) job.x[0].p = train->h_a_all + (size_t)T * BA;
             if (train->c_d_all) { job.c = train->c_d_all + (size_t)(T - 1) * BD; job.c_out = train->c_d_all + (size_t)T * BD; }
+            if (train->pre_d_all) job.pre_out = train->pre_d_all + (size_t)(T - 1) * 4 * BD;
         }
         HIP_TRY(launch_skinny(&job, 1, SK_DECODER, st));
         ++launches;
@@ -1457,14 +1461,15 @@ int gvx_encoder_lstm_forward(gvx_model* m, const float* conv_out, const int32_t*
 int gvx_decoder_teacher_forced_train(gvx_model* m, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in, int T,
                                      const uint8_t* keep_masks, const uint8_t* att_keep, const uint8_t* dec_keep, float p_att, float p_dec,
                                      float* mel_out, float* gate_out, float* align_out, float* att_hidden_all, float* att_cell_all,
-                                     float* dec_cell_all, float* dec_hidden_context_all, void* ws, size_t ws_bytes, void* stream) {
+                                     float* dec_cell_all, float* dec_hidden_context_all, float* att_preact_all, float* dec_preact_all,
+                                     void* ws, size_t ws_bytes, void* stream) {
     int rc = check_common(m, B, L, T, ws, ws_bytes);
     if (rc != GVX_OK) return rc;
     if (!memory || !mel_in || !keep_masks || !att_keep || !dec_keep || !mel_out || !gate_out || !align_out) return fail(GVX_ERR_INVALID_ARG, "null argument");
     if (!(p_att >= 0.f && p_att < 1.f && p_dec >= 0.f && p_dec < 1.f)) return fail(GVX_ERR_INVALID_ARG, "dropout probabilities must be in [0, 1)");
     hipStream_t s = (hipStream_t)stream;
     const int A = m->d.att_rnn_dim, D = m->d.dec_rnn_dim, E = m->d.embed_dim;
-    const LstmDropout tr{att_keep, dec_keep, 1.f / (1.f - p_att), 1.f / (1.f - p_dec), att_hidden_all, att_cell_all, dec_cell_all};
+    const LstmDropout tr{att_keep, dec_keep, 1.f / (1.f - p_att), 1.f / (1.f - p_dec), att_hidden_all, att_cell_all, dec_cell_all, att_preact_all, dec_preact_all};
     if (att_hidden_all) HIP_TRY(zero_async(att_hidden_all, (size_t)B * A * sizeof(float), s));   // slot 0: the initial (zero) states
     if (att_cell_all) HIP_TRY(zero_async(att_cell_all, (size_t)B * A * sizeof(float), s));
     if (dec_cell_all) HIP_TRY(zero_async(dec_cell_all, (size_t)B * D * sizeof(float), s));

@@ -96,6 +96,8 @@ struct SkinnyJob {
     // training mode: where to write the new cell state (nullptr: in place, into c) and, for sequence jobs, the cell state of
     // every position like seq_out (c_seq_out[b][t_b][j], same strides) - what back-propagation through time reads
     float* c_out; float* c_seq_out;
+    // training mode, decoder cells: the gate pre-activations (i, f, g, o of unit j at pre_out[(b * H + j) * 4 ...]) for the backward pass
+    float* pre_out;
     // attention query partial products: slab[tile][b][a] = sum_{j in tile} Wq[a][j] * h'[b][j]
     const float* Wq_t;      // [H/8][att_dim][8] (tile-major repack of query_layer.weight) or nullptr
     float* q_slab; int att_dim;

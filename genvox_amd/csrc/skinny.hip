@@ -542,6 +542,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
                         const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b * J.add_bs + (long)tb * J.add_ts + n);
                         pre[0] += ad.x; pre[1] += ad.y; pre[2] += ad.z; pre[3] += ad.w;
                     }
+                    if (J.pre_out) *reinterpret_cast<float4*>(J.pre_out + ((long)b * H + j) * 4) = make_float4(pre[0], pre[1], pre[2], pre[3]);
                     const float c_old = c_pref;
                     const float c_new = sigmoidf_(pre[1]) * c_old + sigmoidf_(pre[0]) * tanhf_(pre[2]);
                     hval = sigmoidf_(pre[3]) * tanhf_(c_new);

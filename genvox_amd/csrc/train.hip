@@ -418,157 +418,12 @@ int gvx_tacotron2_loss_backward(const float* mel_out, const float* mel_post_out,
 }  // extern "C"
 
 // =====================================================================================================================
-// Back-propagation through time: generic primitives for the host side (genvox_amd/training.py), which walks the decoder
-// loop and the encoder BiLSTM backwards exactly as oracle/train_ref.py states it.  All tensors row-major fp32 with an
-// explicit leading dimension where slices are taken.  Correctness first (one fused kernel per formula group; the dense
-// products go through the exact-fp32 MFMA GEMM).
+// Whole-sequence pieces of the backward pass: generic primitives for the host side (genvox_amd/training.py) - dense products
+// on the exact-fp32 MFMA GEMM, transposes, column sums, elementwise updates, Adam.  All tensors row-major fp32 with an
+// explicit leading dimension where slices are taken.  The two recurrences are at the end of this file.
 // =====================================================================================================================
 namespace gvx {
 namespace {
-
-// ---- LSTM cell backward (torch gate order i, f, g, o in blocks of H along the row) -----------------------------------------
-// dh = dh_a[b][j] (+ dh_b[b][j]); h' = o tanh(c) * keep * scale.  pre = gate pre-activations [B][4H]; c_prev [B][H].
-// active (may be null): rows with active[b] == 0 pass (dh, dc) through: dgates = 0, dc_prev = dc_next, dh_pass = dh.
-__global__ void lstm_cell_bwd_kernel(const float* dh_a, long ld_a, const float* dh_b, long ld_b, const float* dc_next, const float* pre,
-                                     const float* c_prev, const uint8_t* keep, float scale, const uint8_t* active, int B, int H,
-                                     float* dgates, float* dc_prev, float* dh_pass) {
-    const long n = (long)B * H;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(i % H), b = (int)(i / H);
-        float dh = dh_a[(long)b * ld_a + j];
-        if (dh_b) dh += dh_b[(long)b * ld_b + j];
-        const float dcn = dc_next[i];
-        float* dg = dgates + (long)b * 4 * H;
-        if (active && !active[b]) {
-            dg[j] = dg[H + j] = dg[2 * H + j] = dg[3 * H + j] = 0.f;
-            dc_prev[i] = dcn;
-            if (dh_pass) dh_pass[i] = dh;
-            continue;
-        }
-        const float* p = pre + (long)b * 4 * H;
-        const float ig = 1.f / (1.f + expf(-p[j])), fg = 1.f / (1.f + expf(-p[H + j])), gg = tanhf(p[2 * H + j]), og = 1.f / (1.f + expf(-p[3 * H + j]));
-        const float cp = c_prev[i];
-        const float c = fg * cp + ig * gg, tc = tanhf(c);
-        if (keep) dh = keep[i] ? dh * scale : 0.f;
-        const float d_o = dh * tc;
-        const float dc = dh * og * (1.f - tc * tc) + dcn;
-        dg[j] = dc * gg * ig * (1.f - ig);
-        dg[H + j] = dc * cp * fg * (1.f - fg);
-        dg[2 * H + j] = dc * ig * (1.f - gg * gg);
-        dg[3 * H + j] = d_o * og * (1.f - og);
-        dc_prev[i] = dc * fg;
-        if (dh_pass) dh_pass[i] = 0.f;
-    }
-}
-
-// ---- attention step backward, part 1: one workgroup per batch row --------------------------------------------------------
-// dw[l] = dw_next[l] + G[l] + sum_e dctx[e] memory[l][e];  dmemory[l][:] += w[l] dctx;  de[l] = w[l] (dw[l] - sum_l' w dw)
-__global__ __launch_bounds__(256) void attn_bwd_weights_kernel(const float* dctx_a, long ld_a, const float* dctx_b, long ld_b, const float* dctx_c,
-                                                               long ld_c, const float* dw_next, const float* G, const float* memory,
-                                                               const float* w, int L, int E, float* dmemory, float* de, float* dctx_sum) {
-    extern __shared__ float sm[];   // dctx [E], dw [L], red [256]
-    float* dc = sm; float* dw = sm + E; float* red = dw + L;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int e = tid; e < E; e += 256) {
-        float v = dctx_a[(long)b * ld_a + e];
-        if (dctx_b) v += dctx_b[(long)b * ld_b + e];
-        if (dctx_c) v += dctx_c[(long)b * ld_c + e];
-        dc[e] = v;
-        if (dctx_sum) dctx_sum[(long)b * E + e] = v;
-    }
-    __syncthreads();
-    const float* mb = memory + (long)b * L * E;
-    float* dmb = dmemory + (long)b * L * E;
-    const float* wb = w + (long)b * L;
-    for (int l = tid >> 5; l < L; l += 8) {   // 8 groups of 32 lanes, one position each
-        float acc = 0.f;
-        const float wl = wb[l];
-        for (int e = tid & 31; e < E; e += 32) {
-            acc += dc[e] * mb[(long)l * E + e];
-            dmb[(long)l * E + e] += wl * dc[e];
-        }
-        for (int o = 16; o > 0; o >>= 1) acc += __shfl_down(acc, o, 32);
-        if ((tid & 31) == 0) dw[l] = acc + dw_next[(long)b * L + l] + G[(long)b * L + l];
-    }
-    __syncthreads();
-    float part = 0.f;
-    for (int l = tid; l < L; l += 256) part += wb[l] * dw[l];
-    red[tid] = part;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    const float s = red[0];
-    for (int l = tid; l < L; l += 256) de[(long)b * L + l] = wb[l] * (dw[l] - s);
-}
-
-// location convolution forward, channels-last: locf[(b,l)][f] = sum_{c,k} in_c[b][l + k - pad] lw[f][c][k]   (in_0 = w_prev, in_1 = w_cum_prev)
-__global__ void loc_conv_fwd_kernel(const float* w_prev, const float* w_cum, const float* lw, int B, int L, int F, int k, float* locf) {
-    const int pad = (k - 1) / 2;
-    const long n = (long)B * L * F;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int f = (int)(i % F);
-        const long bl = i / F;
-        const int l = (int)(bl % L), b = (int)(bl / L);
-        float acc = 0.f;
-        for (int c = 0; c < 2; ++c) {
-            const float* x = (c == 0 ? w_prev : w_cum) + (long)b * L;
-            for (int j = 0; j < k; ++j) {
-                const int p = l + j - pad;
-                if (p >= 0 && p < L) acc += x[p] * lw[((long)f * 2 + c) * k + j];
-            }
-        }
-        locf[i] = acc;
-    }
-}
-
-// u = q[b] + locd[(b,l)] + pm[(b,l)]; th = tanh(u); du = de v (1 - th^2); dpm += du; per (b): dq[a] = sum_l du, dv_acc[b][a] += sum_l de th
-__global__ __launch_bounds__(256) void attn_bwd_energy_kernel(const float* q, const float* locd, const float* pm, const float* v, const float* de,
-                                                              int L, int a, float* du, float* dpm, float* dq, float* dv_acc) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int d = tid; d < a; d += 256) {
-        const float qd = q[(long)b * a + d], vd = v[d];
-        float sq = 0.f, sv = 0.f;
-        for (int l = 0; l < L; ++l) {
-            const long o = ((long)b * L + l) * a + d;
-            const float th = tanhf(qd + locd[o] + pm[o]);
-            const float e = de[(long)b * L + l];
-            const float g = e * vd * (1.f - th * th);
-            du[o] = g;
-            dpm[o] += g;
-            sq += g; sv += e * th;
-        }
-        dq[(long)b * a + d] = sq;
-        dv_acc[(long)b * a + d] += sv;
-    }
-}
-
-// location convolution backward: dloc_in[b][c][l] = sum_{f,j} dlocf[(b, l - j + pad)][f] lw[f][c][j];
-// dlw_acc[b][f][c][j] += sum_l dlocf[(b,l)][f] in_c[b][l + j - pad]     (per-row accumulators: fixed summation order)
-__global__ __launch_bounds__(256) void loc_conv_bwd_kernel(const float* dlocf, const float* w_prev, const float* w_cum, const float* lw, int L, int F,
-                                                           int k, float* dw_prev_out, float* G, float* dlw_acc) {
-    const int b = blockIdx.x, tid = threadIdx.x, pad = (k - 1) / 2;
-    const float* dl = dlocf + (long)b * L * F;
-    for (int i = tid; i < 2 * L; i += 256) {
-        const int c = i / L, l = i - c * L;
-        float acc = 0.f;
-        for (int j = 0; j < k; ++j) {
-            const int p = l - j + pad;
-            if (p < 0 || p >= L) continue;
-            for (int f = 0; f < F; ++f) acc += dl[(long)p * F + f] * lw[((long)f * 2 + c) * k + j];
-        }
-        if (c == 0) dw_prev_out[(long)b * L + l] = acc;
-        else G[(long)b * L + l] += acc;
-    }
-    for (int i = tid; i < F * 2 * k; i += 256) {
-        const int j = i % k, c = (i / k) % 2, f = i / (2 * k);
-        const float* x = (c == 0 ? w_prev : w_cum) + (long)b * L;
-        float acc = 0.f;
-        for (int l = 0; l < L; ++l) {
-            const int p = l + j - pad;
-            if (p >= 0 && p < L) acc += dl[(long)l * F + f] * x[p];
-        }
-        dlw_acc[(long)b * F * 2 * k + i] += acc;
-    }
-}
 
 // generic elementwise: y[r][c] = alpha * a[r][c] + beta * b[r][c]   (b may be null), each with its own leading dimension
 __global__ void axpby_kernel(const float* a, long lda, float alpha, const float* b, long ldb, float beta, float* y, long ldy, long rows, int cols) {
@@ -673,46 +528,6 @@ int gvx_train_axpby(const float* a, long lda, float alpha, const float* b, long 
     TR_TRY(hipGetLastError());
     return GVX_OK;
 }
-int gvx_train_lstm_cell_backward(const float* dh_a, long ld_a, const float* dh_b, long ld_b, const float* dc_next, const float* pre,
-                                 const float* c_prev, const uint8_t* keep, float scale, const uint8_t* active, int B, int H, float* dgates,
-                                 float* dc_prev, float* dh_pass, void* stream) {
-    if (!dh_a || !dc_next || !pre || !c_prev || !dgates || !dc_prev || B < 1 || H < 1) return tfail(GVX_ERR_INVALID_ARG, "lstm_cell_backward: bad argument");
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(blocks_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dh_a, ld_a, dh_b, ld_b, dc_next, pre,
-                       c_prev, keep, scale, active, B, H, dgates, dc_prev, dh_pass);
-    TR_TRY(hipGetLastError());
-    return GVX_OK;
-}
-int gvx_train_attention_weights_backward(const float* dctx_a, long ld_a, const float* dctx_b, long ld_b, const float* dctx_c, long ld_c,
-                                         const float* dw_next, const float* G, const float* memory, const float* w, int B, int L, int E,
-                                         float* dmemory, float* de, float* dctx_sum, void* stream) {
-    if (!dctx_a || !dw_next || !G || !memory || !w || !dmemory || !de || B < 1 || L < 1 || E < 1) return tfail(GVX_ERR_INVALID_ARG, "attention_weights_backward: bad argument");
-    const size_t lds = (size_t)(E + L + 256) * sizeof(float);
-    if (lds > 64 * 1024) return tfail(GVX_ERR_UNSUPPORTED, "attention_weights_backward: L + E too large for one workgroup's LDS");
-    hipLaunchKernelGGL(attn_bwd_weights_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dctx_a, ld_a, dctx_b, ld_b, dctx_c, ld_c, dw_next, G,
-                       memory, w, L, E, dmemory, de, dctx_sum);
-    TR_TRY(hipGetLastError());
-    return GVX_OK;
-}
-int gvx_train_location_conv_forward(const float* w_prev, const float* w_cum, const float* lw, int B, int L, int F, int k, float* locf, void* stream) {
-    if (!w_prev || !w_cum || !lw || !locf || B < 1 || L < 1 || F < 1 || k < 1 || !(k & 1)) return tfail(GVX_ERR_INVALID_ARG, "location_conv_forward: bad argument");
-    hipLaunchKernelGGL(loc_conv_fwd_kernel, dim3(blocks_for((long)B * L * F)), dim3(256), 0, (hipStream_t)stream, w_prev, w_cum, lw, B, L, F, k, locf);
-    TR_TRY(hipGetLastError());
-    return GVX_OK;
-}
-int gvx_train_attention_energy_backward(const float* q, const float* locd, const float* pm, const float* v, const float* de, int B, int L, int a,
-                                        float* du, float* dpm, float* dq, float* dv_acc, void* stream) {
-    if (!q || !locd || !pm || !v || !de || !du || !dpm || !dq || !dv_acc || B < 1 || L < 1 || a < 1) return tfail(GVX_ERR_INVALID_ARG, "attention_energy_backward: bad argument");
-    hipLaunchKernelGGL(attn_bwd_energy_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, locd, pm, v, de, L, a, du, dpm, dq, dv_acc);
-    TR_TRY(hipGetLastError());
-    return GVX_OK;
-}
-int gvx_train_location_conv_backward(const float* dlocf, const float* w_prev, const float* w_cum, const float* lw, int B, int L, int F, int k,
-                                     float* dw_prev_out, float* G, float* dlw_acc, void* stream) {
-    if (!dlocf || !w_prev || !w_cum || !lw || !dw_prev_out || !G || !dlw_acc || B < 1) return tfail(GVX_ERR_INVALID_ARG, "location_conv_backward: bad argument");
-    hipLaunchKernelGGL(loc_conv_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dlocf, w_prev, w_cum, lw, L, F, k, dw_prev_out, G, dlw_acc);
-    TR_TRY(hipGetLastError());
-    return GVX_OK;
-}
 int gvx_train_relu_dropout_backward(const float* dy, const float* act_out, const uint8_t* keep, float scale, long n, float* dz, void* stream) {
     if (!dy || !act_out || !keep || !dz || n < 1) return tfail(GVX_ERR_INVALID_ARG, "relu_dropout_backward: bad argument");
     hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dy, act_out, keep, scale, n, dz);
@@ -772,6 +587,7 @@ namespace gvx {
 namespace {
 
 constexpr int BP_THREADS = 256;
+#define TR_STAMP(flag, k, i) do { if (flag) GVX_STAMP(k, i); } while (0)
 constexpr int BP_GMAX = 8;   // position chunks per batch row
 
 inline int bptt_chunks(int L) { int g = (L + 3) / 4; return g < 1 ? 1 : (g > BP_GMAX ? BP_GMAX : g); }
@@ -792,6 +608,7 @@ struct BpttAttn {
     float* dctx_out;                          // [B][E] (dctx_all[t])
     float* dpm;                               // [B][L][a]  accumulated
     float* dv_acc; float* dld_acc; float* dlw_acc;   // [B][G][a], [B][G][a][F], [B][G][F * 2 * kl]  accumulated
+    int stamp;                                // stamps build: this launch records its phase times
 };
 
 // LDS rows of the location filters are FS = 32 floats whatever F is (zeros past F): every loop over filters is a compile-time
@@ -800,33 +617,62 @@ constexpr int BA_THREADS = 512;
 constexpr int BA_FS = 32;
 inline size_t bptt_attn_lds_floats(int L, int E, int a, int F, int kl, int G) {
     const int CH = (L + G - 1) / G;
-    return (size_t)E + L + BA_THREADS + 2 * (CH + kl - 1) + (size_t)2 * kl * (BA_FS + 1) + (size_t)a * (BA_FS + 1) + (size_t)CH * BA_FS + CH +
+    return (size_t)E + 2 * L + BA_THREADS + 2 * (CH + kl - 1) + (size_t)2 * kl * (BA_FS + 1) + (size_t)a * (BA_FS + 1) + (size_t)CH * BA_FS + CH +
            (size_t)2 * CH * a + (size_t)CH * BA_FS + (size_t)CH * 2 * kl + 8;
 }
 
 __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
 __global__ __launch_bounds__(BA_THREADS) void bptt_attention_kernel(BpttAttn p) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int L = p.L, E = p.E, a = p.a, F = p.F, kl = p.kl, G = p.G, pad = (kl - 1) / 2;
     constexpr int FS = BA_FS, LDF = BA_FS + 1;
     const int CH = (L + G - 1) / G, l0 = g * CH;
     const int n = max(0, min(L, l0 + CH) - l0);   // positions of this chunk (0: the chunk only passes its partial buffers on)
     const int LW = CH + kl - 1;
-    float* dc = sm;                    // [E]
+    float* locf = sm;                  // [CH][FS]        zeros past F          (16-byte aligned rows: read as float4)
+    float* dlocf = locf + CH * FS;     // [CH][FS]
+    float* dc = dlocf + CH * FS;       // [E]
     float* dwg = dc + E;               // [L]   dw_next + G of the whole row
-    float* red = dwg + L;              // [BA_THREADS]
+    float* wrow = dwg + L;             // [L]   alignment of step t
+    float* red = wrow + L;             // [BA_THREADS]
     float* win = red + BA_THREADS;     // [2][LW] previous / cumulative weights at positions l0 - pad ...
     float* lws = win + 2 * LW;         // [2 kl][FS + 1]  lw[f][c][j] at (c kl + j, f), zeros past F
     float* lds_ = lws + 2 * kl * LDF;  // [a][FS + 1]     zeros past F
-    float* locf = lds_ + a * LDF;      // [CH][FS]        zeros past F
-    float* des = locf + CH * FS;       // [CH]
+    float* des = lds_ + a * LDF;       // [CH]
     float* du = des + CH;              // [CH][a]
     float* dvt = du + CH * a;          // [CH][a]
-    float* dlocf = dvt + CH * a;       // [CH][FS]
-    float* t1 = dlocf + CH * FS;       // [CH][2][kl]
+    float* t1 = dvt + CH * a;          // [CH][2][kl]
+    TR_STAMP(p.stamp, 0, 0);
 
+    // ---- every global operand that does not depend on this launch's arithmetic is requested up front (a dependent round trip
+    // to memory the previous launch wrote costs ~1 us; the first version of this kernel had a dozen of them in a row)
+    constexpr int NBE = 8, NBD = 2, NBC = 4;   // items per thread and batch: energies, dense-gradient groups, conv-gradient items
+    const int n_en = n * a, n_dg = a * (FS / 8), n_cv = F * 2 * kl;
+    float e_pm[NBE], e_dpm[NBE];
+#pragma unroll
+    for (int u = 0; u < NBE; ++u) {
+        const int i = tid + u * BA_THREADS;
+        e_pm[u] = e_dpm[u] = 0.f;
+        if (i < n_en) { const int li = i / a, d = i - li * a; const long o = ((long)b * L + l0 + li) * a + d; e_pm[u] = p.pm[o]; e_dpm[u] = p.dpm[o]; }
+    }
+    float* dldb = p.dld_acc + ((long)b * G + g) * a * F;
+    float d_old[NBD][8];
+#pragma unroll
+    for (int u = 0; u < NBD; ++u) {
+        const int grp = tid + u * BA_THREADS, d = grp >> 2, f0 = (grp & 3) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d_old[u][k] = (grp < n_dg && f0 + k < F) ? dldb[(long)d * F + f0 + k] : 0.f;
+    }
+    float* dlwb = p.dlw_acc + ((long)b * G + g) * F * 2 * kl;
+    float c_old[NBC];
+#pragma unroll
+    for (int u = 0; u < NBC; ++u) { const int i = tid + u * BA_THREADS; c_old[u] = i < n_cv ? dlwb[i] : 0.f; }
+    const long part_o = ((long)b * G + g) * L;
+    float dv_old = 0.f, gq_ = 0.f, gv_ = 0.f;
+    if (tid < a) { dv_old = p.dv_acc[((long)b * G + g) * a + tid]; }
+    if (BA_THREADS % a == 0) { gq_ = p.q[(long)b * a + tid % a]; gv_ = p.v[tid % a]; }
     for (int e = tid; e < E; e += BA_THREADS) {
         float v = p.dhc_ctx[(long)b * p.dhc_ld + e] + p.yd0[(long)b * p.yd_ld + p.yd_ctx + e] + p.yd1[(long)b * p.yd_ld + p.yd_ctx + e];
         if (p.ya0) v += p.ya0[(long)b * p.ya_ld + e] + p.ya1[(long)b * p.ya_ld + e];
@@ -834,9 +680,17 @@ __global__ __launch_bounds__(BA_THREADS) void bptt_attention_kernel(BpttAttn p) 
         if (g == 0) p.dctx_out[(long)b * E + e] = v;
     }
     for (int l = tid; l < L; l += BA_THREADS) {
+        float pd[BP_GMAX], pg[BP_GMAX];
+#pragma unroll
+        for (int gg = 0; gg < BP_GMAX; ++gg) {
+            pd[gg] = gg < G ? p.dw_in[((long)b * G + gg) * L + l] : 0.f;
+            pg[gg] = gg < G ? p.gc_in[((long)b * G + gg) * L + l] : 0.f;
+        }
         float s = 0.f;
-        for (int gg = 0; gg < G; ++gg) s += p.dw_in[((long)b * G + gg) * L + l] + p.gc_in[((long)b * G + gg) * L + l];
+#pragma unroll
+        for (int gg = 0; gg < BP_GMAX; ++gg) s += pd[gg] + pg[gg];
         dwg[l] = s;
+        wrow[l] = p.w[(long)b * L + l];
     }
     for (int i = tid; i < 2 * LW; i += BA_THREADS) {
         const int c = i / LW, ii = i - c * LW, l = l0 + ii - pad;
@@ -853,16 +707,18 @@ __global__ __launch_bounds__(BA_THREADS) void bptt_attention_kernel(BpttAttn p) 
         lds_[d * LDF + f] = f < F ? p.ld[(long)d * F + f] : 0.f;
     }
     __syncthreads();
+    TR_STAMP(p.stamp, 0, 1);
     // s = sum_l w_l dw_l = w . (dw_next + G) + dctx . ctx(t)
     {
         float part = 0.f;
         for (int e = tid; e < E; e += BA_THREADS) part += dc[e] * p.ctx[(long)b * p.ctx_bs + e];
-        for (int l = tid; l < L; l += BA_THREADS) part += p.w[(long)b * L + l] * dwg[l];
+        for (int l = tid; l < L; l += BA_THREADS) part += wrow[l] * dwg[l];
         red[tid] = part;
         __syncthreads();
         for (int o = BA_THREADS / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     }
     const float ssum = red[0];
+    TR_STAMP(p.stamp, 0, 2);
     // dw and de of the chunk's positions: one wave per position, lanes over the memory channels
     {
         const int wave = tid >> 6, lane = tid & 63;
@@ -872,9 +728,10 @@ __global__ __launch_bounds__(BA_THREADS) void bptt_attention_kernel(BpttAttn p) 
 #pragma unroll 8
             for (int e = lane; e < E; e += 64) acc += dc[e] * mrow[e];
             for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-            if (lane == 0) des[li] = p.w[(long)b * L + l0 + li] * (acc + dwg[l0 + li] - ssum);
+            if (lane == 0) des[li] = wrow[l0 + li] * (acc + dwg[l0 + li] - ssum);
         }
     }
+    TR_STAMP(p.stamp, 0, 3);
     // location features of the chunk (recomputed): locf[l][f] = sum_{c,j} in_c[l + j - pad] lw[f][c][j]
     for (int i = tid; i < n * FS; i += BA_THREADS) {
         const int li = i >> 5, f = i & (FS - 1);
@@ -886,50 +743,82 @@ __global__ __launch_bounds__(BA_THREADS) void bptt_attention_kernel(BpttAttn p) 
         locf[i] = acc;   // (filters past F: zero weights -> 0)
     }
     __syncthreads();
+    TR_STAMP(p.stamp, 0, 4);
     // energies backwards: u = q + locf ld^T + pm, th = tanh(u), du = de v (1 - th^2).  A thread keeps the dense row of its
     // attention dim in registers while that dim does not change (a | 512: never)
     {
         float ldr[FS];
         int d_have = -1;
-        float qd = 0.f, vd = 0.f;
-        for (int i = tid; i < n * a; i += BA_THREADS) {
-            const int li = i / a, d = i - li * a;
-            if (d != d_have) {
+        float qd = gq_, vd = gv_;
+        for (int i0 = tid; i0 < n_en; i0 += NBE * BA_THREADS) {
+            if (i0 != tid) {   // later batches (more than 8 items per thread): their operands are requested here
 #pragma unroll
-                for (int f = 0; f < FS; ++f) ldr[f] = lds_[d * LDF + f];
-                qd = p.q[(long)b * a + d]; vd = p.v[d];
-                d_have = d;
+                for (int u = 0; u < NBE; ++u) {
+                    const int i = i0 + u * BA_THREADS;
+                    if (i < n_en) { const int li = i / a, d = i - li * a; const long o = ((long)b * L + l0 + li) * a + d; e_pm[u] = p.pm[o]; e_dpm[u] = p.dpm[o]; }
+                }
             }
-            const long o = ((long)b * L + l0 + li) * a + d;
-            const float pmv = p.pm[o], dpm_old = p.dpm[o];
-            float locd = 0.f;
 #pragma unroll
-            for (int f = 0; f < FS; ++f) locd += locf[li * FS + f] * ldr[f];
-            const float th = fast_tanh(qd + locd + pmv);
-            const float e_ = des[li];
-            const float gq = e_ * vd * (1.f - th * th);
-            du[i] = gq;
-            dvt[i] = e_ * th;
-            p.dpm[o] = dpm_old + gq;
+            for (int u = 0; u < NBE; ++u) {
+                const int i = i0 + u * BA_THREADS;
+                if (i < n_en) {
+                    const int li = i / a, d = i - li * a;
+                    if (d != d_have) {
+#pragma unroll
+                        for (int f = 0; f < FS; ++f) ldr[f] = lds_[d * LDF + f];
+                        if (BA_THREADS % a != 0) { qd = p.q[(long)b * a + d]; vd = p.v[d]; }
+                        d_have = d;
+                    }
+                    float locd = 0.f;
+#pragma unroll
+                    for (int f = 0; f < FS; ++f) locd += locf[li * FS + f] * ldr[f];
+                    const float th = fast_tanh(qd + locd + e_pm[u]);
+                    const float e_ = des[li];
+                    const float gq = e_ * vd * (1.f - th * th);
+                    du[i] = gq;
+                    dvt[i] = e_ * th;
+                    p.dpm[((long)b * L + l0 + li) * a + d] = e_dpm[u] + gq;
+                }
+            }
         }
     }
     __syncthreads();
+    TR_STAMP(p.stamp, 0, 5);
     for (int d = tid; d < a; d += BA_THREADS) {
+        if (d != tid) dv_old = p.dv_acc[((long)b * G + g) * a + d];
         float sq = 0.f, sv = 0.f;
 #pragma unroll 4
         for (int li = 0; li < n; ++li) { sq += du[li * a + d]; sv += dvt[li * a + d]; }
         p.dq_part[((long)b * G + g) * a + d] = sq;
-        p.dv_acc[((long)b * G + g) * a + d] += sv;
+        p.dv_acc[((long)b * G + g) * a + d] = dv_old + sv;
     }
-    for (int i = tid; i < a * F; i += BA_THREADS) {   // d location_dense[d][f] += sum_l du[l][d] locf[l][f]
-        const int d = i / F, f = i - d * F;
-        float* acc_p = p.dld_acc + ((long)b * G + g) * a * F + i;
-        const float old = *acc_p;
-        float acc = 0.f;
+    TR_STAMP(p.stamp, 0, 6);
+    // d location_dense[d][f] += sum_l du[l][d] locf[l][f]: a thread owns 8 consecutive filters of one attention dim
+    for (int g0 = tid; g0 < n_dg; g0 += NBD * BA_THREADS) {
+#pragma unroll
+        for (int u = 0; u < NBD; ++u) {
+            const int grp = g0 + u * BA_THREADS;
+            if (grp < n_dg) {
+                const int d = grp >> 2, f0 = (grp & 3) * 8;
+                if (g0 != tid) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) d_old[u][k] = f0 + k < F ? dldb[(long)d * F + f0 + k] : 0.f;
+                }
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int li = 0; li < n; ++li) acc += du[li * a + d] * locf[li * FS + f];
-        *acc_p = old + acc;
+                for (int li = 0; li < n; ++li) {
+                    const float dv_ = du[li * a + d];
+                    const float4 x0 = *reinterpret_cast<const float4*>(locf + li * FS + f0), x1 = *reinterpret_cast<const float4*>(locf + li * FS + f0 + 4);
+                    acc[0] += dv_ * x0.x; acc[1] += dv_ * x0.y; acc[2] += dv_ * x0.z; acc[3] += dv_ * x0.w;
+                    acc[4] += dv_ * x1.x; acc[5] += dv_ * x1.y; acc[6] += dv_ * x1.z; acc[7] += dv_ * x1.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (f0 + k < F) dldb[(long)d * F + f0 + k] = d_old[u][k] + acc[k];
+            }
+        }
     }
+    TR_STAMP(p.stamp, 0, 7);
     for (int i = tid; i < n * FS; i += BA_THREADS) {   // dlocf[l][f] = sum_d du[l][d] ld[d][f]
         const int li = i >> 5, f = i & (FS - 1);
         float acc = 0.f;
@@ -938,6 +827,7 @@ __global__ __launch_bounds__(BA_THREADS) void bptt_attention_kernel(BpttAttn p) 
         dlocf[i] = acc;
     }
     __syncthreads();
+    TR_STAMP(p.stamp, 0, 8);
     for (int i = tid; i < n * 2 * kl; i += BA_THREADS) {   // t1[l][c][j] = sum_f dlocf[l][f] lw[f][c][j]
         const int li = i / (2 * kl), cj = i - li * 2 * kl;
         float acc = 0.f;
@@ -945,28 +835,36 @@ __global__ __launch_bounds__(BA_THREADS) void bptt_attention_kernel(BpttAttn p) 
         for (int f = 0; f < FS; ++f) acc += dlocf[li * FS + f] * lws[cj * LDF + f];
         t1[i] = acc;
     }
-    for (int i = tid; i < F * 2 * kl; i += BA_THREADS) {   // d location_conv[f][c][j] += sum_l dlocf[l][f] in_c[l + j - pad]
-        const int f = i / (2 * kl), cj = i - f * 2 * kl, c = cj / kl, j = cj - c * kl;
-        float* acc_p = p.dlw_acc + ((long)b * G + g) * F * 2 * kl + i;
-        const float old = *acc_p;
-        float acc = 0.f;
+    TR_STAMP(p.stamp, 0, 9);
+    // d location_conv[f][c][j] += sum_l dlocf[l][f] in_c[l + j - pad]
+    for (int i0 = tid; i0 < n_cv; i0 += NBC * BA_THREADS) {
+#pragma unroll
+        for (int u = 0; u < NBC; ++u) {
+            const int i = i0 + u * BA_THREADS;
+            if (i < n_cv) {
+                if (i0 != tid) c_old[u] = dlwb[i];
+                const int f = i / (2 * kl), cj = i - f * 2 * kl, c = cj / kl, j = cj - c * kl;
+                float acc = 0.f;
 #pragma unroll 4
-        for (int li = 0; li < n; ++li) acc += dlocf[li * FS + f] * win[c * LW + li + j];
-        *acc_p = old + acc;
+                for (int li = 0; li < n; ++li) acc += dlocf[li * FS + f] * win[c * LW + li + j];
+                dlwb[i] = c_old[u] + acc;
+            }
+        }
     }
     __syncthreads();
+    TR_STAMP(p.stamp, 0, 10);
     // d in_c[l'] = sum over the chunk's l of t1[l][c][l' - l + pad]: c = 0 -> previous weights (next step's dw_next),
     // c = 1 -> cumulative weights (added to G for all earlier steps)
     for (int i = tid; i < 2 * L; i += BA_THREADS) {
         const int c = i / L, lt = i - c * L;
-        const long o = ((long)b * G + g) * L + lt;
-        const float old = c == 0 ? 0.f : p.gc_in[o];
+        const float old = c == 0 ? 0.f : p.gc_in[part_o + lt];
         float acc = 0.f;
         const int li_lo = max(0, lt + pad - (kl - 1) - l0), li_hi = min(n, lt + pad - l0 + 1);   // 0 <= lt - (l0 + li) + pad < kl
         for (int li = li_lo; li < li_hi; ++li) acc += t1[(li * 2 + c) * kl + lt - (l0 + li) + pad];
-        if (c == 0) p.dw_out[o] = acc;
-        else p.gc_out[o] = old + acc;
+        if (c == 0) p.dw_out[part_o + lt] = acc;
+        else p.gc_out[part_o + lt] = old + acc;
     }
+    TR_STAMP(p.stamp, 0, 11);
 }
 
 struct BpttCells {
@@ -976,7 +874,7 @@ struct BpttCells {
     const float* yd0; const float* yd1; int yd_ld;      // decoder-cell products of step t: h_a columns at 0, h_d columns at A + E
     const float* ya0; const float* ya1; int ya_ld;      // attention-cell products of step t + 1 (nullptr at t = T - 1): h_a columns at E
     const float* dq_part; const float* wq;              // [B][G][a], [a][A]
-    const float* pre_a; const float* c_a; const uint8_t* keep_a; float scale_a;   // step t: [B][4A], [B][A], [B][A]
+    const float* pre_a; const float* c_a; const uint8_t* keep_a; float scale_a;   // step t: [B][A][4], [B][A], [B][A]
     float* dc_a;                                        // [B][A] state
     float* dga; float* xa_blk; float* dq_out;           // dga_all[t] [B][4A], blocked copy, dq_all[t] [B][a]
     // decoder cell of step t - 1 (dec == 0: skipped)
@@ -1023,9 +921,9 @@ __global__ __launch_bounds__(BP_THREADS) void bptt_cells_kernel(BpttCells p) {
         for (int d = 0; d < p.a; ++d) hq += dq[d] * p.wq[(long)d * A + j];
         dh += hq;
         dh = p.keep_a[(long)b * A + j] ? dh * p.scale_a : 0.f;
-        const float* pr = p.pre_a + (long)b * 4 * A;
+        const float4 pr = *reinterpret_cast<const float4*>(p.pre_a + ((long)b * A + j) * 4);
         float gi, gf, gg, go, dcp;
-        lstm_cell_bwd_one(dh, p.dc_a[(long)b * A + j], pr[j], pr[A + j], pr[2 * A + j], pr[3 * A + j], p.c_a[(long)b * A + j], gi, gf, gg, go, dcp);
+        lstm_cell_bwd_one(dh, p.dc_a[(long)b * A + j], pr.x, pr.y, pr.z, pr.w, p.c_a[(long)b * A + j], gi, gf, gg, go, dcp);
         p.dc_a[(long)b * A + j] = dcp;
         const float gv[4] = {gi, gf, gg, go};
 #pragma unroll
@@ -1040,9 +938,9 @@ __global__ __launch_bounds__(BP_THREADS) void bptt_cells_kernel(BpttCells p) {
         float dh = p.dhc_hd[(long)b * p.dhc_ld + jd];
         if (p.have_yd) dh += p.yd0[(long)b * p.yd_ld + A + p.E + jd] + p.yd1[(long)b * p.yd_ld + A + p.E + jd];
         dh = p.keep_d[(long)b * D + jd] ? dh * p.scale_d : 0.f;
-        const float* pr = p.pre_d + (long)b * 4 * D;
+        const float4 pr = *reinterpret_cast<const float4*>(p.pre_d + ((long)b * D + jd) * 4);
         float gi, gf, gg, go, dcp;
-        lstm_cell_bwd_one(dh, p.dc_d[(long)b * D + jd], pr[jd], pr[D + jd], pr[2 * D + jd], pr[3 * D + jd], p.c_d[(long)b * D + jd], gi, gf, gg, go, dcp);
+        lstm_cell_bwd_one(dh, p.dc_d[(long)b * D + jd], pr.x, pr.y, pr.z, pr.w, p.c_d[(long)b * D + jd], gi, gf, gg, go, dcp);
         p.dc_d[(long)b * D + jd] = dcp;
         const float gv[4] = {gi, gf, gg, go};
 #pragma unroll
@@ -1207,6 +1105,7 @@ int gvx_train_decoder_bptt(const gvx_bptt_decoder_args* ap, void* workspace, siz
             q.dq_part = ws + pl.dqp;
             q.dctx_out = a.dctx_all + (size_t)t * B * E;
             q.dpm = a.dpm; q.dv_acc = ws + pl.dv_acc; q.dld_acc = ws + pl.dld_acc; q.dlw_acc = ws + pl.dlw_acc;
+            q.stamp = t == T / 2;
             hipLaunchKernelGGL(bptt_attention_kernel, dim3(G, B), dim3(BA_THREADS), lds_attn, s, q);
         }
         {
@@ -1292,58 +1191,111 @@ struct EncBptt {
     float* dc;               // [2][B][H] state
     float* dg_pos;           // [2][B][L][4H]  gate gradients filed under the position they belong to (zeros elsewhere)
     float* hprev_pos;        // [2][B][L][H]   the previous hidden state of that position
+    int stamp;
 };
 
 __global__ __launch_bounds__(256) void encoder_bptt_step_kernel(EncBptt p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H = p.H, H4 = 4 * H, L = p.L, B = p.B;
     const int dir = blockIdx.y, j0 = blockIdx.x * EB_UJ, tid = threadIdx.x;
+    TR_STAMP(p.stamp, 1, 0);
+    const int r = tid & 7, b0 = tid >> 3;
+    const int len0 = b0 < B ? p.lengths[b0] : 0;   // (requested before the staging loads: the row's addresses depend on it)
     float* wcol = sm;                    // [UJ][4H]  column j of W_hh = row j of its transpose
     float* wrow = sm + EB_UJ * H4;       // [4][UJ][H] rows (q H + j) of W_hh
     const float* whh = p.w_hh + (size_t)dir * H4 * H;
     const float* whht = p.w_hh_t + (size_t)dir * H * H4;
-    for (int i = tid; i < EB_UJ * H4; i += 256) { const int jl = i / H4, n = i - jl * H4; wcol[i] = j0 + jl < H ? whht[(size_t)(j0 + jl) * H4 + n] : 0.f; }
-    for (int i = tid; i < 4 * EB_UJ * H; i += 256) {
-        const int k = i % H, qj = i / H, jl = qj % EB_UJ, q = qj / EB_UJ;
-        wrow[i] = j0 + jl < H ? whh[((size_t)q * H + j0 + jl) * H + k] : 0.f;
+    // staging: rows of 4H / H floats are contiguous on both sides -> 16-byte pieces, all requested before the first LDS store
+    {
+        constexpr int NV = 8;
+        const int nc4 = EB_UJ * H4 / 4, nr4 = 4 * EB_UJ * H / 4;
+        for (int i0 = tid; i0 < nc4 + nr4; i0 += NV * 256) {
+            float4 v[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int i = i0 + u * 256;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nc4) {
+                    const int jl = i / (H4 / 4), n4 = i - jl * (H4 / 4);
+                    if (j0 + jl < H) v[u] = reinterpret_cast<const float4*>(whht + (size_t)(j0 + jl) * H4)[n4];
+                } else if (i < nc4 + nr4) {
+                    const int ii = i - nc4, qj = ii / (H / 4), k4 = ii - qj * (H / 4), jl = qj % EB_UJ, q = qj / EB_UJ;
+                    if (j0 + jl < H) v[u] = reinterpret_cast<const float4*>(whh + ((size_t)q * H + j0 + jl) * H)[k4];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int i = i0 + u * 256;
+                if (i < nc4 + nr4) reinterpret_cast<float4*>(sm)[i] = v[u];   // (wrow starts right behind wcol)
+            }
+        }
     }
     __syncthreads();
+    TR_STAMP(p.stamp, 1, 1);
     // thread = (batch row, lane r of 8).  The 8 lanes of a row split K in float4 pieces: lane r takes the floats
     // 32 i + 4 r ... + 3, so that a row's 8 lanes read 128 contiguous bytes per instruction (global and LDS alike)
-    const int r = tid & 7;
     const bool vec_h = (H & 31) == 0;
-    for (int b = tid >> 3; b < B; b += 32) {
-        const int len = p.lengths[b];
+    for (int b = b0; b < B; b += 32) {
+        const int len = b == b0 ? len0 : p.lengths[b];
         const bool active = p.s < len;
         const int t_idx = dir == 0 ? p.s : max(len - 1 - p.s, 0);
         const int p_idx = dir == 0 ? t_idx - 1 : t_idx + 1;
         const bool has_prev = active && p.s > 0;
         const float* hp = p.memory + ((size_t)b * L + min(max(p_idx, 0), L - 1)) * 2 * H + dir * H;
         const float* dgi = p.dg_in + ((size_t)dir * B + b) * H4;
+        // operands of the cell (lanes r < UJ own unit j0 + r): requested now, used after the dot products
+        const int j = j0 + r;
+        const bool own = r < EB_UJ && j < H;
+        const size_t sj = ((size_t)dir * B + b) * H + (own ? j : 0);
+        float o_pass = 0.f, o_dmem = 0.f, o_dc = 0.f, o_cp = 0.f, o_hp = 0.f, o_x0 = 0.f, o_x1 = 0.f, o_x2 = 0.f, o_x3 = 0.f;
+        if (own) {
+            o_pass = p.dpass_in[sj]; o_dc = p.dc[sj];
+            if (active) {
+                o_dmem = p.dmemory[((size_t)b * L + t_idx) * 2 * H + dir * H + j];
+                const float* xg = p.xg + (((size_t)dir * B + b) * L + t_idx) * H4;
+                o_x0 = xg[j]; o_x1 = xg[H + j]; o_x2 = xg[2 * H + j]; o_x3 = xg[3 * H + j];
+                if (has_prev) { o_cp = p.c_enc[((size_t)b * L + p_idx) * 2 * H + dir * H + j]; o_hp = hp[j]; }
+            }
+        }
         float sdh[EB_UJ], sp[4][EB_UJ];
 #pragma unroll
         for (int jl = 0; jl < EB_UJ; ++jl) { sdh[jl] = 0.f; sp[0][jl] = sp[1][jl] = sp[2][jl] = sp[3][jl] = 0.f; }
-#pragma unroll 4
-        for (int i = 0; i < H4 / 32; ++i) {
-            const float4 x = *reinterpret_cast<const float4*>(dgi + 32 * i + 4 * r);
+        constexpr int NX = 16;   // float4 pieces of the row requested together
+        for (int ib = 0; ib < H4 / 32; ib += NX) {
+            float4 x[NX];
 #pragma unroll
-            for (int jl = 0; jl < EB_UJ; ++jl) {
-                const float4 w = *reinterpret_cast<const float4*>(wcol + jl * H4 + 32 * i + 4 * r);
-                sdh[jl] += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+            for (int u = 0; u < NX; ++u) x[u] = ib + u < H4 / 32 ? *reinterpret_cast<const float4*>(dgi + 32 * (ib + u) + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                if (ib + u < H4 / 32) {
+#pragma unroll
+                    for (int jl = 0; jl < EB_UJ; ++jl) {
+                        const float4 w = *reinterpret_cast<const float4*>(wcol + jl * H4 + 32 * (ib + u) + 4 * r);
+                        sdh[jl] += x[u].x * w.x + x[u].y * w.y + x[u].z * w.z + x[u].w * w.w;
+                    }
+                }
             }
         }
+        TR_STAMP(p.stamp, 1, 2);
         if (has_prev) {
             if (vec_h) {
-#pragma unroll 2
-                for (int i = 0; i < H / 32; ++i) {
-                    const float4 x = *reinterpret_cast<const float4*>(hp + 32 * i + 4 * r);
+                constexpr int NHX = 8;
+                for (int ib = 0; ib < H / 32; ib += NHX) {
+                    float4 x[NHX];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int u = 0; u < NHX; ++u) x[u] = ib + u < H / 32 ? *reinterpret_cast<const float4*>(hp + 32 * (ib + u) + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int jl = 0; jl < EB_UJ; ++jl) {
-                            const float4 w = *reinterpret_cast<const float4*>(wrow + (q * EB_UJ + jl) * H + 32 * i + 4 * r);
-                            sp[q][jl] += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+                    for (int u = 0; u < NHX; ++u) {
+                        if (ib + u < H / 32) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int jl = 0; jl < EB_UJ; ++jl) {
+                                    const float4 w = *reinterpret_cast<const float4*>(wrow + (q * EB_UJ + jl) * H + 32 * (ib + u) + 4 * r);
+                                    sp[q][jl] += x[u].x * w.x + x[u].y * w.y + x[u].z * w.z + x[u].w * w.w;
+                                }
                         }
+                    }
                 }
             } else {
                 for (int k = r; k < H; k += 8) {
@@ -1355,6 +1307,7 @@ __global__ __launch_bounds__(256) void encoder_bptt_step_kernel(EncBptt p) {
                 }
             }
         }
+        TR_STAMP(p.stamp, 1, 3);
         float my_dh = 0.f, my_pre[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int jl = 0; jl < EB_UJ; ++jl) {
@@ -1366,30 +1319,26 @@ __global__ __launch_bounds__(256) void encoder_bptt_step_kernel(EncBptt p) {
             }
             if (r == jl) { my_dh = v0; my_pre[0] = v1; my_pre[1] = v2; my_pre[2] = v3; my_pre[3] = v4; }
         }
-        const int j = j0 + r;
-        if (r < EB_UJ && j < H) {
-            const size_t sj = ((size_t)dir * B + b) * H + j;
-            float dh = my_dh + p.dpass_in[sj];
-            if (active) dh += p.dmemory[((size_t)b * L + t_idx) * 2 * H + dir * H + j];
+        TR_STAMP(p.stamp, 1, 4);
+        if (own) {
+            const float dh = my_dh + o_pass + o_dmem;
             float* dgo = p.dg_out + ((size_t)dir * B + b) * H4;
             if (!active) {
                 dgo[j] = dgo[H + j] = dgo[2 * H + j] = dgo[3 * H + j] = 0.f;
                 p.dpass_out[sj] = dh;   // (dc stays)
             } else {
-                const float* xg = p.xg + (((size_t)dir * B + b) * L + t_idx) * H4;
-                const float cp = has_prev ? p.c_enc[((size_t)b * L + p_idx) * 2 * H + dir * H + j] : 0.f;
                 float gi, gf, gg, go, dcp;
-                lstm_cell_bwd_one(dh, p.dc[sj], xg[j] + my_pre[0], xg[H + j] + my_pre[1], xg[2 * H + j] + my_pre[2], xg[3 * H + j] + my_pre[3], cp,
-                                  gi, gf, gg, go, dcp);
+                lstm_cell_bwd_one(dh, o_dc, o_x0 + my_pre[0], o_x1 + my_pre[1], o_x2 + my_pre[2], o_x3 + my_pre[3], o_cp, gi, gf, gg, go, dcp);
                 p.dc[sj] = dcp;
                 p.dpass_out[sj] = 0.f;
                 dgo[j] = gi; dgo[H + j] = gf; dgo[2 * H + j] = gg; dgo[3 * H + j] = go;
                 float* dgp = p.dg_pos + (((size_t)dir * B + b) * L + t_idx) * H4;
                 dgp[j] = gi; dgp[H + j] = gf; dgp[2 * H + j] = gg; dgp[3 * H + j] = go;
-                p.hprev_pos[(((size_t)dir * B + b) * L + t_idx) * H + j] = has_prev ? hp[j] : 0.f;
+                p.hprev_pos[(((size_t)dir * B + b) * L + t_idx) * H + j] = o_hp;
             }
         }
     }
+    TR_STAMP(p.stamp, 1, 5);
 }
 
 // dst[d][c][r] = src[d][r][c]
@@ -1454,6 +1403,7 @@ int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const floa
         q.dg_in = ws + pl.dg + (size_t)(par ^ 1) * 2 * B * 4 * H; q.dg_out = ws + pl.dg + (size_t)par * 2 * B * 4 * H;
         q.dpass_in = ws + pl.dpass + (size_t)(par ^ 1) * 2 * B * H; q.dpass_out = ws + pl.dpass + (size_t)par * 2 * B * H;
         q.dc = ws + pl.dc; q.dg_pos = dg_pos; q.hprev_pos = hprev_pos;
+        q.stamp = st == L / 2;
         hipLaunchKernelGGL(encoder_bptt_step_kernel, dim3((H + EB_UJ - 1) / EB_UJ, 2), dim3(256), lds, s, q);
     }
     TR_TRY(hipGetLastError());
@@ -1461,3 +1411,10 @@ int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const floa
 }
 
 }  // extern "C"
+
+#ifdef GVX_STAMPS
+// diagnostic build only: phase timestamps of the flagged BPTT launches (tools/stamps_train.py)
+extern "C" int gvx_debug_read_stamps_train(unsigned long long* host96) {
+    return hipMemcpyFromSymbol(host96, HIP_SYMBOL(gvx::gvx_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : 1;
+}
+#endif

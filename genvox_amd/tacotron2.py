@@ -442,15 +442,17 @@ class Tacotron2(nn.Module):
         ha_blk = torch.empty((T + 1) * B * A, device=dev)
         c_a_all, c_d_all = torch.empty(T + 1, B, A, device=dev), torch.empty(T + 1, B, D, device=dev)
         hc_blk = torch.empty((T + 1) * B * (D + E), device=dev)
+        pre_a, pre_d = torch.empty(T, B, A, 4, device=dev), torch.empty(T, B, D, 4, device=dev)   # gate pre-activations of both cells
         _lib.check(lib.gvx_decoder_teacher_forced_train(
             self._handle, memory.data_ptr(), tok_len.data_ptr(), B, L, mel_in.data_ptr(), T, masks.data_ptr(), att_keep.data_ptr(),
             dec_keep.data_ptr(), float(mc.p_attention_dropout), float(mc.p_decoder_dropout), dec_mel.data_ptr(), gate.data_ptr(),
-            align.data_ptr(), ha_blk.data_ptr(), c_a_all.data_ptr(), c_d_all.data_ptr(), hc_blk.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            align.data_ptr(), ha_blk.data_ptr(), c_a_all.data_ptr(), c_d_all.data_ptr(), hc_blk.data_ptr(), pre_a.data_ptr(), pre_d.data_ptr(),
+            ws.data_ptr(), ws.numel(), st))
         # the rest of the tape: per-step vectors as plain rows, the Prenet activations and the processed memory
         ops = training._Ops(dev)
         export = lambda what, shape: (lambda t: (_lib.check(lib.gvx_train_export(self._handle, ws.data_ptr(), ws.numel(), B, L, T, what, t.data_ptr(), st)), t)[1])(torch.empty(*shape, device=dev))
         dec_tape = {"h_a_all": training._unblock(ops, ha_blk, T + 1, B, A), "hc_all": training._unblock(ops, hc_blk, T + 1, B, D + E),
-                    "c_a_all": c_a_all, "c_d_all": c_d_all, "frames": export(0, (T + 1, B, M)), "p1": export(1, (T + 1, B, P)),
+                    "c_a_all": c_a_all, "c_d_all": c_d_all, "pre_a": pre_a, "pre_d": pre_d, "frames": export(0, (T + 1, B, M)), "p1": export(1, (T + 1, B, P)),
                     "p2": export(2, (T + 1, B, P)), "pm": export(3, (B, L, mc.attention_dim)), "att_keep": att_keep, "dec_keep": dec_keep,
                     "prenet_keep": masks.reshape(2, T + 1, B, P), "enc_conv_out": conv_out, "enc_cell_states": enc_c}
         post_y, post_tape = training.convstack_train_forward(self, "postnet.convolutions", training.postnet_acts(self), dec_mel, post_keep)

@@ -7,14 +7,16 @@ backwards in explicit formulas - criterion, Postnet, projections, BPTT over the 
 output dropout, the location-sensitive attention with its previous / cumulative-weights path), Prenet, encoder BiLSTM with
 packed-sequence semantics, encoder convolutions, embedding - exactly as ``oracle/train_ref.py`` states them, and every
 formula runs in a HIP kernel behind the C ABI (csrc/train.hip: ``gvx_conv_bn_act_train_*``, ``gvx_train_*``; the dense
-products on the exact-fp32 MFMA GEMM of the forward path).  torch allocates, slices and reshapes.  Parameters are updated in
+products on the exact-fp32 MFMA GEMM of the forward path).  The two recurrences are one C-ABI call each
+(``gvx_train_decoder_bptt``: three launches per decoder step, ``gvx_train_encoder_lstm_bptt``: one per time step); torch
+allocates, slices and reshapes around them.  Parameters are updated in
 place in the reference's own layouts (``Adam``); the packed blob of the forward kernels is re-built before the next forward.
 
 Pinned by ``tests/golden/train_small.npz`` - the reference's own train step (all 48 parameter gradients, the gradient norm,
 every parameter after the Adam update) - and against the oracle at the default layer sizes (tests/test_training_gpu.py).
 Dropout keep masks are explicit inputs where parity is tested (uint8, the shape of the dropout's input) and drawn on the
-device otherwise.  First version: correct, not tuned (about twenty small launches per decoder step on the way back;
-0.54 s per step at 32 x 200 frames x 128 tokens, profiles/r03_train_step_timing.txt).
+device otherwise.  32 x 200 frames x 128 tokens: 0.54 s per step with the first version (host-strung primitives, host
+re-packing), about 0.035 s now (profiles/r03_train_step_timing.txt).
 """
 from __future__ import annotations
 
@@ -214,22 +216,6 @@ class _Ops:
                                             _p(out), self._ld(out), rows, cols, self.st))
         return out
 
-    def pad_cols(self, A, Kp):
-        """[M, K] -> dense [M, Kp] with zero columns appended."""
-        out = self.zeros(A.shape[0], Kp)
-        self.axpby(A, out=out[:, :A.shape[1]])
-        return out
-
-    def lstm_cell_backward(self, dh_a, dh_b, dc_next, pre, c_prev, keep, scale, active=None, want_pass=False):
-        B, H4 = pre.shape
-        H = H4 // 4
-        dgates, dc_prev = self.new(B, H4), self.new(B, H)
-        dh_pass = self.new(B, H) if want_pass else None
-        _lib.check(self.lib.gvx_train_lstm_cell_backward(
-            _p(dh_a), self._ld(dh_a), _p(dh_b), self._ld(dh_b) if dh_b is not None else 0, _p(dc_next), _p(pre.contiguous()),
-            _p(c_prev.contiguous()), _p(keep), float(scale), _p(active), B, H, _p(dgates), _p(dc_prev), _p(dh_pass), self.st))
-        return dgates, dc_prev, dh_pass
-
 
 def _unblock(ops: _Ops, blocked: torch.Tensor, n_slots: int, B: int, K: int) -> torch.Tensor:
     out = ops.new(n_slots, B, K)
@@ -285,14 +271,9 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     ha_prev = ha[:T].reshape(T * B, A)
     Wia, Wha = W("decoder.attention_rnn.weight_ih"), W("decoder.attention_rnn.weight_hh")
     Wid, Whd = W("decoder.decoder_rnn.weight_ih"), W("decoder.decoder_rnn.weight_hh")
-    ba = ops.axpby(W("decoder.attention_rnn.bias_ih")[None, :], 1.0, W("decoder.attention_rnn.bias_hh")[None, :], 1.0)[0]
-    bd = ops.axpby(W("decoder.decoder_rnn.bias_ih")[None, :], 1.0, W("decoder.decoder_rnn.bias_hh")[None, :], 1.0)[0]
-    pre_a = ops.gemm_nt(xa, Wia, bias=ba)
-    pre_a = ops.axpby(pre_a, 1.0, ops.gemm_nt(ha_prev, Wha), 1.0).reshape(T, B, 4 * A)
     xd = torch.cat((ha[1:], hc[1:, :, D:]), dim=2).reshape(T * B, A + E).contiguous()   # [h_a(t) ; ctx(t)]
     hd_prev = hc[:T, :, :D].reshape(T * B, D).contiguous()
-    pre_d = ops.gemm_nt(xd, Wid, bias=bd)
-    pre_d = ops.axpby(pre_d, 1.0, ops.gemm_nt(hd_prev, Whd), 1.0).reshape(T, B, 4 * D)
+    pre_a, pre_d = tape["pre_a"], tape["pre_d"]                   # [T, B, H, 4]: the gate pre-activations the forward computed
     wq, v = W(att + "query_layer.linear_layer.weight"), W(att + "v.linear_layer.weight")
     lw, ld = W(att + "location_layer.location_conv.conv.weight").contiguous(), W(att + "location_layer.location_dense.linear_layer.weight")
     wm = W(att + "memory_layer.linear_layer.weight")

@@ -213,14 +213,15 @@ int gvx_tacotron2_loss(const float* mel_out, const float* mel_post_out, const fl
  *   att_hidden_all [T+1][A/8][B][8]     the attention LSTM's dropped hidden state after every step (slot t + 1; slot 0 zeros)
  *                                       as k-group-blocked vectors: element (b, k) at (k / 8) * B * 8 + b * 8 + k % 8;
  *   att_cell_all, dec_cell_all [T+1][B][H]   both cells' states (slot t + 1 = after step t);
- *   dec_hidden_context_all [T+1][(D+E)/8][B][8]   [h_d ; ctx] after every step, blocked as above. */
+ *   dec_hidden_context_all [T+1][(D+E)/8][B][8]   [h_d ; ctx] after every step, blocked as above;
+ *   att_preact_all [T][B][A][4], dec_preact_all [T][B][D][4]   gate pre-activations i, f, g, o of every unit and step. */
 int gvx_encoder_lstm_forward(gvx_model* model, const float* conv_out, const int32_t* lengths, int B, int L, float* memory_out,
                              float* cell_states_out, float* input_preact_out, void* workspace, size_t workspace_bytes, void* stream);
 int gvx_decoder_teacher_forced_train(gvx_model* model, const float* memory, const int32_t* lengths, int B, int L, const float* mel_in,
                                      int T, const uint8_t* keep_masks, const uint8_t* att_keep, const uint8_t* dec_keep, float p_att,
                                      float p_dec, float* mel_out, float* gate_out, float* align_out, float* att_hidden_all,
-                                     float* att_cell_all, float* dec_cell_all, float* dec_hidden_context_all, void* workspace,
-                                     size_t workspace_bytes, void* stream);
+                                     float* att_cell_all, float* dec_cell_all, float* dec_hidden_context_all, float* att_preact_all,
+                                     float* dec_preact_all, void* workspace, size_t workspace_bytes, void* stream);
 /* Copy one of the decoder's per-call buffers out of the workspace of the last gvx_decoder_teacher_forced(_train) call with the
  * same (B, L, T), row-major: what 0 = decoder input frames [(T+1) B, n_mels] (row t B + b; frame 0 = zeros), 1 = Prenet layer-1
  * output [(T+1) B, prenet_dim], 2 = Prenet output [(T+1) B, prenet_dim], 3 = processed memory [B, L, att_dim]. */
@@ -245,9 +246,10 @@ int gvx_tacotron2_loss_backward(const float* mel_out, const float* mel_post_out,
                                 const float* gate_target, int B, int n_mels, int T, float* dmel_out, float* dmel_post_out,
                                 float* dgate_out, void* stream);
 
-/* ---- Back-propagation through time: primitives the host mirror (genvox_amd/training.py) strings together exactly as
- * oracle/train_ref.py states the training step (the reference: loss.backward(), clip_grad_norm_, Adam.step,
- * models/tts/tacotron2.py:515-522).  Row-major fp32 with explicit leading dimensions; LSTM gates in torch order i, f, g, o. */
+/* ---- The training step's whole-sequence pieces: primitives the host mirror (genvox_amd/training.py) strings together as
+ * oracle/train_ref.py states them (the reference: loss.backward(), clip_grad_norm_, Adam.step, models/tts/tacotron2.py:515-522);
+ * the two recurrences are single calls (gvx_train_decoder_bptt, gvx_train_encoder_lstm_bptt below).  Row-major fp32 with
+ * explicit leading dimensions; LSTM gates in torch order i, f, g, o. */
 /* C[m][n] = sum_k A[m * lda + k] W[n * ldw + k] (+ bias[n]), K % 4 == 0.  scratch (may be NULL): device scratch for split-K
  * partial tiles, used when the product has few output tiles and a long K. */
 int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K, const float* bias,
@@ -255,20 +257,6 @@ int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float*
 int gvx_train_transpose(const float* src, long ld_src, float* dst, long rows, int cols, long rows_padded, void* stream);
 int gvx_train_colsum(const float* X, long rows, int C, float* out, void* stream);
 int gvx_train_axpby(const float* a, long lda, float alpha, const float* b, long ldb, float beta, float* y, long ldy, long rows, int cols, void* stream);
-/* dgates [B, 4H], dc_prev [B, H] of one LSTM cell step from dh (= dh_a + dh_b) and dc_next; pre = gate pre-activations;
- * keep / scale: dropout on the cell's hidden output; active (may be NULL): rows with 0 pass (dh, dc) through (packed sequences). */
-int gvx_train_lstm_cell_backward(const float* dh_a, long ld_a, const float* dh_b, long ld_b, const float* dc_next, const float* pre,
-                                 const float* c_prev, const uint8_t* keep, float scale, const uint8_t* active, int B, int H, float* dgates,
-                                 float* dc_prev, float* dh_pass, void* stream);
-/* one decoder step of the location-sensitive attention, backwards (Attention.forward, models/tts/tacotron2.py:89-129) */
-int gvx_train_attention_weights_backward(const float* dctx_a, long ld_a, const float* dctx_b, long ld_b, const float* dctx_c, long ld_c,
-                                         const float* dw_next, const float* G, const float* memory, const float* w, int B, int L, int E,
-                                         float* dmemory, float* de, float* dctx_sum, void* stream);
-int gvx_train_location_conv_forward(const float* w_prev, const float* w_cum, const float* lw, int B, int L, int F, int k, float* locf, void* stream);
-int gvx_train_attention_energy_backward(const float* q, const float* locd, const float* pm, const float* v, const float* de, int B, int L, int a,
-                                        float* du, float* dpm, float* dq, float* dv_acc, void* stream);
-int gvx_train_location_conv_backward(const float* dlocf, const float* w_prev, const float* w_cum, const float* lw, int B, int L, int F, int k,
-                                     float* dw_prev_out, float* G, float* dlw_acc, void* stream);
 int gvx_train_relu_dropout_backward(const float* dy, const float* act_out, const uint8_t* keep, float scale, long n, float* dz, void* stream);
 int gvx_train_unblock(const float* blocked, float* rows_out, long n_slots, int B, int K, void* stream);
 int gvx_train_embedding_backward(const int64_t* tokens, const float* dx, long n_tokens_in_batch, int E, int n_rows, float* demb, void* stream);
@@ -287,8 +275,8 @@ typedef struct gvx_bptt_decoder_args {
     int32_t A, D, E, P, a, F, kl;       /* att_rnn_dim, dec_rnn_dim, embed_dim, prenet_dim, att_dim, location filters / kernel size */
     float att_scale, dec_scale;         /* 1 / (1 - p) of the dropout on each cell's hidden output */
     const float* dhc_all;               /* [T][B][D+E]  d loss / d [h_d(t) ; ctx(t)] through the mel / gate projection */
-    const float* pre_a;                 /* [T][B][4A]   gate pre-activations of the attention LSTM */
-    const float* pre_d;                 /* [T][B][4D]   ... of the decoder LSTM */
+    const float* pre_a;                 /* [T][B][A][4] gate pre-activations of the attention LSTM as the forward's tape holds them */
+    const float* pre_d;                 /* [T][B][D][4] ... of the decoder LSTM */
     const float* c_a_all;               /* [T+1][B][A]  cell states, slot t = before step t */
     const float* c_d_all;               /* [T+1][B][D] */
     const uint8_t* att_keep;            /* [T][B][A]    keep masks of the hidden-output dropouts */

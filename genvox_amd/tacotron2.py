@@ -407,8 +407,6 @@ class Tacotron2(nn.Module):
         mel_len = batch["mel_lengths"].to(device=dev, dtype=torch.int32).contiguous()
         B, L = tokens.shape
         _, M, T = mel_in.shape
-        if B > STREAM_ROWS:
-            raise NotImplementedError("training-mode forward: at most 32 rows per call")
         E, A, D, P = mc.encoder_embedding_dim, mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.prenet_dim
         given = batch.get("train_keep_masks") or {}
         draw = lambda shape, p: (torch.rand(shape, device=dev) >= p).to(torch.uint8)
@@ -426,35 +424,47 @@ class Tacotron2(nn.Module):
         dec_keep = dec_keep.to(device=dev, dtype=torch.uint8).contiguous()
         pk = batch.get("prenet_keep_masks")
         masks = self._keep_masks(pk.to(device=dev, dtype=torch.uint8).reshape(2, T + 1, B, P).contiguous() if pk is not None else None,
-                                 2 * (T + 1) * B * P, dev)
-        # encoder: embedding, training-mode convolution stack (parameters in place), BiLSTM
+                                 2 * (T + 1) * B * P, dev).reshape(2, T + 1, B, P)
+        # encoder: embedding, training-mode convolution stack on the WHOLE batch (BatchNorm batch statistics), parameters in place
         emb = self.embedding.weight.data[tokens].transpose(1, 2).contiguous()          # [B, E, L]  (:459)
         conv_out, enc_tape = training.convstack_train_forward(self, "encoder.convolutions", training.encoder_acts(self), emb, enc_keep)
-        ws = self._get_workspace(B, L, T)
         st = self._stream()
-        memory = torch.empty(B, L, E, device=dev)
-        enc_c = torch.empty(B, L, E, device=dev)
-        _lib.check(lib.gvx_encoder_lstm_forward(self._handle, conv_out.data_ptr(), tok_len.data_ptr(), B, L, memory.data_ptr(),
-                                                enc_c.data_ptr(), None, ws.data_ptr(), ws.numel(), st))
         dec_mel = torch.empty(B, M, T, device=dev)
         gate = torch.empty(B, T, device=dev)
         align = torch.empty(B, T, L, device=dev)
-        ha_blk = torch.empty((T + 1) * B * A, device=dev)
-        c_a_all, c_d_all = torch.empty(T + 1, B, A, device=dev), torch.empty(T + 1, B, D, device=dev)
-        hc_blk = torch.empty((T + 1) * B * (D + E), device=dev)
-        pre_a, pre_d = torch.empty(T, B, A, 4, device=dev), torch.empty(T, B, D, 4, device=dev)   # gate pre-activations of both cells
-        _lib.check(lib.gvx_decoder_teacher_forced_train(
-            self._handle, memory.data_ptr(), tok_len.data_ptr(), B, L, mel_in.data_ptr(), T, masks.data_ptr(), att_keep.data_ptr(),
-            dec_keep.data_ptr(), float(mc.p_attention_dropout), float(mc.p_decoder_dropout), dec_mel.data_ptr(), gate.data_ptr(),
-            align.data_ptr(), ha_blk.data_ptr(), c_a_all.data_ptr(), c_d_all.data_ptr(), hc_blk.data_ptr(), pre_a.data_ptr(), pre_d.data_ptr(),
-            ws.data_ptr(), ws.numel(), st))
-        # the rest of the tape: per-step vectors as plain rows, the Prenet activations and the processed memory
         ops = training._Ops(dev)
-        export = lambda what, shape: (lambda t: (_lib.check(lib.gvx_train_export(self._handle, ws.data_ptr(), ws.numel(), B, L, T, what, t.data_ptr(), st)), t)[1])(torch.empty(*shape, device=dev))
-        dec_tape = {"h_a_all": training._unblock(ops, ha_blk, T + 1, B, A), "hc_all": training._unblock(ops, hc_blk, T + 1, B, D + E),
-                    "c_a_all": c_a_all, "c_d_all": c_d_all, "pre_a": pre_a, "pre_d": pre_d, "frames": export(0, (T + 1, B, M)), "p1": export(1, (T + 1, B, P)),
-                    "p2": export(2, (T + 1, B, P)), "pm": export(3, (B, L, mc.attention_dim)), "att_keep": att_keep, "dec_keep": dec_keep,
-                    "prenet_keep": masks.reshape(2, T + 1, B, P), "enc_conv_out": conv_out, "enc_cell_states": enc_c}
+        # The recurrent part - BiLSTM and decoder loop - never mixes rows: batches above 32 rows (the reference's trainer
+        # defaults to 64, its run.py uses 256) go through it in chunks of at most 32 rows, each with its own tape
+        chunks = []
+        for lo in range(0, B, STREAM_ROWS):
+            hi = min(B, lo + STREAM_ROWS)
+            Bc = hi - lo
+            ws = self._get_workspace(Bc, L, T)
+            tl_c = tok_len[lo:hi].contiguous()
+            memory = torch.empty(Bc, L, E, device=dev)
+            enc_c = torch.empty(Bc, L, E, device=dev)
+            _lib.check(lib.gvx_encoder_lstm_forward(self._handle, conv_out[lo:hi].data_ptr(), tl_c.data_ptr(), Bc, L, memory.data_ptr(),
+                                                    enc_c.data_ptr(), None, ws.data_ptr(), ws.numel(), st))
+            ha_blk = torch.empty((T + 1) * Bc * A, device=dev)
+            c_a_all, c_d_all = torch.empty(T + 1, Bc, A, device=dev), torch.empty(T + 1, Bc, D, device=dev)
+            hc_blk = torch.empty((T + 1) * Bc * (D + E), device=dev)
+            pre_a, pre_d = torch.empty(T, Bc, A, 4, device=dev), torch.empty(T, Bc, D, 4, device=dev)   # gate pre-activations of both cells
+            whole = lo == 0 and hi == B
+            mk = masks if whole else masks[:, :, lo:hi].contiguous()
+            ak = att_keep if whole else att_keep[:, lo:hi].contiguous()
+            dk = dec_keep if whole else dec_keep[:, lo:hi].contiguous()
+            _lib.check(lib.gvx_decoder_teacher_forced_train(
+                self._handle, memory.data_ptr(), tl_c.data_ptr(), Bc, L, mel_in[lo:hi].data_ptr(), T, mk.data_ptr(), ak.data_ptr(),
+                dk.data_ptr(), float(mc.p_attention_dropout), float(mc.p_decoder_dropout), dec_mel[lo:hi].data_ptr(), gate[lo:hi].data_ptr(),
+                align[lo:hi].data_ptr(), ha_blk.data_ptr(), c_a_all.data_ptr(), c_d_all.data_ptr(), hc_blk.data_ptr(), pre_a.data_ptr(), pre_d.data_ptr(),
+                ws.data_ptr(), ws.numel(), st))
+            # the rest of the chunk's tape: per-step vectors as plain rows, the Prenet activations and the processed memory
+            export = lambda what, shape: (lambda t: (_lib.check(lib.gvx_train_export(self._handle, ws.data_ptr(), ws.numel(), Bc, L, T, what, t.data_ptr(), st)), t)[1])(torch.empty(*shape, device=dev))
+            chunks.append({"rows": (lo, hi), "token_lengths": tl_c, "memory": memory, "enc_cell_states": enc_c,
+                           "h_a_all": training._unblock(ops, ha_blk, T + 1, Bc, A), "hc_all": training._unblock(ops, hc_blk, T + 1, Bc, D + E),
+                           "c_a_all": c_a_all, "c_d_all": c_d_all, "pre_a": pre_a, "pre_d": pre_d, "frames": export(0, (T + 1, Bc, M)),
+                           "p1": export(1, (T + 1, Bc, P)), "p2": export(2, (T + 1, Bc, P)), "pm": export(3, (Bc, L, mc.attention_dim)),
+                           "att_keep": ak, "dec_keep": dk, "prenet_keep": mk})
         post_y, post_tape = training.convstack_train_forward(self, "postnet.convolutions", training.postnet_acts(self), dec_mel, post_keep)
         mel_out, mel_post = dec_mel.clone(), dec_mel + post_y
         if mc.mask_padding:
@@ -463,7 +473,7 @@ class Tacotron2(nn.Module):
             mel_post.masked_fill_(pad[:, None, :], 0.0)
             gate.masked_fill_(pad, 1e3)
         outputs = {"mel_outputs": mel_out, "mel_outputs_postnet": mel_post, "gate_outputs": gate, "alignments": align}
-        tape = {"encoder": enc_tape, "postnet": post_tape, "decoder_mel_unmasked": dec_mel, "memory": memory, **dec_tape}
+        tape = {"encoder": enc_tape, "postnet": post_tape, "decoder_mel_unmasked": dec_mel, "enc_conv_out": conv_out, "chunks": chunks}
         # the HIP kernels updated the BatchNorm running statistics through raw pointers (no tensor version bump): the packed
         # blob - whose eval-mode convolutions have those statistics folded in - is stale now
         self._packed_key = None

@@ -223,36 +223,39 @@ def _unblock(ops: _Ops, blocked: torch.Tensor, n_slots: int, B: int, K: int) -> 
     return out
 
 
-def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, torch.Tensor], tape: dict) -> Dict[str, torch.Tensor]:
-    """Gradients of loss = Tacotron2Loss(batch, outputs) w.r.t. every parameter (keys = the reference's state_dict names),
-    from the tape of ``Tacotron2._forward_train``."""
+def _accumulate(ops: "_Ops", total: Dict[str, torch.Tensor], part: Dict[str, torch.Tensor]) -> None:
+    """total[k] += part[k] (gradients of the row chunks are added in chunk order)."""
+    for k, v in part.items():
+        if k in total:
+            t = total[k]
+            ops.axpby(t.reshape(1, -1), 1.0, v.reshape(1, -1), 1.0, out=t.reshape(1, -1))
+        else:
+            total[k] = v.contiguous()
+
+
+def _recurrent_backward(model, ops: "_Ops", ch: dict, dmel: torch.Tensor, dgate: torch.Tensor, x: torch.Tensor, align: torch.Tensor
+                        ) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+    """The part of the backward that never mixes batch rows, for one chunk of at most 32 rows: projection, decoder loop
+    (gvx_train_decoder_bptt), Prenet, memory layer, encoder BiLSTM (gvx_train_encoder_lstm_bptt).  dmel [Bc, M, T] and dgate
+    [Bc, T] are d loss / d of the decoder's mel / gate outputs, x [Bc, L, E] the BiLSTM's input, align [Bc, T, L] the
+    alignments.  Returns (parameter gradients of this chunk's rows, d loss / d x as [Bc * L, E])."""
     mc = model.model_config
-    dev = outputs["mel_outputs"].device
-    ops = _Ops(dev)
+    dev = dmel.device
     lib, st = ops.lib, ops.st
     P_ = dict(model.named_parameters())
     W = lambda name: P_[name].data
     att = "decoder.attention_layer."
-    tok = batch["token_padded"].to(device=dev, dtype=torch.int64).contiguous()
-    tl = batch["token_lengths"].to(device=dev, dtype=torch.int64)
-    B, L = tok.shape
-    M, T = outputs["mel_outputs"].shape[1], outputs["mel_outputs"].shape[2]
+    B, M, T = dmel.shape
+    L = x.shape[1]
     A, D, E, Pn, a = mc.attention_rnn_dim, mc.decoder_rnn_dim, mc.encoder_embedding_dim, mc.prenet_dim, mc.attention_dim
     F_, kl = mc.attention_location_n_filters, mc.attention_location_kernel_size
     g: Dict[str, torch.Tensor] = {}
-
-    # ---- criterion and Postnet
-    dmel_direct, dpost, dgate = loss_backward(batch, outputs)
-    dx, pg = convstack_train_backward(tape["postnet"], dpost, first_layer_wgrad_input=outputs["mel_outputs"])
-    g.update(pg)
-    dmel = ops.axpby(dmel_direct.reshape(B * M, T), 1.0, dpost.reshape(B * M, T), 1.0)
-    dmel = ops.axpby(dmel, 1.0, dx.reshape(B * M, T), 1.0).reshape(B, M, T)
     # ---- projection: rows (t, b); [dmel | dgate | 0-pad] [T B, Mp] x [Wp ; Wg]
     Mp = -(-(M + 1) // 4) * 4
     dmg = ops.zeros(T * B, Mp)
     dmg[:, :M] = dmel.permute(2, 0, 1).reshape(T * B, M)          # (torch: layout plumbing only)
     dmg[:, M] = dgate.t().reshape(T * B)
-    hc = tape["hc_all"]                                           # [T+1, B, D+E] rows: slot t + 1 = [h_d(t) ; ctx(t)]
+    hc = ch["hc_all"]                                             # [T+1, B, D+E] rows: slot t + 1 = [h_d(t) ; ctx(t)]
     hc_t = hc[1:].reshape(T * B, D + E)
     Wpg = ops.zeros(Mp, D + E)
     Wpg[:M] = W("decoder.linear_projection.linear_layer.weight")
@@ -263,9 +266,9 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     g["decoder.linear_projection.linear_layer.bias"], g["decoder.gate_layer.linear_layer.bias"] = db[:M].contiguous(), db[M:M + 1].contiguous()
     dhc_all = ops.gemm_nt(dmg, ops.transpose(Wpg)).reshape(T, B, D + E)       # d loss / d [h_d(t) ; ctx(t)] through the projection
 
-    # ---- operands of every step, hoisted: inputs and gate pre-activations of both cells, the attention queries
-    p2 = tape["p2"]                                               # [T+1, B, P]
-    ha = tape["h_a_all"]                                          # [T+1, B, A]  slot t + 1 = dropped h_a(t)
+    # ---- operands of the weight gradients (inputs of both cells at every step) and the attention queries
+    p2 = ch["p2"]                                                 # [T+1, B, P]
+    ha = ch["h_a_all"]                                            # [T+1, B, A]  slot t + 1 = dropped h_a(t)
     ctx_prev = hc[:T, :, D:]                                      # ctx(t-1), slot t
     xa = torch.cat((p2[:T], ctx_prev), dim=2).reshape(T * B, Pn + E).contiguous()
     ha_prev = ha[:T].reshape(T * B, A)
@@ -273,14 +276,14 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     Wid, Whd = W("decoder.decoder_rnn.weight_ih"), W("decoder.decoder_rnn.weight_hh")
     xd = torch.cat((ha[1:], hc[1:, :, D:]), dim=2).reshape(T * B, A + E).contiguous()   # [h_a(t) ; ctx(t)]
     hd_prev = hc[:T, :, :D].reshape(T * B, D).contiguous()
-    pre_a, pre_d = tape["pre_a"], tape["pre_d"]                   # [T, B, H, 4]: the gate pre-activations the forward computed
+    pre_a, pre_d = ch["pre_a"], ch["pre_d"]                       # [T, B, H, 4]: the gate pre-activations the forward computed
     wq, v = W(att + "query_layer.linear_layer.weight"), W(att + "v.linear_layer.weight")
     lw, ld = W(att + "location_layer.location_conv.conv.weight").contiguous(), W(att + "location_layer.location_dense.linear_layer.weight")
     wm = W(att + "memory_layer.linear_layer.weight")
     q_all = ops.gemm_nt(ha[1:].reshape(T * B, A), wq).reshape(T, B, a)
-    memory, pm = tape["memory"], tape["pm"]
-    w_all = outputs["alignments"].permute(1, 0, 2).contiguous()   # [T, B, L]
-    c_a, c_d = tape["c_a_all"], tape["c_d_all"]                   # [T+1, B, H]
+    memory, pm = ch["memory"], ch["pm"]
+    w_all = align.permute(1, 0, 2).contiguous()                   # [T, B, L]
+    c_a, c_d = ch["c_a_all"], ch["c_d_all"]                       # [T+1, B, H]
     # ---- back-propagation through the decoder loop: one C-ABI call (three launches per step, csrc/train.hip)
     dga_all, dgd_all = ops.new(T, B, 4 * A), ops.new(T, B, 4 * D)
     dq_all, dctx_all = ops.new(T, B, a), ops.new(T, B, E)
@@ -296,7 +299,7 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
         return t.data_ptr()
     ba_.dhc_all, ba_.pre_a, ba_.pre_d = ptr(dhc_all), ptr(pre_a), ptr(pre_d)
     ba_.c_a_all, ba_.c_d_all = ptr(c_a), ptr(c_d)
-    ba_.att_keep, ba_.dec_keep, ba_.q_all = ptr(tape["att_keep"]), ptr(tape["dec_keep"]), ptr(q_all)
+    ba_.att_keep, ba_.dec_keep, ba_.q_all = ptr(ch["att_keep"]), ptr(ch["dec_keep"]), ptr(q_all)
     ba_.ctx_all = hc.data_ptr() + 4 * (B * (D + E) + D)          # ctx(t) = hc[t + 1, b, D:]
     ba_.ctx_ts, ba_.ctx_bs = B * (D + E), D + E
     ba_.w_all, ba_.memory, ba_.pm = ptr(w_all), ptr(memory), ptr(pm)
@@ -328,9 +331,9 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     g[att + "memory_layer.linear_layer.weight"] = ops.mm_tn(dpm2, memory.reshape(B * L, E))
     dmemory = ops.axpby(dmemory.reshape(B * L, E), 1.0, ops.gemm_nt(dpm2, ops.transpose(wm)), 1.0).reshape(B, L, E)
     # ---- Prenet (relu then dropout, twice; models/tts/tacotron2.py:140-144)
-    pk = tape["prenet_keep"]                                      # [2, T+1, B, P] uint8
-    p1 = tape["p1"]
-    w0, w1 = W("decoder.prenet.layers.0.linear_layer.weight"), W("decoder.prenet.layers.1.linear_layer.weight")
+    pk = ch["prenet_keep"]                                        # [2, T+1, B, P] uint8
+    p1 = ch["p1"]
+    w1 = W("decoder.prenet.layers.1.linear_layer.weight")
     n_rows = (T + 1) * B
     dz2 = ops.new(n_rows, Pn)
     _lib.check(lib.gvx_train_relu_dropout_backward(_p(dp2), _p(p2.contiguous()), _p(pk[1].contiguous()), 2.0, n_rows * Pn, _p(dz2), st))
@@ -338,11 +341,11 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     dp1 = ops.gemm_nt(dz2, ops.transpose(w1))
     dz1 = ops.new(n_rows, Pn)
     _lib.check(lib.gvx_train_relu_dropout_backward(_p(dp1), _p(p1.contiguous()), _p(pk[0].contiguous()), 2.0, n_rows * Pn, _p(dz1), st))
-    g["decoder.prenet.layers.0.linear_layer.weight"] = ops.mm_tn(dz1, tape["frames"].reshape(n_rows, M).contiguous())
-    # ---- encoder BiLSTM, packed-sequence semantics (models/tts/tacotron2.py:239-245)
+    g["decoder.prenet.layers.0.linear_layer.weight"] = ops.mm_tn(dz1, ch["frames"].reshape(n_rows, M).contiguous())
+    # ---- encoder BiLSTM, packed-sequence semantics (models/tts/tacotron2.py:239-245): one C-ABI call, a launch per time step
     H = E // 2
-    x = tape["enc_conv_out"].permute(0, 2, 1).contiguous()        # [B, L, E]
-    c_enc = tape["enc_cell_states"]                               # [B, L, E] (forward direction in channels [0, H))
+    x = x.contiguous()
+    c_enc = ch["enc_cell_states"]                                 # [B, L, E] (forward direction in channels [0, H))
     dx_enc = ops.zeros(B * L, E)
     sfxs = ("", "_reverse")
     w_ih2 = [W("encoder.lstm.weight_ih_l0" + sfx) for sfx in sfxs]
@@ -353,7 +356,7 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
         ops.gemm_nt(x.reshape(B * L, E), w_ih2[d_], bias=bsum, out=xg[d_])
     dg_pos, hprev_pos = torch.empty(2, B * L, 4 * H, device=dev), torch.empty(2, B * L, H, device=dev)
     wse = torch.empty(lib.gvx_train_encoder_lstm_bptt_workspace_bytes(B, H), dtype=torch.uint8, device=dev)
-    tl32 = tl.to(torch.int32).contiguous()
+    tl32 = ch["token_lengths"].to(device=dev, dtype=torch.int32).contiguous()
     _lib.check(lib.gvx_train_encoder_lstm_bptt(_p(xg), _p(memory.contiguous()), _p(c_enc.contiguous()), _p(dmemory.contiguous()), _p(w_hh2), _p(tl32),
                                                B, L, H, _p(dg_pos), _p(hprev_pos), _p(wse), wse.numel(), st))
     for d_, sfx in enumerate(sfxs):
@@ -363,10 +366,41 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
         g["encoder.lstm.bias_ih_l0" + sfx] = ops.colsum(dg2)
         g["encoder.lstm.bias_hh_l0" + sfx] = g["encoder.lstm.bias_ih_l0" + sfx].clone()
         dx_enc = ops.axpby(dx_enc, 1.0, ops.gemm_nt(dg2, ops.transpose(w_ih2[d_])), 1.0)
-    # ---- encoder convolution stack and embedding
+    return g, dx_enc
+
+
+def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, torch.Tensor], tape: dict) -> Dict[str, torch.Tensor]:
+    """Gradients of loss = Tacotron2Loss(batch, outputs) w.r.t. every parameter (keys = the reference's state_dict names),
+    from the tape of ``Tacotron2._forward_train``.  What mixes batch rows - the criterion's means and the BatchNorm batch
+    statistics of both convolution stacks - runs on the whole batch; the recurrent part runs per chunk of at most 32 rows
+    (``_recurrent_backward``), its parameter gradients added in chunk order."""
+    dev = outputs["mel_outputs"].device
+    ops = _Ops(dev)
+    lib, st = ops.lib, ops.st
+    P_ = dict(model.named_parameters())
+    tok = batch["token_padded"].to(device=dev, dtype=torch.int64).contiguous()
+    B, L = tok.shape
+    M, T = outputs["mel_outputs"].shape[1], outputs["mel_outputs"].shape[2]
+    E = model.model_config.encoder_embedding_dim
+    g: Dict[str, torch.Tensor] = {}
+    # ---- criterion and Postnet (whole batch)
+    dmel_direct, dpost, dgate = loss_backward(batch, outputs)
+    dx, pg = convstack_train_backward(tape["postnet"], dpost, first_layer_wgrad_input=outputs["mel_outputs"])
+    g.update(pg)
+    dmel = ops.axpby(dmel_direct.reshape(B * M, T), 1.0, dpost.reshape(B * M, T), 1.0)
+    dmel = ops.axpby(dmel, 1.0, dx.reshape(B * M, T), 1.0).reshape(B, M, T)
+    # ---- the recurrent part, chunk by chunk
+    x_all = tape["enc_conv_out"].permute(0, 2, 1).contiguous()    # [B, L, E]: the BiLSTM's input
+    dx_enc = ops.new(B * L, E)
+    for ch in tape["chunks"]:
+        lo, hi = ch["rows"]
+        cg, dxe = _recurrent_backward(model, ops, ch, dmel[lo:hi], dgate[lo:hi], x_all[lo:hi], outputs["alignments"][lo:hi])
+        _accumulate(ops, g, cg)
+        dx_enc[lo * L:hi * L] = dxe
+    # ---- encoder convolution stack and embedding (whole batch)
     dconv, eg = convstack_train_backward(tape["encoder"], dx_enc.reshape(B, L, E).permute(0, 2, 1).contiguous())
     g.update(eg)
-    demb = torch.empty_like(W("embedding.weight"))
+    demb = torch.empty_like(P_["embedding.weight"].data)
     dtok = dconv.permute(0, 2, 1).contiguous()                    # [B, L, E]
     _lib.check(lib.gvx_train_embedding_backward(_p(tok), _p(dtok), B * L, E, demb.shape[0], _p(demb), st))
     g["embedding.weight"] = demb

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time Tacotron2.train_step on synthetic batches (first version of the training step: correct, not tuned)."""
+"""Time Tacotron2.train_step on synthetic batches (profiles/r03_train_step_timing.txt)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,10 +12,10 @@ m = Tacotron2(mc, ac, tc)
 m.load_state_dict(gw.generate_state_dict(mc, ac, tc, seed=0))
 m = m.to("cuda:0")
 opt = m.get_optimizer()
-for B, L, T in ((8, 64, 100), (32, 128, 200)):
+for B, L, T in ((8, 64, 100), (32, 128, 200), (64, 128, 200), (32, 128, 800)):
     batch = {k: torch.from_numpy(v).cuda() for k, v in gw.synthetic_inputs(B, L, T, 40, 80, seed=3).items()}
     times, losses = [], []
-    for i in range(3):
+    for i in range(4):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         m.train_step(batch, m.get_criterion(), opt)
         torch.cuda.synchronize(); times.append(time.perf_counter() - t0); losses.append(round(m.loss_items["loss"], 4))

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // consecutive blocks share the W panel (same n-tile) -> neighbouring M tiles stay in one L2
     const int n_tiles = (p.N + BN - 1) / BN;
     const int mt = blockIdx.x / n_tiles, nt = blockIdx.x % n_tiles;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
     // split-K: this workgroup's k range and partial output (the whole K and C itself when splitk == 1)
     const int k_begin = p.splitk > 1 ? (int)blockIdx.y * p.kchunk : 0;
     const int k_end = p.splitk > 1 ? min(p.K, k_begin + p.kchunk) : p.K;
@@ -193,13 +193,15 @@ hipError_t gemm_init() {
     if (e != hipSuccess) return e;
     e = init_cfg<4, 1, 1, 3>();
     if (e != hipSuccess) return e;
+    e = init_cfg<2, 2, 1, 1>();
+    if (e != hipSuccess) return e;
     return init_cfg<4, 1, 1, 1>();
 }
 
 template <int WR, int WC, int TM, int TN>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-    const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int grid = ((p.M - p.m_begin + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     gemm_f32_kernel<WR, WC, TM, TN><<<dim3(grid, p.splitk > 1 ? p.splitk : 1), dim3(256), lds_bytes_cfg<WR, WC, TM, TN>(), s>>>(p);
     return hipGetLastError();
 }
@@ -211,8 +213,25 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.N <= 96) return launch_cfg<4, 1, 1, 3>(p, s);
     // fewer than ~1.5 workgroups per CU with 128 x 128 tiles (encoder convolutions: 4096 x 512): halve the tile height so
     // that all 256 CUs get work
-    const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const long n_tiles = (p.N + 127) / 128, tiles128 = (long)((p.M + 127) / 128) * n_tiles;
     if (tiles128 < 384) return launch_cfg<2, 2, 1, 2>(p, s);
+    // Wave quantisation: 128 x 128 tiles run in rounds of 256 (one per CU); a last round with few tiles leaves most of the
+    // chip idle for a whole tile time (the Postnet at 32 x 800 frames: 800 tiles = 3 rounds + 32 tiles, 78 % of 4 rounds).
+    // When the last round would be at most a quarter full, the rows of the full rounds get the big tiles and the remaining
+    // rows a second launch with 64 x 64 tiles (four times as many workgroups, a quarter of the time each).  Every output
+    // element still sums its K products in the same order: results do not depend on the tile shape.
+    const long rem = tiles128 % 256;
+    if (p.splitk <= 1 && p.m_begin == 0 && rem > 0 && rem <= 64) {
+        const long rows_big = ((tiles128 - rem) / n_tiles) * 128;   // whole row tiles of the full rounds
+        if (rows_big > 0 && rows_big < p.M) {
+            GemmParams a = p, b = p;
+            a.M = (int)rows_big;
+            b.m_begin = (int)rows_big;
+            const hipError_t e = launch_cfg<2, 2, 2, 2>(a, s);
+            if (e != hipSuccess) return e;
+            return launch_cfg<2, 2, 1, 1>(b, s);
+        }
+    }
     return launch_cfg<2, 2, 2, 2>(p, s);
 }
 

@@ -429,6 +429,9 @@ def main():
             e = {"s_per_step": round(dt, 4), "mel_frames_per_s": round(B * Tt / dt, 1), "loss_after": round(model.loss_items["loss"], 4),
                  "grad_norm": round(model.grad_norm_val, 4),
                  "note": "explicit backward (no autograd): both recurrences as single C-ABI calls (3 launches per decoder step, 1 per encoder step), weights re-packed on the device; pinned to the reference's own train_step"}
+            # forward 48.5 MFLOP per mel frame, the backward twice that (data and weight gradients)
+            e["tflops"] = round(3 * 48.5e6 * B * Tt / dt / 1e12, 2)
+            e["mfma_frac_of_157TF"] = round(e["tflops"] / 157.3, 4)
             if with_cpu:
                 from oracle import train_ref
                 Bc, Lc, Tc2 = 4, 64, 24

@@ -1097,7 +1097,10 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     }
     // Persistent attention (attn_persist.hip): the loop is then T + 1 LSTM launches on `st` and ONE attention kernel on a
     // forked stream; the LSTM tiles stream the k-groups of the context last and wait for it in the launch.
-    const bool pa = !train && persistent_path(m, B, L);   // (training mode runs the launch-per-step loop)
+    // (training mode takes the same loop since round 3: the tape - dropped hidden states, cell states, gate pre-activations -
+    // is written by the cell epilogues of both launch layouts; GVX_TRAIN_RESIDENT=0 keeps the launch per attention step)
+    static const bool train_resident = [] { const char* e = std::getenv("GVX_TRAIN_RESIDENT"); return !(e && e[0] == '0'); }();
+    const bool pa = (!train || train_resident) && persistent_path(m, B, L);
     const int pa_layout = attention_persistent_layout(B, L);   // 1: L <= 128 (32 CUs, 224 workgroups); 2: L <= 256 (64 CUs, 192
                                                                // workgroups); 3: 33 .. 64 rows (64 CUs, 384 workgroups, two per CU)
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
@@ -1476,6 +1479,12 @@ int gvx_decoder_teacher_forced_train(gvx_model* m, const float* memory, const in
     const WsPlan wp = make_ws_plan(m, B, L, T);
     rc = decoder_tf_impl(m, memory, lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws, wp, s, false, &tr);
     if (rc != GVX_OK) return rc;
+    {   // a hand-off of the resident-attention loop that timed out must not look like a result (NaN outputs + sticky status)
+        float* outs[3] = {mel_out, gate_out, align_out};
+        const size_t counts[3] = {(size_t)B * m->d.n_mels * T, (size_t)B * T, (size_t)B * T * L};
+        rc = poison_if_timed_out(m, B, L, ws, wp, outs, counts, 3, s);
+        if (rc != GVX_OK) return rc;
+    }
     if (dec_hidden_context_all)   // [T+1] slots of blocked [h_d ; ctx] vectors: slot t + 1 = after step t
         HIP_TRY(hipMemcpyAsync(dec_hidden_context_all, ws_ptr<float>(ws, wp.hc), (size_t)(T + 1) * B * (D + E) * sizeof(float),
                                hipMemcpyDeviceToDevice, s));

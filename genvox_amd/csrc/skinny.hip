@@ -496,9 +496,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         const int jloc = 4 * xhalf + g2, j = xt * 8 + jloc, H = J.N >> 2;
         float hval = 0.f;
         if (b2 < B) {
-            const float c_new = sigmoidf_(s2[1] + bias_pref.y) * c_pref + sigmoidf_(s2[0] + bias_pref.x) * tanhf_(s2[2] + bias_pref.z);
-            hval = sigmoidf_(s2[3] + bias_pref.w) * tanhf_(c_new);
-            J.c[(long)b2 * H + j] = c_new;
+            const float p0 = s2[0] + bias_pref.x, p1 = s2[1] + bias_pref.y, p2 = s2[2] + bias_pref.z, p3 = s2[3] + bias_pref.w;
+            if (J.pre_out) *reinterpret_cast<float4*>(J.pre_out + ((long)b2 * H + j) * 4) = make_float4(p0, p1, p2, p3);   // (training tape)
+            const float c_new = sigmoidf_(p1) * c_pref + sigmoidf_(p0) * tanhf_(p2);
+            hval = sigmoidf_(p3) * tanhf_(c_new);
+            if (J.h_keep) hval = J.h_keep[(long)b2 * H + j] ? hval * J.h_scale : 0.f;
+            (J.c_out ? J.c_out : J.c)[(long)b2 * H + j] = c_new;
             J.h_out[(long)xt * blk + b2 * 8 + jloc] = hval;
         }
         hs2[b2 * 4 + g2] = hval;

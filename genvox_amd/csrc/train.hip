@@ -22,6 +22,20 @@ namespace {
 constexpr float BN_EPS_F = 1e-5f;
 inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
+// Split-K factor for a product with `tiles` output tiles of 64 x 128 and a long K (weight gradients: few outputs, thousands of
+// rows to sum over): the tiles run in rounds of 256 (one per CU), so the time goes like ceil(tiles * s / 256) / s - the
+// smallest s <= 8 that minimises it, pieces of at least 256 k.  1 = no split.
+inline int choose_splitk(long tiles, int K) {
+    if (tiles >= 256 || K < 512) return 1;
+    int best = 1;
+    double best_t = 1.0;   // (tiles < 256: one round at s = 1)
+    for (int sp = 2; sp <= 8 && K / sp >= 256; ++sp) {
+        const double t = (double)((tiles * sp + 255) / 256) / sp;
+        if (t < best_t - 1e-9) { best_t = t; best = sp; }
+    }
+    return best;
+}
+
 // [Cout][Cin][k] -> Wk[Cout][k][Cin] (forward)  and  W2[Cin][k][Cout] with flipped taps (dgrad)
 __global__ void repack_conv_kernel(const float* w, float* wk, float* w2, int Cout, int Cin, int k) {
     const long n = (long)Cout * Cin * k;
@@ -233,7 +247,7 @@ inline int blocks_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1
 // layout of the saved-for-backward buffer and of the scratch of one layer (byte offsets)
 struct ConvTrainPlan {
     size_t xcl, xhat, a, mean, invstd, saved_total;                       // saved
-    size_t wk, w2, z, du, dz, dzh, dzt, xt, dwk, dxcl, xcl2, ws_total;   // workspace
+    size_t wk, w2, z, du, dz, dzh, dzt, xt, dwk, dxcl, xcl2, dwk_part, ws_total;   // workspace
 };
 ConvTrainPlan conv_train_plan(int B, int Cin, int Cout, int T, int k) {
     const int pad = (k - 1) / 2;
@@ -259,6 +273,7 @@ ConvTrainPlan conv_train_plan(int B, int Cin, int Cout, int T, int k) {
     p.dwk = take((size_t)Cout * k * Cin);
     p.dxcl = take((size_t)rows * Cin);
     p.xcl2 = take((size_t)B * (T + 2 * pad) * Cin);
+    p.dwk_part = take((size_t)8 * Cout * k * Cin);   // split-K partial tiles of the weight gradient (at most 8 splits)
     p.ws_total = o;
     return p;
 }
@@ -383,7 +398,10 @@ int gvx_conv_bn_act_train_backward(const float* dy, const void* saved, size_t sa
         g.W = xt; g.ldw = rows_p;
         g.C = dwk; g.cmap = RowMap{Cout, 0, (long)k * Cin};
         g.M = Cout; g.N = k * Cin; g.K = (int)rows_p; g.act = ACT_NONE;
-        TR_TRY(launch_gemm(g, s));
+        // few output tiles, thousands of rows to sum over: K split over enough workgroups to fill the chip (the Postnet's 512 x 2560
+        // gradients are 160 tiles, its first layer's 32: 290 / 330 us each as one round)
+        const long tiles = (long)((Cout + 63) / 64) * ((k * Cin + 127) / 128);
+        TR_TRY(launch_gemm_splitk(g, choose_splitk(tiles, (int)rows_p), at<float>(workspace, pl.dwk_part), s));
     }
     hipLaunchKernelGGL(unpack_dw_kernel, dim3(blocks_for((long)Cout * Cin * k)), dim3(256), 0, s, dwk, dw, Cout, Cin, k);
     if (dx) {   // data gradient: flipped-tap implicit GEMM on the halo-padded dz
@@ -499,12 +517,8 @@ int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float*
     // few output tiles and a long K (the per-step products of the backward: 32 rows x thousands of columns): split K over
     // enough workgroups to fill the chip, partial tiles in the caller's scratch, added in split order (deterministic)
     const long tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
-    int splitk = 1;
-    if (scratch && tiles < 128 && K >= 512) {
-        splitk = (int)((256 + tiles - 1) / tiles);
-        if (splitk > K / 128) splitk = K / 128;
-        while (splitk > 1 && (size_t)splitk * M * N * sizeof(float) > scratch_bytes) --splitk;
-    }
+    int splitk = scratch ? choose_splitk(tiles, K) : 1;
+    while (splitk > 1 && (size_t)splitk * M * N * sizeof(float) > scratch_bytes) --splitk;
     TR_TRY(launch_gemm_splitk(g, splitk, scratch, (hipStream_t)stream));
     return GVX_OK;
 }

@@ -28,6 +28,14 @@ class gvx_weight_desc(C.Structure):
 _vp, _i, _sz, _f, _l = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_long
 
 
+class gvx_tensor_ref(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+class gvx_adam_ref(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("numel", C.c_int64)]
+
+
 class gvx_bptt_decoder_args(C.Structure):
     """Argument block of gvx_train_decoder_bptt (include/genvox_amd.h)."""
     _fields_ = ([(n, C.c_int32) for n in ("B", "L", "T", "A", "D", "E", "P", "a", "F", "kl")]
@@ -74,8 +82,9 @@ SIGNATURES = {
     "gvx_train_relu_dropout_backward": (_i, [_vp, _vp, _vp, _f, _l, _vp, _vp]),
     "gvx_train_unblock": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "gvx_train_embedding_backward": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp]),
-    "gvx_train_sqnorm_accumulate": (_i, [_vp, _l, _vp, _vp]),
-    "gvx_train_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _i, _vp]),
+    "gvx_train_sqnorm_scratch_bytes": (_sz, [_i]),
+    "gvx_train_sqnorm_many": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "gvx_train_adam_step_many": (_i, [_vp, _i, _f, _f, _f, _f, _f, _f, _i, _vp]),
     "gvx_train_decoder_bptt_workspace_bytes": (_sz, [C.POINTER(gvx_bptt_decoder_args)]),
     "gvx_train_decoder_bptt": (_i, [C.POINTER(gvx_bptt_decoder_args), _vp, _sz, _vp]),
     "gvx_train_encoder_lstm_bptt_workspace_bytes": (_sz, [_i, _i]),

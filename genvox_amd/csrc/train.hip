@@ -470,33 +470,65 @@ __global__ void unblock_kernel(const float* src, float* dst, long n_slots, int B
         dst[i] = src[s * B * K + (long)(k >> 3) * B * 8 + b * 8 + (k & 7)];
     }
 }
-__global__ void embedding_bwd_kernel(const int64_t* tokens, const float* dx, long n_tok, int E, int n_rows, float* demb) {
-    const long n = n_tok * E;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const long t = i / E;
-        const int e = (int)(i % E);
-        const int64_t id = tokens[t];
-        if (id >= 0 && id < n_rows) atomicAdd(demb + id * E + e, dx[i]);
+// d embedding[row][e] = sum over the batch positions that hold token `row`, added in position order (no atomics: the result
+// does not depend on the launch's scheduling).  One workgroup per table row, threads over the channels.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* tokens, const float* dx, long n_tok, int E, int n_rows, float* demb) {
+    const int row = blockIdx.x;
+    for (int e0 = threadIdx.x; e0 < E; e0 += 4 * 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int e1 = e0 + 256, e2 = e0 + 512, e3 = e0 + 768;
+        for (long t = 0; t < n_tok; ++t) {
+            if (tokens[t] != row) continue;   // (uniform across the workgroup)
+            const float* r = dx + t * E;
+            a0 += r[e0];
+            if (e1 < E) a1 += r[e1];
+            if (e2 < E) a2 += r[e2];
+            if (e3 < E) a3 += r[e3];
+        }
+        demb[(long)row * E + e0] = a0;
+        if (e1 < E) demb[(long)row * E + e1] = a1;
+        if (e2 < E) demb[(long)row * E + e2] = a2;
+        if (e3 < E) demb[(long)row * E + e3] = a3;
     }
 }
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* x, long n, double* acc) {
+// sum of squares of MANY tensors in one launch: workgroup (x, tensor) writes its partial (double) to partials[tensor][x]; a
+// second tiny launch adds all partials in index order - the total does not depend on the launch's scheduling (torch's
+// clip_grad_norm_ on the reference side is a tree of its own; this one is at least reproducible)
+constexpr int SQN_BLOCKS = 64;
+__global__ __launch_bounds__(256) void sqnorm_many_kernel(const gvx_tensor_ref* refs, double* partials) {
     __shared__ double red[256];
-    double s = 0.0;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += (double)x[i] * (double)x[i];
-    red[threadIdx.x] = s;
+    const gvx_tensor_ref r = refs[blockIdx.y];
+    double s0 = 0.0, s1 = 0.0;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)SQN_BLOCKS * 256;
+    for (; i + stride < r.numel; i += 2 * stride) {
+        const double a = r.data[i], b = r.data[i + stride];
+        s0 += a * a; s1 += b * b;
+    }
+    if (i < r.numel) { const double a = r.data[i]; s0 += a * a; }
+    red[threadIdx.x] = s0 + s1;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+    if (threadIdx.x == 0) partials[(long)blockIdx.y * SQN_BLOCKS + blockIdx.x] = red[0];
 }
-// torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected), gradient pre-scaled by gscale (clipping)
-__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float gscale, float lr, float wd, float b1, float b2, float eps,
-                            float bc1, float bc2_sqrt) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale + wd * p[i];
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+__global__ void sqnorm_finish_kernel(const double* partials, int n, double* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += partials[i];
+        out[0] = s;
+    }
+}
+// torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected), gradient pre-scaled by gscale (clipping),
+// for MANY tensors in one launch: workgroup (x, tensor) walks its share of the tensor
+__global__ void adam_many_kernel(const gvx_adam_ref* refs, float gscale, float lr, float wd, float b1, float b2, float eps, float bc1,
+                                 float bc2_sqrt) {
+    const gvx_adam_ref r = refs[blockIdx.y];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < r.numel; i += (long)gridDim.x * blockDim.x) {
+        const float gi = r.grad[i] * gscale + wd * r.param[i];
+        const float mi = b1 * r.exp_avg[i] + (1.f - b1) * gi;
+        const float vi = b2 * r.exp_avg_sq[i] + (1.f - b2) * gi * gi;
+        r.exp_avg[i] = mi; r.exp_avg_sq[i] = vi;
+        r.param[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
     }
 }
 
@@ -556,23 +588,24 @@ int gvx_train_unblock(const float* blocked, float* rows_out, long n_slots, int B
 }
 int gvx_train_embedding_backward(const int64_t* tokens, const float* dx, long n_tokens_in_batch, int E, int n_rows, float* demb, void* stream) {
     if (!tokens || !dx || !demb || n_tokens_in_batch < 1 || E < 1 || n_rows < 1) return tfail(GVX_ERR_INVALID_ARG, "embedding_backward: bad argument");
-    TR_TRY(hipMemsetAsync(demb, 0, (size_t)n_rows * E * sizeof(float), (hipStream_t)stream));
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(blocks_for(n_tokens_in_batch * E)), dim3(256), 0, (hipStream_t)stream, tokens, dx, n_tokens_in_batch, E, n_rows, demb);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, tokens, dx, n_tokens_in_batch, E, n_rows, demb);
     TR_TRY(hipGetLastError());
     return GVX_OK;
 }
-int gvx_train_sqnorm_accumulate(const float* x, long n, double* acc, void* stream) {
-    if (!x || !acc || n < 1) return tfail(GVX_ERR_INVALID_ARG, "sqnorm: bad argument");
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks_for(n) > 256 ? 256 : blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, acc);
+int gvx_train_sqnorm_many(const gvx_tensor_ref* refs_device, int n_tensors, double* scratch, double* sumsq_out, void* stream) {
+    if (!refs_device || !scratch || !sumsq_out || n_tensors < 1) return tfail(GVX_ERR_INVALID_ARG, "sqnorm_many: bad argument");
+    hipLaunchKernelGGL(sqnorm_many_kernel, dim3(SQN_BLOCKS, n_tensors), dim3(256), 0, (hipStream_t)stream, refs_device, scratch);
+    hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, SQN_BLOCKS * n_tensors, sumsq_out);
     TR_TRY(hipGetLastError());
     return GVX_OK;
 }
-int gvx_train_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float grad_scale, float lr, float weight_decay,
-                        float beta1, float beta2, float eps, int step, void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return tfail(GVX_ERR_INVALID_ARG, "adam_step: bad argument");
+size_t gvx_train_sqnorm_scratch_bytes(int n_tensors) { return n_tensors < 1 ? 0 : (size_t)SQN_BLOCKS * n_tensors * sizeof(double); }
+int gvx_train_adam_step_many(const gvx_adam_ref* refs_device, int n_tensors, float grad_scale, float lr, float weight_decay, float beta1,
+                             float beta2, float eps, int step, void* stream) {
+    if (!refs_device || n_tensors < 1 || step < 1) return tfail(GVX_ERR_INVALID_ARG, "adam_step_many: bad argument");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, grad_scale, lr, weight_decay,
-                       beta1, beta2, eps, bc1, bc2s);
+    hipLaunchKernelGGL(adam_many_kernel, dim3(128, n_tensors), dim3(256), 0, (hipStream_t)stream, refs_device, grad_scale, lr, weight_decay, beta1, beta2,
+                       eps, bc1, bc2s);
     TR_TRY(hipGetLastError());
     return GVX_OK;
 }

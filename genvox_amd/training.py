@@ -407,21 +407,33 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     return g
 
 
+def _device_table(entries, dev) -> torch.Tensor:
+    """A ctypes array of reference structs as device bytes (what the many-tensor kernels index by blockIdx.y)."""
+    raw = bytes(entries)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+
 def clip_grad_norm(grads: Dict[str, torch.Tensor], max_norm: float) -> Tuple[float, float]:
-    """torch.nn.utils.clip_grad_norm_ (models/tts/tacotron2.py:521): returns (total norm, scale to apply to every gradient)."""
+    """torch.nn.utils.clip_grad_norm_ (models/tts/tacotron2.py:521): returns (total norm, scale to apply to every gradient).
+    One launch over all gradients + one that adds the partial sums in a fixed order (reproducible bit for bit)."""
     lib = _lib.load()
-    any_g = next(iter(grads.values()))
-    acc = torch.zeros(1, dtype=torch.float64, device=any_g.device)
-    st = torch.cuda.current_stream(any_g.device).cuda_stream
-    for v in grads.values():
-        _lib.check(lib.gvx_train_sqnorm_accumulate(_p(v.contiguous()), v.numel(), _p(acc), st))
-    total = float(acc.sqrt().item())
+    gs = [v if v.is_contiguous() else v.contiguous() for v in grads.values()]
+    dev = gs[0].device
+    st = torch.cuda.current_stream(dev).cuda_stream
+    refs = (_lib.gvx_tensor_ref * len(gs))()
+    for i, v in enumerate(gs):
+        refs[i] = _lib.gvx_tensor_ref(v.data_ptr(), v.numel())
+    table = _device_table(refs, dev)
+    scratch = torch.empty(lib.gvx_train_sqnorm_scratch_bytes(len(gs)), dtype=torch.uint8, device=dev)
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    _lib.check(lib.gvx_train_sqnorm_many(_p(table), len(gs), _p(scratch), _p(out), st))
+    total = float(out.sqrt().item())
     coef = max_norm / (total + 1e-6)
     return total, (coef if coef < 1.0 else 1.0)
 
 
 class Adam:
-    """torch.optim.Adam as the reference configures it (models/tts/tacotron2.py:506-513), one HIP kernel per tensor."""
+    """torch.optim.Adam as the reference configures it (models/tts/tacotron2.py:506-513): one HIP launch for all parameters."""
 
     def __init__(self, model, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8):
         self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
@@ -431,12 +443,19 @@ class Adam:
     def step(self, grads: Dict[str, torch.Tensor], grad_scale: float = 1.0) -> None:
         lib = _lib.load()
         self.step_count += 1
-        for name, p in self.model.named_parameters():
+        params = list(self.model.named_parameters())
+        refs = (_lib.gvx_adam_ref * len(params))()
+        keep = []
+        for i, (name, p) in enumerate(params):
             gk = grads[name].contiguous()
+            keep.append(gk)
             if name not in self.state:
                 self.state[name] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
             m, v = self.state[name]
-            _lib.check(lib.gvx_train_adam_step(_p(p.data), _p(gk), _p(m), _p(v), p.numel(), float(grad_scale), float(self.lr), float(self.wd),
-                                               float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count,
-                                               torch.cuda.current_stream(p.device).cuda_stream))
-            p.data.add_(0)   # bump the tensor version: the packed blob is re-built before the next forward
+            refs[i] = _lib.gvx_adam_ref(p.data.data_ptr(), gk.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+        dev = params[0][1].device
+        table = _device_table(refs, dev)
+        _lib.check(lib.gvx_train_adam_step_many(_p(table), len(params), float(grad_scale), float(self.lr), float(self.wd), float(self.betas[0]),
+                                                float(self.betas[1]), float(self.eps), self.step_count, torch.cuda.current_stream(dev).cuda_stream))
+        # the parameters changed through raw pointers: the packed blob of the forward kernels is stale
+        self.model._packed_key = None

@@ -260,9 +260,15 @@ int gvx_train_axpby(const float* a, long lda, float alpha, const float* b, long 
 int gvx_train_relu_dropout_backward(const float* dy, const float* act_out, const uint8_t* keep, float scale, long n, float* dz, void* stream);
 int gvx_train_unblock(const float* blocked, float* rows_out, long n_slots, int B, int K, void* stream);
 int gvx_train_embedding_backward(const int64_t* tokens, const float* dx, long n_tokens_in_batch, int E, int n_rows, float* demb, void* stream);
-int gvx_train_sqnorm_accumulate(const float* x, long n, double* acc, void* stream);
-int gvx_train_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float grad_scale, float lr, float weight_decay,
-                        float beta1, float beta2, float eps, int step, void* stream);
+/* Many tensors per launch (device arrays of references, built by the caller once per step): sum of squares of all of them -
+ * the square of clip_grad_norm_'s total norm, added in a fixed order (scratch: gvx_train_sqnorm_scratch_bytes) - and the Adam
+ * update of all of them. */
+typedef struct gvx_tensor_ref { const float* data; int64_t numel; } gvx_tensor_ref;
+typedef struct gvx_adam_ref { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t numel; } gvx_adam_ref;
+size_t gvx_train_sqnorm_scratch_bytes(int n_tensors);
+int gvx_train_sqnorm_many(const gvx_tensor_ref* refs_device, int n_tensors, double* scratch, double* sumsq_out, void* stream);
+int gvx_train_adam_step_many(const gvx_adam_ref* refs_device, int n_tensors, float grad_scale, float lr, float weight_decay, float beta1,
+                             float beta2, float eps, int step, void* stream);
 
 /* ---- Back-propagation through the decoder loop in one call (three launches per step issued by the library instead of ~20
  * primitives per step strung together by the host): d loss / d of both LSTM cells' gates at every step, of the attention

@@ -41,6 +41,8 @@ import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
+# (kernel, batch rows, tokens) -> HBM bytes per launch measured with PMC counters (profiles/r03_pmc_sq_pa.json: 1.06 x algorithmic)
+MEASURED_HBM_BYTES_PER_LAUNCH = {("decoder_lstm_step_pa_kernel", 32, 128): 74524540}
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
@@ -255,7 +257,12 @@ def main():
             if persistent else f"decoder_lstm_step_kernel<{2 if b > 32 else 1}>"
         return {"bound": "hbm", "kernel": kname,
                 "achieved": round(gbs, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; counter
+                # collection serialises kernels, so it cannot run inside this command): the committed measurement of the same
+                # kernel at this shape, not something read at bench time
+                "traffic": MEASURED_HBM_BYTES_PER_LAUNCH.get((kname, b, L)),
+                "traffic_source": "profiles/r03_pmc_sq_pa.json" if (kname, b, L) in MEASURED_HBM_BYTES_PER_LAUNCH else None,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(kt["decoder_lstm_step"] * 1e3, 2),
                 "attention": "attn_persistent_kernel (one launch per decoder loop, 32 CUs)" if persistent else "attn_step_kernel per step",
                 "attention_launch_us": None if persistent else round(kt["attention_step"] * 1e3, 2),

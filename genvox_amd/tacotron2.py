@@ -327,7 +327,7 @@ class Tacotron2(nn.Module):
         """Teacher-forced text->mel (reference: models/tts/tacotron2.py:450-481).  No autograd graph is built in either
         mode.  Under ``.train()`` the forward is the reference's training-mode forward - BatchNorm batch statistics (and the
         running-statistics update), dropout after the encoder / Postnet convolutions and on both LSTM cells' outputs - see
-        ``_forward_train``; the backward of the training step exists for its convolution stacks only (genvox_amd.training)."""
+        ``_forward_train`` (the backward through the whole model is genvox_amd.training.train_backward; ``train_step`` runs both)."""
         dev = self._require_gpu()
         if self.training:
             return self._forward_train(batch)[0]
@@ -654,8 +654,9 @@ class Tacotron2(nn.Module):
         """One training step (reference: tacotron2.py:515-522): training-mode forward, Tacotron2Loss, backward through the whole
         model, clip_grad_norm_, Adam.  No autograd: the backward is explicit (genvox_amd.training.train_backward, HIP kernels
         behind the C ABI; the formulas are pinned to the reference's loss.backward() through oracle/train_ref.py).  Fills
-        ``loss_items`` and ``grad_norm_val`` like the reference.  First version: correct, not tuned (the decoder loop is
-        walked back with ~20 small launches per step); at most 32 rows per call."""
+        ``loss_items`` and ``grad_norm_val`` like the reference.  Any batch size (the recurrent part runs in chunks of at most
+        32 rows); both recurrences are walked back inside single C-ABI calls and the packed blob is re-built on the device:
+        32 ms per step at 32 x 200 frames, reproducible bit for bit (profiles/r03_train_step_timing.txt)."""
         from . import training
 
         if optimizer is None:

@@ -16,7 +16,7 @@ Pinned by ``tests/golden/train_small.npz`` - the reference's own train step (all
 every parameter after the Adam update) - and against the oracle at the default layer sizes (tests/test_training_gpu.py).
 Dropout keep masks are explicit inputs where parity is tested (uint8, the shape of the dropout's input) and drawn on the
 device otherwise.  32 x 200 frames x 128 tokens: 0.54 s per step with the first version (host-strung primitives, host
-re-packing), about 0.035 s now (profiles/r03_train_step_timing.txt).
+re-packing), 0.032 s now (profiles/r03_train_step_timing.txt).
 """
 from __future__ import annotations
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "gvx_conv_bn_act_train_backward": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gvx_tacotron2_loss_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gvx_train_gemm_nt": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "gvx_train_gemm_tn": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _l, _vp, _sz, _vp]),
     "gvx_train_transpose": (_i, [_vp, _l, _vp, _l, _i, _l, _vp]),
     "gvx_train_colsum": (_i, [_vp, _l, _i, _vp, _vp]),
     "gvx_train_axpby": (_i, [_vp, _l, _f, _vp, _l, _f, _vp, _l, _l, _i, _vp]),

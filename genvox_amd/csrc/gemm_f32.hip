@@ -32,7 +32,9 @@ __device__ __forceinline__ long row_off(const RowMap& m, int row) {
     return (long)(row / m.R) * m.s1 + (long)(row % m.R) * m.s0;
 }
 
-template <int WR, int WC, int TM, int TN>
+// KMAJ: both operands are K-major - element (m, k) of A at A + amap(k) + m, element (n, k) of W at W + wmap(k) + n - the
+// form of a weight gradient (sum over the rows of two activation matrices) without transposed copies.
+template <int WR, int WC, int TM, int TN, bool KMAJ = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int BM = WR * TM * 32;
     constexpr int BN = WC * TN * 32;
@@ -59,24 +61,68 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int ld_row = tid >> 3, ld_c4 = tid & 7;
     const float* a_ptr[A_V4]; bool a_ok[A_V4];
     const float* b_ptr[B_V4]; bool b_ok[B_V4];
+    // K-major operands: a thread owns 4 consecutive rows of the tile (m or n) and one quad of k per pass: four 16-byte loads
+    // (one per k, coalesced across the lanes along m), a 4 x 4 transpose in registers, four 16-byte LDS stores (one per m) in
+    // the same [row][k] layout as the row-major form.  Needs M, N and the row strides to be multiples of 4.
+    constexpr int A_MQ = BM / 4, B_NQ = BN / 4;             // threads along m / n
+    constexpr int A_P = (8 * A_MQ + 255) / 256, B_P = (8 * B_NQ + 255) / 256;   // passes over the tile's 8 k-quads
+    const int amq = tid % A_MQ, akq = tid / A_MQ, bnq = tid % B_NQ, bkq = tid / B_NQ;
+    const int a_col = min(m0 + 4 * amq, p.M - 4), b_col = min(n0 + 4 * bnq, p.N - 4);   // (rows past M / N are never stored)
+    // (group, index) of the first k of the thread's quads under the two-level row maps, kept up to date from k-tile to k-tile
+    // by increments (a division per load would make the K-major form VALU bound)
+    int ak_g[A_P], ak_i[A_P], bk_g[B_P], bk_i[B_P];
+    long a_safe = 0, b_safe = 0;
+    float4 ka_reg[A_P][4], kb_reg[B_P][4];
+    if (KMAJ) {
 #pragma unroll
-    for (int i = 0; i < A_V4; ++i) {
-        int m = m0 + ld_row + 32 * i;
-        a_ok[i] = m < p.M;
-        a_ptr[i] = p.A + (a_ok[i] ? row_off(p.amap, m) : 0);
+        for (int i = 0; i < A_P; ++i) { const int k = k_begin + 4 * (akq + (256 / A_MQ) * i); ak_g[i] = k / p.amap.R; ak_i[i] = k - ak_g[i] * p.amap.R; }
+#pragma unroll
+        for (int i = 0; i < B_P; ++i) { const int k = k_begin + 4 * (bkq + (256 / B_NQ) * i); bk_g[i] = k / p.wmap.R; bk_i[i] = k - bk_g[i] * p.wmap.R; }
+        a_safe = row_off(p.amap, k_begin); b_safe = row_off(p.wmap, k_begin);
     }
+    if (!KMAJ) {
 #pragma unroll
-    for (int i = 0; i < B_V4; ++i) {
-        int n = n0 + ld_row + 32 * i;
-        b_ok[i] = n < p.N;
-        b_ptr[i] = p.W + (b_ok[i] ? (long)n * p.ldw : 0);
+        for (int i = 0; i < A_V4; ++i) {
+            int m = m0 + ld_row + 32 * i;
+            a_ok[i] = m < p.M;
+            a_ptr[i] = p.A + (a_ok[i] ? row_off(p.amap, m) : 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) {
+            int n = n0 + ld_row + 32 * i;
+            b_ok[i] = n < p.N;
+            b_ptr[i] = p.W + (b_ok[i] ? (long)n * p.ldw : 0);
+        }
     }
     float4 a_reg[A_V4], b_reg[B_V4];
 
     // global -> registers for the k-tile starting at K0.  Rows past M / N read row 0 (in bounds): their products land in
     // accumulator rows / columns the epilogue never stores, so only the k tail is masked (per component: a float4
     // select makes LLVM build a scratch lookup table).
+#define GEMM_KMAJ_LOAD(NP, QPP, KQ, KG, KI, MAP, SAFE, PTR, COL, REG)                                        \
+        _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                    \
+            const int c_ = KQ + QPP * i;                                                                    \
+            if (c_ < BK / 4) {                                                                              \
+                const int kq_ = (K0_) + 4 * c_;                                                             \
+                int g_ = KG[i], x_ = KI[i];                                                                 \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+                    const bool ok_ = kq_ + j < k_end;                                                       \
+                    const float4 ld_ = *reinterpret_cast<const float4*>(PTR + (ok_ ? (long)g_ * MAP.s1 + (long)x_ * MAP.s0 : SAFE) + COL); \
+                    REG[i][j].x = ok_ ? ld_.x : 0.f; REG[i][j].y = ok_ ? ld_.y : 0.f;                       \
+                    REG[i][j].z = ok_ ? ld_.z : 0.f; REG[i][j].w = ok_ ? ld_.w : 0.f;                       \
+                    if (++x_ == MAP.R) { x_ = 0; ++g_; }                                                    \
+                }                                                                                           \
+                x_ = KI[i] + BK; g_ = KG[i];                                                                \
+                while (x_ >= MAP.R) { x_ -= MAP.R; ++g_; }                                                  \
+                KI[i] = x_; KG[i] = g_;                                                                     \
+            }                                                                                               \
+        }
 #define GEMM_LOAD_TILE(K0)                                                                                  \
+    if (KMAJ) {                                                                                             \
+        const int K0_ = (K0);                                                                               \
+        GEMM_KMAJ_LOAD(A_P, (256 / A_MQ), akq, ak_g, ak_i, p.amap, a_safe, p.A, a_col, ka_reg)              \
+        GEMM_KMAJ_LOAD(B_P, (256 / B_NQ), bkq, bk_g, bk_i, p.wmap, b_safe, p.W, b_col, kb_reg)              \
+    } else                                                                                                  \
     {                                                                                                       \
         const int k_ = (K0) + 4 * ld_c4;                                                                    \
         const bool k_ok_ = k_ < k_end;                                                                      \
@@ -92,7 +138,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             b_reg[i].z = k_ok_ ? v_.z : 0.f; b_reg[i].w = k_ok_ ? v_.w : 0.f;                               \
         }                                                                                                   \
     }
+#define GEMM_KMAJ_STORE(NP, QPP, KQ, SM, ROWS, RQ, REG, BUF)                                                 \
+        _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                    \
+            const int c_ = KQ + QPP * i;                                                                    \
+            if (c_ < BK / 4) {                                                                              \
+                float* d_ = &SM[((BUF) * ROWS + 4 * RQ) * LDS_LD + 4 * c_];                                 \
+                *reinterpret_cast<float4*>(d_) = make_float4(REG[i][0].x, REG[i][1].x, REG[i][2].x, REG[i][3].x);              \
+                *reinterpret_cast<float4*>(d_ + LDS_LD) = make_float4(REG[i][0].y, REG[i][1].y, REG[i][2].y, REG[i][3].y);     \
+                *reinterpret_cast<float4*>(d_ + 2 * LDS_LD) = make_float4(REG[i][0].z, REG[i][1].z, REG[i][2].z, REG[i][3].z); \
+                *reinterpret_cast<float4*>(d_ + 3 * LDS_LD) = make_float4(REG[i][0].w, REG[i][1].w, REG[i][2].w, REG[i][3].w); \
+            }                                                                                               \
+        }
 #define GEMM_STORE_TILE(BUF)                                                                                \
+    if (KMAJ) {                                                                                             \
+        GEMM_KMAJ_STORE(A_P, (256 / A_MQ), akq, As, BM, amq, ka_reg, BUF)                                   \
+        GEMM_KMAJ_STORE(B_P, (256 / B_NQ), bkq, Bs, BN, bnq, kb_reg, BUF)                                   \
+    } else                                                                                                  \
     {                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < A_V4; ++i)                                                    \
             *reinterpret_cast<float4*>(&As[((BUF) * BM + ld_row + 32 * i) * LDS_LD + 4 * ld_c4]) = a_reg[i]; \
@@ -142,6 +203,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
     GEMM_COMPUTE_TILE(kt & 1)               // last tile
 #undef GEMM_LOAD_TILE
+#undef GEMM_KMAJ_LOAD
+#undef GEMM_KMAJ_STORE
 #undef GEMM_STORE_TILE
 #undef GEMM_COMPUTE_TILE
 
@@ -180,9 +243,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 template <int WR, int WC, int TM, int TN>
 static size_t lds_bytes_cfg() { return (size_t)2 * (WR * TM * 32 + WC * TN * 32) * LDS_LD * sizeof(float); }
 
-template <int WR, int WC, int TM, int TN>
+template <int WR, int WC, int TM, int TN, bool KMAJ = false>
 static hipError_t init_cfg() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<WR, WC, TM, TN>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<WR, WC, TM, TN, KMAJ>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_cfg<WR, WC, TM, TN>());
 }
 
@@ -195,19 +258,28 @@ hipError_t gemm_init() {
     if (e != hipSuccess) return e;
     e = init_cfg<2, 2, 1, 1>();
     if (e != hipSuccess) return e;
+    e = init_cfg<2, 2, 2, 2, true>();
+    if (e != hipSuccess) return e;
+    e = init_cfg<2, 2, 1, 2, true>();
+    if (e != hipSuccess) return e;
     return init_cfg<4, 1, 1, 1>();
 }
 
-template <int WR, int WC, int TM, int TN>
+template <int WR, int WC, int TM, int TN, bool KMAJ = false>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
     const int grid = ((p.M - p.m_begin + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    gemm_f32_kernel<WR, WC, TM, TN><<<dim3(grid, p.splitk > 1 ? p.splitk : 1), dim3(256), lds_bytes_cfg<WR, WC, TM, TN>(), s>>>(p);
+    gemm_f32_kernel<WR, WC, TM, TN, KMAJ><<<dim3(grid, p.splitk > 1 ? p.splitk : 1), dim3(256), lds_bytes_cfg<WR, WC, TM, TN>(), s>>>(p);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if (p.kmajor) {   // K-major operands (weight gradients): the two square-ish tile shapes only, any K; 16-byte pieces along m / n
+        if ((p.M & 3) || (p.N & 3) || p.M < 4 || p.N < 4 || ((p.amap.s0 | p.amap.s1 | p.wmap.s0 | p.wmap.s1) & 3)) return hipErrorInvalidValue;
+        const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        return t128 < 384 ? launch_cfg<2, 2, 1, 2, true>(p, s) : launch_cfg<2, 2, 2, 2, true>(p, s);
+    }
     if (p.K & 3) return hipErrorInvalidValue;
     if (p.N <= 32) return launch_cfg<4, 1, 1, 1>(p, s);
     if (p.N <= 96) return launch_cfg<4, 1, 1, 3>(p, s);

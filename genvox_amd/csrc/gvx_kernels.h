@@ -55,6 +55,7 @@ struct GemmParams {
     // tile, split s sums k in [s * kchunk, (s + 1) * kchunk) and writes its partial tile at C + s * c_split; no bias /
     // activation / mask then (launch_gemm_splitk adds the partials in split order and the bias)
     int splitk = 1; int kchunk = 0; long c_split = 0;
+    bool kmajor = false; RowMap wmap{1, 0, 0};   // K-major operands: A(m, k) at A + amap(k) + m, W(n, k) at W + wmap(k) + n (ldw, a_kblk unused)
     int m_begin = 0;                   // first row of this launch (launch_gemm may cover the rows of one product with two tile shapes)
     const int32_t* row_len = nullptr;  // [M / cmap.R] valid rows per group: rows at or past it are written as zeros
     int c_halo = 0;                    // > 0: C has c_halo halo rows before and after each group's cmap.R rows (C points at

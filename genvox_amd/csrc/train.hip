@@ -196,22 +196,6 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* src, fl
         if (c < C && r < rows_p) dst[(long)c * rows_p + r] = tile[tx][ty + 8 * i];
     }
 }
-// XT[(j*Cin + ci)][b*T + t] = xcl[b][t + j][ci]   (xcl halo-padded channels-last), rows padded with zeros up to rows_p
-__global__ void im2col_t_kernel(const float* xcl, float* xt, int B, int Cin, int T, int k, long rows_p) {
-    const int pad = (k - 1) / 2;
-    const long n = (long)k * Cin * rows_p;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const long r = i % rows_p;
-        const long jc = i / rows_p;
-        const int ci = (int)(jc % Cin), j = (int)(jc / Cin);
-        float v = 0.f;
-        if (r < (long)B * T) {
-            const int t = (int)(r % T), b = (int)(r / T);
-            v = xcl[((long)b * (T + 2 * pad) + t + j) * Cin + ci];
-        }
-        xt[i] = v;
-    }
-}
 // dwk [Cout][k][Cin] -> dw [Cout][Cin][k]
 __global__ void unpack_dw_kernel(const float* dwk, float* dw, int Cout, int Cin, int k) {
     const long n = (long)Cout * Cin * k;
@@ -247,11 +231,11 @@ inline int blocks_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1
 // layout of the saved-for-backward buffer and of the scratch of one layer (byte offsets)
 struct ConvTrainPlan {
     size_t xcl, xhat, a, mean, invstd, saved_total;                       // saved
-    size_t wk, w2, z, du, dz, dzh, dzt, xt, dwk, dxcl, xcl2, dwk_part, ws_total;   // workspace
+    size_t wk, w2, z, du, dz, dzh, dwk, dxcl, xcl2, dwk_part, ws_total;   // workspace
 };
 ConvTrainPlan conv_train_plan(int B, int Cin, int Cout, int T, int k) {
     const int pad = (k - 1) / 2;
-    const long rows = (long)B * T, rows_p = (rows + 3) / 4 * 4;
+    const long rows = (long)B * T;
     ConvTrainPlan p{};
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o = up256(o + floats * sizeof(float)); return r; };
@@ -268,8 +252,6 @@ ConvTrainPlan conv_train_plan(int B, int Cin, int Cout, int T, int k) {
     p.du = take((size_t)rows * Cout);
     p.dz = take((size_t)rows * Cout);
     p.dzh = take((size_t)B * (T + 2 * pad) * Cout);
-    p.dzt = take((size_t)Cout * rows_p);
-    p.xt = take((size_t)k * Cin * rows_p);
     p.dwk = take((size_t)Cout * k * Cin);
     p.dxcl = take((size_t)rows * Cin);
     p.xcl2 = take((size_t)B * (T + 2 * pad) * Cin);
@@ -364,7 +346,7 @@ int gvx_conv_bn_act_train_backward(const float* dy, const void* saved, size_t sa
     if (saved_bytes < pl.saved_total || workspace_bytes < pl.ws_total) return tfail(GVX_ERR_WORKSPACE, "saved / workspace buffer too small");
     hipStream_t s = (hipStream_t)stream;
     const int pad = (k - 1) / 2;
-    const long rows = (long)B * T, rows_p = (rows + 3) / 4 * 4;
+    const long rows = (long)B * T;
     const float* xhat = at<float>(saved, pl.xhat);
     const float* a = at<float>(saved, pl.a);
     const float* invstd = at<float>(saved, pl.invstd);
@@ -378,7 +360,6 @@ int gvx_conv_bn_act_train_backward(const float* dy, const void* saved, size_t sa
     TR_TRY(hipMemsetAsync(dzh, 0, (size_t)B * (T + 2 * pad) * Cout * sizeof(float), s));
     hipLaunchKernelGGL(bn_bwd_kernel, dim3(blocks_for(rows * Cout)), dim3(256), 0, s, du, xhat, gamma, invstd, dbeta, dgamma, B, Cout, T, pad, dz, dzh);
     hipLaunchKernelGGL(col_reduce_kernel, dim3((Cout + 31) / 32), dim3(1024), 0, s, dz, (const float*)nullptr, rows, Cout, dbias, (float*)nullptr);
-    // weight gradient: dzT [Cout][rows_p] x XT [(j, ci)][rows_p]
     const float* xcl = at<float>(saved, pl.xcl);
     const float* xcl_w = xcl;
     if (x_wgrad) {   // (the reference masks the Postnet's input in place after its forward - outside autograd, so the first
@@ -387,21 +368,19 @@ int gvx_conv_bn_act_train_backward(const float* dy, const void* saved, size_t sa
         TR_TRY(launch_to_channels_last(x_wgrad, x2, B, Cin, T, pad, nullptr, s));
         xcl_w = x2;
     }
-    float* dzt = at<float>(workspace, pl.dzt);
-    float* xt = at<float>(workspace, pl.xt);
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((rows_p + 31) / 32), (Cout + 31) / 32), dim3(256), 0, s, dz, dzt, rows, Cout, rows_p);
-    hipLaunchKernelGGL(im2col_t_kernel, dim3(blocks_for((long)k * Cin * rows_p)), dim3(256), 0, s, xcl_w, xt, B, Cin, T, k, rows_p);
     float* dwk = at<float>(workspace, pl.dwk);
-    {
+    {   // dwk[co][(j, ci)] = sum over the rows r = (b, t) of dz[r][co] * xcl[b][t + j][ci]: both operands K-major as they lie in
+        // memory (the im2col row of r is the k * Cin contiguous floats at padded row t) - no transposed copies
         GemmParams g{};
-        g.A = dzt; g.amap = RowMap{Cout, 0, rows_p};
-        g.W = xt; g.ldw = rows_p;
+        g.kmajor = true;
+        g.A = dz; g.amap = RowMap{(int)rows, 0, (long)Cout};
+        g.W = xcl_w; g.wmap = RowMap{T, (long)(T + 2 * pad) * Cin, (long)Cin};
         g.C = dwk; g.cmap = RowMap{Cout, 0, (long)k * Cin};
-        g.M = Cout; g.N = k * Cin; g.K = (int)rows_p; g.act = ACT_NONE;
+        g.M = Cout; g.N = k * Cin; g.K = (int)rows; g.act = ACT_NONE;
         // few output tiles, thousands of rows to sum over: K split over enough workgroups to fill the chip (the Postnet's 512 x 2560
         // gradients are 160 tiles, its first layer's 32: 290 / 330 us each as one round)
         const long tiles = (long)((Cout + 63) / 64) * ((k * Cin + 127) / 128);
-        TR_TRY(launch_gemm_splitk(g, choose_splitk(tiles, (int)rows_p), at<float>(workspace, pl.dwk_part), s));
+        TR_TRY(launch_gemm_splitk(g, choose_splitk(tiles, (int)rows), at<float>(workspace, pl.dwk_part), s));
     }
     hipLaunchKernelGGL(unpack_dw_kernel, dim3(blocks_for((long)Cout * Cin * k)), dim3(256), 0, s, dwk, dw, Cout, Cin, k);
     if (dx) {   // data gradient: flipped-tap implicit GEMM on the halo-padded dz
@@ -550,6 +529,22 @@ int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float*
     // enough workgroups to fill the chip, partial tiles in the caller's scratch, added in split order (deterministic)
     const long tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
     int splitk = scratch ? choose_splitk(tiles, K) : 1;
+    while (splitk > 1 && (size_t)splitk * M * N * sizeof(float) > scratch_bytes) --splitk;
+    TR_TRY(launch_gemm_splitk(g, splitk, scratch, (hipStream_t)stream));
+    return GVX_OK;
+}
+// C[m][n] = sum_r A[r * lda + m] * Bm[r * ldb + n]: the weight-gradient form, both operands as they lie in memory
+int gvx_train_gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, long rows, float* scratch,
+                      size_t scratch_bytes, void* stream) {
+    if (!A || !Bm || !C || M < 1 || N < 1 || rows < 1 || rows > (1L << 30)) return tfail(GVX_ERR_INVALID_ARG, "gemm_tn: bad argument");
+    GemmParams g{};
+    g.kmajor = true;
+    g.A = A; g.amap = RowMap{(int)rows, 0, lda};
+    g.W = Bm; g.wmap = RowMap{(int)rows, 0, ldb};
+    g.C = C; g.cmap = RowMap{M, 0, ldc};
+    g.M = M; g.N = N; g.K = (int)rows; g.act = ACT_NONE;
+    const long tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
+    int splitk = scratch ? choose_splitk(tiles, (int)rows) : 1;
     while (splitk > 1 && (size_t)splitk * M * N * sizeof(float) > scratch_bytes) --splitk;
     TR_TRY(launch_gemm_splitk(g, splitk, scratch, (hipStream_t)stream));
     return GVX_OK;

@@ -656,7 +656,7 @@ class Tacotron2(nn.Module):
         behind the C ABI; the formulas are pinned to the reference's loss.backward() through oracle/train_ref.py).  Fills
         ``loss_items`` and ``grad_norm_val`` like the reference.  Any batch size (the recurrent part runs in chunks of at most
         32 rows); both recurrences are walked back inside single C-ABI calls and the packed blob is re-built on the device:
-        32 ms per step at 32 x 200 frames, reproducible bit for bit (profiles/r03_train_step_timing.txt)."""
+        31 ms per step at 32 x 200 frames, reproducible bit for bit (profiles/r03_train_step_timing.txt)."""
         from . import training
 
         if optimizer is None:

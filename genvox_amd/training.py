@@ -16,7 +16,7 @@ Pinned by ``tests/golden/train_small.npz`` - the reference's own train step (all
 every parameter after the Adam update) - and against the oracle at the default layer sizes (tests/test_training_gpu.py).
 Dropout keep masks are explicit inputs where parity is tested (uint8, the shape of the dropout's input) and drawn on the
 device otherwise.  32 x 200 frames x 128 tokens: 0.54 s per step with the first version (host-strung primitives, host
-re-packing), 0.032 s now (profiles/r03_train_step_timing.txt).
+re-packing), 0.031 s now (profiles/r03_train_step_timing.txt).
 """
 from __future__ import annotations
 
@@ -200,8 +200,14 @@ class _Ops:
         return out
 
     def mm_tn(self, A, Bm):
-        """A^T @ Bm for A [R, M], Bm [R, N] -> [M, N] (the weight-gradient form: both operands made row-contiguous in R)."""
-        return self.gemm_nt(self.transpose(A), self.transpose(Bm))
+        """A^T @ Bm for A [R, M], Bm [R, N] -> [M, N] (the weight-gradient form: the K-major GEMM reads both as they lie)."""
+        R, M = A.shape
+        R2, N = Bm.shape
+        assert R == R2, (A.shape, Bm.shape)
+        out = self.new(M, N)
+        _lib.check(self.lib.gvx_train_gemm_tn(_p(A), self._ld(A), _p(Bm), self._ld(Bm), _p(out), N, M, N, R, _p(self.scratch),
+                                              self.scratch.numel() * 4, self.st))
+        return out
 
     def colsum(self, X):
         X = X.contiguous()

@@ -254,6 +254,10 @@ int gvx_tacotron2_loss_backward(const float* mel_out, const float* mel_post_out,
  * partial tiles, used when the product has few output tiles and a long K. */
 int gvx_train_gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K, const float* bias,
                       float* scratch, size_t scratch_bytes, void* stream);
+/* C[m][n] = sum_r A[r * lda + m] Bm[r * ldb + n] (a weight gradient: the sum over the rows of two activation matrices, no
+ * transposed copies). */
+int gvx_train_gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, long rows, float* scratch,
+                      size_t scratch_bytes, void* stream);
 int gvx_train_transpose(const float* src, long ld_src, float* dst, long rows, int cols, long rows_padded, void* stream);
 int gvx_train_colsum(const float* X, long rows, int C, float* out, void* stream);
 int gvx_train_axpby(const float* a, long lda, float alpha, const float* b, long ldb, float beta, float* y, long ldy, long rows, int cols, void* stream);

@@ -1103,11 +1103,8 @@ int gvx_train_decoder_bptt(const gvx_bptt_decoder_args* ap, void* workspace, siz
     float* ws = reinterpret_cast<float*>(workspace);
     const int B = a.B, L = a.L, T = a.T, A = a.A, D = a.D, E = a.E, P = a.P, G = pl.G, Na = pl.Na, Nd = pl.Nd;
     const int Ka = 4 * A, Kd = 4 * D;
-    static bool lds_set = false;
-    if (!lds_set) {
-        TR_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bptt_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_set = true;
-    }
+    // (per call, not once per process: the attribute belongs to the current device)
+    TR_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bptt_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t lds_attn = bptt_attn_lds_floats(L, E, a.a, a.F, a.kl, G) * sizeof(float);
 
     // ---- before the loop: transposed matrices in fragment order, cumulative weights, cleared state and accumulators
@@ -1428,11 +1425,7 @@ int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const floa
     if (lds > 160 * 1024) return tfail(GVX_ERR_UNSUPPORTED, "encoder_lstm_bptt: H too large for the LDS");
     hipStream_t s = (hipStream_t)stream;
     float* ws = reinterpret_cast<float*>(workspace);
-    static bool lds_set = false;
-    if (!lds_set) {
-        TR_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_bptt_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_set = true;
-    }
+    TR_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_bptt_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(transpose_batched_kernel, dim3(blocks_for((long)2 * 4 * H * H)), dim3(256), 0, s, w_hh, ws + pl.wt, 2, 4 * H, H);
     TR_TRY(hipMemsetAsync(ws + pl.dg, 0, (pl.total - pl.dg) * sizeof(float), s));
     TR_TRY(hipMemsetAsync(dg_pos, 0, (size_t)2 * B * L * 4 * H * sizeof(float), s));

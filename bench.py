@@ -455,6 +455,12 @@ def main():
                 cs = time.perf_counter() - c0
                 e["cpu_baseline"] = {"mel_frames_per_s": round(Bc * Tc2 / cs, 1), "cores": n_thr, "kind": "port",
                                      "sample": f"oracle train_forward + train_backward (explicit formulas, torch CPU), batch {Bc} x {Tc2} frames x {Lc} tokens, {cs:.1f} s"}
+            # the same step at the C2 size (32 x 800 frames): what one batch of the headline configuration costs to train on
+            tb8 = {k: torch.from_numpy(v).to(dev) for k, v in gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=3).items()}
+            dt8 = timed(torch, lambda: model.train_step(tb8, model.get_criterion(), opt), 1, 2)
+            model.check_status()
+            e["c2_size_b32x800"] = {"s_per_step": round(dt8, 4), "mel_frames_per_s": round(B * T / dt8, 1)}
+            del tb8
             extra["train_step_b32x200"] = e
             model.load_state_dict(sd_keep)
             model.eval()

@@ -15,7 +15,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == c:
-            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     out[c] = {k: {"launches": len(v), "avg_KiB": sum(v) / len(v)} for k, v in agg.items() if "gvx::" in k}
 rows = []
 for k in sorted(out["FETCH_SIZE"], key=lambda k: -out["FETCH_SIZE"][k]["avg_KiB"] * out["FETCH_SIZE"][k]["launches"]):

@@ -441,7 +441,7 @@ def main():
             e["mfma_frac_of_157TF"] = round(e["tflops"] / 157.3, 4)
             if with_cpu:
                 from oracle import train_ref
-                Bc, Lc, Tc2 = 4, 64, 24
+                Bc, Lc, Tc2 = 8, 64, 96
                 cb = {k: torch.from_numpy(v) for k, v in gw.synthetic_inputs(Bc, Lc, Tc2, tc.n_tokens, ac.n_mels, seed=3).items()}
                 gen = torch.Generator().manual_seed(1)
                 bern = lambda shape, p: (torch.rand(shape, generator=gen) >= p).to(torch.uint8)

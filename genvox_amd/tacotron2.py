@@ -665,6 +665,9 @@ class Tacotron2(nn.Module):
         outputs, tape = self._forward_train(batch)
         loss = (criterion or self.get_criterion())["loss"](batch, outputs)
         self.loss_items = {key: val.item() for key, val in loss.items()}
+        # (the .item() calls have synchronised: a token id outside the table or a timed-out hand-off of the forward raises HERE,
+        # before NaN gradients could reach the weights)
+        self.check_status()
         grads = training.train_backward(self, batch, outputs, tape)
         self.grad_norm_val, scale = training.clip_grad_norm(grads, self.model_config.grad_clip_thresh)
         optimizer["optimizer"].step(grads, scale)

@@ -95,6 +95,31 @@ def test_pack_weights_errors_and_unsupported_dims():
     lib.gvx_model_destroy(h)
 
 
+def test_training_entry_points_validate_their_arguments_on_the_host():
+    """The argument checks of the back-propagation entry points run before anything touches a GPU: unsupported shapes and null
+    pointers are refused with a message, the workspace sizes are positive for the default layer sizes."""
+    lib = _lib.load()
+    a = _lib.gvx_bptt_decoder_args()
+    a.B, a.L, a.T, a.A, a.D, a.E, a.P, a.a, a.F, a.kl = 32, 128, 200, 1024, 1024, 512, 256, 128, 32, 31
+    a.att_scale = a.dec_scale = 1.0
+    assert lib.gvx_train_decoder_bptt_workspace_bytes(C.byref(a)) == 0 and b"null pointer" in lib.gvx_last_error()
+    for n, _t in _lib.gvx_bptt_decoder_args._fields_:
+        if _t is C.c_void_p:
+            setattr(a, n, 256)   # any non-null value: the size query never dereferences
+    ws = lib.gvx_train_decoder_bptt_workspace_bytes(C.byref(a))
+    assert 70e6 < ws < 100e6, ws   # transposed matrices in fragment order (67 MB) + cumulative weights + accumulators
+    a.B = 33
+    assert lib.gvx_train_decoder_bptt_workspace_bytes(C.byref(a)) == 0 and b"B <= 32" in lib.gvx_last_error()
+    a.B, a.a = 32, 300
+    assert lib.gvx_train_decoder_bptt_workspace_bytes(C.byref(a)) == 0 and b"unsupported layer sizes" in lib.gvx_last_error()
+    a.a, a.L = 128, 4000
+    assert lib.gvx_train_decoder_bptt_workspace_bytes(C.byref(a)) == 0 and b"LDS" in lib.gvx_last_error()
+    assert lib.gvx_train_encoder_lstm_bptt_workspace_bytes(32, 256) > 0
+    assert lib.gvx_train_encoder_lstm_bptt(None, None, None, None, None, None, 32, 128, 256, None, None, None, 0, None) == -1
+    assert lib.gvx_train_sqnorm_scratch_bytes(48) == 48 * 64 * 8
+    assert lib.gvx_train_gemm_tn(None, 0, None, 0, None, 0, 4, 4, 8, None, 0, None) == -1
+
+
 # ---- rows a16 / f1 / f2 pinned by files the reference itself produced (tests/golden/make_fixtures.py host) -----------
 GOLDEN = os.path.join(REPO, "tests", "golden")
 

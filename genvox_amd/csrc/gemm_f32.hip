@@ -288,7 +288,8 @@ static bool bx3_enabled() {   // GVX_GEMM_BX3=1: dense products on the bf16 matr
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
-    if (bx3_enabled() && gemm_bx3_serves(p)) return launch_gemm_bx3(p, s);
+    static const int bx3_min_rows = [] { const char* e = std::getenv("GVX_GEMM_BX3_MINROWS"); return e ? std::atoi(e) : 0; }();   // (diagnostics)
+    if (bx3_enabled() && p.M >= bx3_min_rows && gemm_bx3_serves(p)) return launch_gemm_bx3(p, s);
     if (p.kmajor) {   // K-major operands (weight gradients): the two square-ish tile shapes only, any K; 16-byte pieces along m / n
         if ((p.M & 3) || (p.N & 3) || p.M < 4 || p.N < 4 || ((p.amap.s0 | p.amap.s1 | p.wmap.s0 | p.wmap.s1) & 3)) return hipErrorInvalidValue;
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);

@@ -14,11 +14,14 @@
 // MFMA operands: lane (row = lane & 31, half = lane >> 5) holds the 8 consecutive k = 8 half ... 8 half + 7 of its row.
 //
 // OPT-IN (GVX_GEMM_BX3=1), not the default.  Measured (round 3): Postnet on 256 x 800 frames 16.0 -> 13.0 ms, the 32 x 800
-// forward 19.4 -> 18.7 ms, whole parity suite green - but with these kernels in flight on one lane of a 64-row autoregressive
-// decode, the OTHER lane's step kernels, when replayed from hipGraphs, give run-to-run different results (a few rows, 1e-6 ..
-// 4e-5 on the alignments; tools/ar_determinism.py).  Eager launches are bit-reproducible, so are the fp32 GEMMs, and so are
-// these kernels alone from one or two streams (tools/bx3_determinism.py, tools/bx3_two_streams.py).  Same signature as round 1's
-// observation with the bf16 split in the LSTM step; cause not found, so the default stays on the fp32 matrix instruction.
+// forward 19.4 -> 18.7 ms, whole parity suite green - but while waves of this kernel are on the chip, OTHER kernels of other
+// streams (the autoregressive step kernels of a second lane, of another model) stop being bit-reproducible.  Traced to the
+// instruction, not to this code: a self-contained probe (tools/micro/mfma_bf16_neighbour.hip, results in
+// profiles/r03_mfma_bf16_neighbour_probe.txt) shows a race-free fp32 VALU + LDS kernel returning different numbers whenever a
+// kernel full of v_mfma_f32_32x32x16_bf16 (or v_mfma_f32_16x16x32_bf16 - the double-rate bf16 forms new in gfx950) runs
+// beside it, and never beside v_mfma_f32_32x32x8_bf16_1k, v_mfma_f32_32x32x2_f32 or plain VALU / LDS work with the same
+// launch shape (DESIGN.md section 4, round-3 experiments: "bf16 matrix instructions and their neighbours").  The split only pays at the double
+// rate (at the 32x32x8 rate six piece products cost more than the fp32 instruction), so the default stays on fp32 MFMA.
 #include "gvx_kernels.h"
 
 namespace gvx {

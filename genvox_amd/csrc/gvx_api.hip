@@ -1658,6 +1658,17 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     const int E = d.embed_dim, M = d.n_mels, P = d.prenet_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim, T = max_steps;
     const WsPlan wp = make_ws_plan(m, B, L, T, WS_AUTOREGRESSIVE);
     const DecoderBuffers db = decoder_buffers(ws, wp);
+    if (std::getenv("GVX_DEBUG_PLAN")) {   // (diagnostics, tools/ar_ws_diff.py: byte offsets of the workspace buffers)
+        static bool printed = false;
+        if (!printed) {
+            printed = true;
+#define GVX_PL(f) std::fprintf(stderr, "wsplan %s %zu\n", #f, wp.f);
+            GVX_PL(xa) GVX_PL(xb) GVX_PL(xg) GVX_PL(enc_h) GVX_PL(enc_c) GVX_PL(flags) GVX_PL(sync) GVX_PL(memory) GVX_PL(pm) GVX_PL(frames) GVX_PL(pre1) GVX_PL(prenet) GVX_PL(h_a) GVX_PL(c_a) GVX_PL(c_d)
+            GVX_PL(hc) GVX_PL(w_cum) GVX_PL(q_slab) GVX_PL(proj) GVX_PL(energies) GVX_PL(align_tm) GVX_PL(len_copy) GVX_PL(loc) GVX_PL(ar_masks)
+            GVX_PL(p_slab) GVX_PL(p_ctx) GVX_PL(att_part) GVX_PL(dec_part) GVX_PL(pre_gate) GVX_PL(xchg) GVX_PL(ya) GVX_PL(yb) GVX_PL(total)
+#undef GVX_PL
+        }
+    }
     HIP_TRY(zero_async(ws_ptr<unsigned>(ws, wp.sync), HANDOFF_WORDS * sizeof(unsigned), s));   // hand-off status of THIS call
     const int PSB = m->PSB();
     int32_t* flags = ws_ptr<int32_t>(ws, wp.flags);

@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
     sfx = ".stamps.o" if stamps else ".o"
     if os.environ.get("GVX_LIB_NAME"):
         sfx = "." + os.environ["GVX_LIB_NAME"] + ".o"
-    headers = [os.path.join(CSRC, "gvx_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "genvox_amd.h")]
+    headers = [os.path.join(CSRC, "gvx_kernels.h"), os.path.join(CSRC, "attn_step_body.h"), os.path.join(os.path.dirname(HERE), "include", "genvox_amd.h")]
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", sfx))

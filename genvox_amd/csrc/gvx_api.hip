@@ -136,6 +136,8 @@ struct gvx_model {
     // (round 3, 200-step decodes) 49 vs 47 us per step at batch 1 and no gain at 2 x 32 rows - launch C then has 256 equal
     // tiles for 256 - B free CUs, so one CU streams two of them
     bool ar_resident = false;
+    bool ar_split_h = true;       // autoregressive step: the h_a(t) columns of both cells as partial sums beside the attention step
+                                  // (GVX_AR_SPLIT_H=0: the round-2 schedule, attention as a launch of its own)
     // GVX_TF_ROWS64=1: batches of 33 .. 64 rows run as ONE call beside a 64-CU resident kernel (layout 3).  Off by default:
     // with two batch tiles per workgroup the fp32 matrix pipe sets the launch length (37 us per 64-row step, MFMA pipe 54 %
     // busy on the 192 CUs, round 3) and two 32-row lanes on two streams are faster (40.1 vs 44.4 us per 64-row step)
@@ -263,7 +265,7 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T, int mode = WS_TEACH
     w.loc = take((size_t)B * L * d.att_dim);  // location features of the current step
     w.p_slab = take((size_t)(D / 8) * B * m->PSB());   // autoregressive mode: projection partials of the decoder-LSTM tiles
     w.p_ctx = take((size_t)B * m->PSB());            //   and of the context columns (blocked vector)
-    w.att_part = take((size_t)B * 4 * A);            // autoregressive mode: partial gate pre-activations [B][4A] / [B][4D] of the
+    w.att_part = take((size_t)2 * B * 4 * A);        // autoregressive mode: partial gate pre-activations [B][4A] / [B][4D] of the
     w.dec_part = take((size_t)2 * B * 4 * D);        //   column slices that are known one launch early (two buffers: the 64-row
                                                      //   teacher-forced loop finishes a decoder cell one launch after its partial)
     // teacher-forced loop beside the persistent attention kernel: Prenet contribution to the attention LSTM's gates, all steps
@@ -440,6 +442,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
         if (const char* e = std::getenv(name))
             if (e[0] != '\0' && e[0] != '0') m->attn_persistent = false;
     if (const char* e = std::getenv("GVX_AR_RESIDENT")) m->ar_resident = e[0] == '1';
+    if (const char* e = std::getenv("GVX_AR_SPLIT_H")) m->ar_split_h = e[0] != '0';
     if (const char* e = std::getenv("GVX_TF_ROWS64")) m->tf_rows64 = e[0] == '1';
     if (const char* e = std::getenv("GVX_PA_DEPTH")) m->pa_depth = std::atoi(e) == 6 ? 6 : 4;
     if (const char* e = std::getenv("GVX_HANDOFF_SPIN_LIMIT")) m->spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
@@ -1696,6 +1699,14 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     const bool pa = m->ar_resident && m->attn_one_launch && attention_persistent_layout(B, L) == 1 &&
                     attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
     const bool fold = B <= 32 && E / 4 == D / 8;
+    // h_a(t) exists when launch A ends, the context only after the attention step: the h_a columns of both cells (two thirds of
+    // what launch C used to stream) are summed by tiles that share the attention step's launch - the step's latency chain
+    // hides under 33 MB of weight stream - and launch C is left with the context columns
+    // (not on handles that share the chip with other calls - gvx_model_set_persistent_attention(model, 0), the lanes of a
+    // batch above 32 rows: two such launches of 512 workgroups each queue behind one another, measured 66 vs 61 us per step)
+    const bool split_h = !pa && m->ar_split_h && m->attn_persistent && m->attn_one_launch && B <= 32 && d.att_dim > 32 && d.att_dim <= 128;
+    float* att_part2 = db.att_part + (size_t)B * 4 * A;
+    float* dec_part2 = db.dec_part + (size_t)B * 4 * D;
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
     if (pa) {
         rc = ensure_side_stream(m);
@@ -1756,7 +1767,27 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
                 HIP_TRY(launch_skinny(ja, 2, SK_AR, st, &lq));
                 AttnParams ap;
                 fill_attn(m, ap, memory_ws, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
-                HIP_TRY(launch_attn(m, ap, st));
+                if (split_h) {
+                    SkinnyJob jb[2];
+                    std::memset(jb, 0, sizeof jb);
+                    {   // decoder LSTM of step t: partial sums over the h_a(t) columns
+                        SkinnyJob& J = jb[0];
+                        J.Wp = m->dev_blob + m->blob.dec_frag;
+                        J.x[0] = XSeg{ha_new, A};
+                        J.N = 4 * D; J.nkg = kgA; J.kg0 = 0; J.nkg_w = kgA + kgE + kgD; J.mode = 2; J.B = B;
+                        J.y = dec_part2;
+                    }
+                    {   // attention LSTM of step t+1: partial sums over the h_a(t) columns
+                        SkinnyJob& J = jb[1];
+                        J.Wp = m->dev_blob + m->blob.att_frag;
+                        J.x[0] = XSeg{ha_new, A};
+                        J.N = 4 * A; J.nkg = kgA; J.kg0 = kgP + kgE; J.nkg_w = kgP + kgE + kgA; J.mode = 2; J.B = B;
+                        J.y = att_part2;
+                    }
+                    HIP_TRY(launch_skinny_attn(jb, 2, ap, st));
+                } else {
+                    HIP_TRY(launch_attn(m, ap, st));
+                }
             }
             SkinnyJob jc[3];
             std::memset(jc, 0, sizeof jc);
@@ -1781,6 +1812,16 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
                 J.x[2] = XSeg{ha_new, A};
                 J.N = 4 * A; J.nkg = kgE + kgA; J.kg0 = kgP; J.nkg_w = kgP + kgE + kgA; J.mode = 2; J.B = B;
                 J.y = db.att_part;
+            }
+            if (split_h) {   // launch C streams the context columns only; the h_a columns arrive as sums
+                SkinnyJob& Jd = jc[0];
+                Jd.x[0] = XSeg{hc_n + (size_t)D * B, E}; Jd.x[1] = XSeg{nullptr, 0};
+                Jd.nkg = kgE; Jd.kg0 = kgA;
+                Jd.addend2 = dec_part2;
+                SkinnyJob& Ja = jc[1];
+                Ja.x[0] = XSeg{hc_n + (size_t)D * B, E}; Ja.x[1] = XSeg{nullptr, 0}; Ja.x[2] = XSeg{nullptr, 0};
+                Ja.nkg = kgE; Ja.kg0 = kgP;
+                Ja.addend = att_part2; Ja.add_bs = 4 * A;
             }
             if (pa)
                 for (int i = 0; i < 2; ++i) {   // the context of step t is published by the resident kernel while this launch streams
@@ -1836,7 +1877,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     if (m->use_graph) {
         gvx_model::LoopKey key{ws, memory_ws, m->dev_blob, B, L, T, lengths != nullptr};
         key.threshold = gate_threshold;
-        key.variant = pa ? 1 : 0;
+        key.variant = pa ? 1 : (split_h ? 2 : 0);
         gset = touch_graph_set(m, m->ar_graphs, key);
     }
     // One chunk of look-ahead: chunk k + 1 is enqueued BEFORE the host reads chunk k's all-rows-finished counter (pinned slot,

@@ -89,6 +89,9 @@ struct SkinnyJob {
     // encoder extras (all nullptr/0 for the decoder)
     const float* addend; long add_bs, add_ts;  // pre-activation addend[b][t_b][n] (encoder: x-projection incl. bias;
                                                // autoregressive decoder: partial sums of the other column slice)
+    const float* addend2;                      // decoder cells / partial-sum jobs: a second addend [b][n] with the stride add_bs
+                                               // (autoregressive loop: the h_a columns, summed beside the attention step); a mode-2
+                                               // job adds `addend` and `addend2` to the sums it stores
     const int32_t* lengths; int step; int reverse; int seq_len;  // packed-sequence semantics
     float* seq_out; long seq_bs, seq_ts;       // seq_out[b][t_b][j] (row-major encoder output)
     const float* h_prev;                       // blocked; carried over for inactive rows
@@ -135,6 +138,10 @@ struct LocJob {
 };
 enum SkinnyKind : int { SK_DECODER = 0, SK_ENCODER = 1, SK_AR = 2, SK_TRAIN = 3 };  // kernel name only; same code (up to 4 jobs)
 hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t s, const LocJob* loc = nullptr);
+struct AttnParams;
+// autoregressive loop: the one-launch attention step (attention.hip) and partial-sum tiles that only need h_a(t) in ONE launch -
+// the attention workgroups first, then the tiles of `jobs` (B <= 32, attention dim <= 128)
+hipError_t launch_skinny_attn(const SkinnyJob* jobs, int njobs, const AttnParams& ap, hipStream_t s);
 // teacher-forced step beside the persistent attention kernel: attention-LSTM (+ decoder-LSTM of the previous step) dealt to
 // 96 (224) workgroups of equal weight (skinny.hip); default layer sizes, B <= 32
 // layout 1: 224 (96) workgroups beside a 32-CU resident kernel; layout 2: 192 (64) workgroups beside a 64-CU one (skinny.hip)

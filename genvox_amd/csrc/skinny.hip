@@ -23,6 +23,7 @@
 //     hidden units (slab[tile][b][:]), so the attention kernel never has to re-read the 512 KiB query matrix
 //     per batch row.
 #include "gvx_kernels.h"
+#include "attn_step_body.h"
 
 #include <cstdlib>
 
@@ -54,6 +55,7 @@ struct SkinnyJobs {
     int tiles;    // tiles of all jobs; blocks >= tiles are location-feature workgroups
     LocJob loc;
     int pa_layout;   // teacher-forced step beside the persistent attention kernel: 224 (96) workgroups, see skinny_body
+    int block0 = 0;  // first block of the tiles (launch shared with attention workgroups: ar_attn_tiles_kernel); 0 otherwise
     int rot;         // > 0: every workgroup walks its waves' k-group slices from a start rotated by (tile * rot) - thousands of
                      // waves otherwise read the same 1-KiB x fragments (L2 lines) at the same time
 };
@@ -188,7 +190,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     float* hs = smem + SK_WAVES * NT * 16 * 64;          // [MT*32][RT*8] h' of this workgroup's hidden units (LSTM + q slabs)
     float* red2 = hs + NT * 32 * 8;                      // XH: [SK_WAVES][8][64] of the extra half tile, then its h' [32][4]
 
-    int jsel = 0, tile = (int)blockIdx.x;
+    int jsel = 0, tile = (int)blockIdx.x - jobs.block0;
     int xt = -1, xhalf = 0;    // extra half tile: packed rows 16 xhalf .. 16 xhalf + 15 of tile xt
     if (jobs.pa_layout == 2) {
         const int bid = (int)blockIdx.x;
@@ -234,6 +236,23 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         if (J.addend && !J.seq_out && b_ < B) {
             const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b_ * J.add_bs + tile_ * 32 + 8 * g_ + 4 * h);
             bias_pref.x += ad.x; bias_pref.y += ad.y; bias_pref.z += ad.z; bias_pref.w += ad.w;
+            if (J.addend2) {
+                const float4 a2 = *reinterpret_cast<const float4*>(J.addend2 + (long)b_ * J.add_bs + tile_ * 32 + 8 * g_ + 4 * h);
+                bias_pref.x += a2.x; bias_pref.y += a2.y; bias_pref.z += a2.z; bias_pref.w += a2.w;
+            }
+        }
+    }
+    // partial-sum jobs that continue somebody else's sums: the addends of the lane's four rows, fetched now as well
+    if (J.mode == 2 && J.addend && wave < 4 * NT) {
+        const int t_ = wave >> 2, g_ = wave & 3;
+        const int mt_ = RT > 1 ? 0 : t_, tile_ = tile + (RT > 1 ? t_ : 0);
+        const int b_ = mt_ * 32 + bl;
+        if (b_ < B) {
+            bias_pref = *reinterpret_cast<const float4*>(J.addend + (long)b_ * J.add_bs + tile_ * 32 + 8 * g_ + 4 * h);
+            if (J.addend2) {
+                const float4 a2 = *reinterpret_cast<const float4*>(J.addend2 + (long)b_ * J.add_bs + tile_ * 32 + 8 * g_ + 4 * h);
+                bias_pref.x += a2.x; bias_pref.y += a2.y; bias_pref.z += a2.z; bias_pref.w += a2.w;
+            }
         }
     }
 
@@ -561,7 +580,8 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
             if (J.q_slab) hs[(b * RT + rt) * 8 + jloc] = hval;
         } else if (J.mode == 2) {
             // partial pre-activations of a column slice: raw sums, batch-major [B][N] (the layout `addend` is read in)
-            if (b < B) *reinterpret_cast<float4*>(J.y + (long)b * J.N + n) = make_float4(s[0], s[1], s[2], s[3]);
+            if (b < B) *reinterpret_cast<float4*>(J.y + (long)b * J.N + n) =
+                make_float4(s[0] + bias_pref.x, s[1] + bias_pref.y, s[2] + bias_pref.z, s[3] + bias_pref.w);   // (zeros without addends)
         } else {
             if (b < B) {
 #pragma unroll
@@ -725,6 +745,12 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_ker
     if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }
     skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
 }
+// autoregressive launch B: the attention step of the row slices (attn_step_body.h) in the first `n_attn` workgroups, behind them
+// the partial sums that only need h_a(t) - they stream while the attention's latency chain runs
+__global__ __launch_bounds__(SK_THREADS, 4) void ar_attn_tiles_kernel(SkinnyJobs jobs, AttnParams ap) {   // 4 waves per SIMD: two workgroups per CU
+    if ((int)blockIdx.x < jobs.block0) { attn_step_body<4, 4>(ap, (int)blockIdx.x); return; }   // uniform per workgroup
+    skinny_body<1, SK_DEPTH1>(jobs);
+}
 // autoregressive launch C beside the resident attention kernel: the context of the step arrives inside the launch (deferred segment)
 __global__ __launch_bounds__(SK_THREADS) void ar_lstm_defer_kernel(SkinnyJobs jobs) { skinny_body<1, SK_DEPTH1, false, true>(jobs); }
 // training step, back-propagation through the decoder loop: dgates x transposed recurrent matrices as partial sums (mode 2 jobs, train.hip)
@@ -756,6 +782,7 @@ hipError_t skinny_init() {
     if ((e = set_lds(decoder_lstm_step_pa192_kernel, 2)) != hipSuccess) return e;
     if ((e = set_lds(decoder_lstm_step_pa64_kernel, 2)) != hipSuccess) return e;
     if ((e = set_lds(ar_lstm_defer_kernel, 1)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_attn_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = set_lds(train_bptt_products_kernel, 1)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
     return set_lds(encoder_lstm_step_kernel<2>, 2);
@@ -854,6 +881,32 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
             ar_lstm_defer_kernel<<<grid, block, lds, s>>>(js);
         } else ar_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_skinny_attn(const SkinnyJob* jobs, int njobs, const AttnParams& ap, hipStream_t s) {
+    static_assert(MA_THREADS == SK_THREADS, "the attention step and the tiles share a launch: same workgroup size");
+    if (njobs < 1 || njobs > 4 || ap.a > 128 || ap.a <= 32 || ap.G < 1) return hipErrorInvalidValue;
+    if (!attention_supported(ap.L, ap.a, ap.F, ap.kl, ap.E)) return hipErrorInvalidValue;
+    SkinnyJobs js;
+    js.njobs = njobs;
+    js.pa_layout = 0; js.rot = sk_rot();
+    js.loc = LocJob{};
+    for (int i = 0; i < 4; ++i) js.job[i] = jobs[i < njobs ? i : njobs - 1];
+    js.tiles0 = (jobs[0].N + 31) / 32;
+    js.tiles1 = njobs > 1 ? (jobs[1].N + 31) / 32 : 0;
+    js.tiles2 = njobs > 2 ? (jobs[2].N + 31) / 32 : 0;
+    js.tiles = js.tiles0 + js.tiles1 + js.tiles2 + (njobs > 3 ? (jobs[3].N + 31) / 32 : 0);
+    const int B = jobs[0].B;
+    if (B < 1 || B > 32 || B != ap.B) return hipErrorInvalidValue;   // one batch tile
+    for (int i = 0; i < njobs; ++i)
+        if (jobs[i].B != B || jobs[i].mode != 2 || (jobs[i].N & 31) || jobs[i].defer_seg || jobs[i].q_slab) return hipErrorInvalidValue;
+    js.block0 = 8 * ((ap.B + 7) / 8) * ap.G;   // the attention step's own grid (attention.hip, launch_attention_step)
+    size_t lds = skinny_lds(1);
+    const size_t lds_a = (size_t)step_lds_layout(ap.a, ap.L).total * sizeof(float);
+    if (lds_a > lds) lds = lds_a;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    ar_attn_tiles_kernel<<<dim3(js.block0 + js.tiles), dim3(SK_THREADS), lds, s>>>(js, ap);
     return hipGetLastError();
 }
 

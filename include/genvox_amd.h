@@ -117,7 +117,10 @@ int gvx_workspace_status(const gvx_model* model, void* workspace, size_t workspa
 /* Teacher-forced decoder loop: run the attention as ONE kernel that lives beside the step launches (default, used when the
  * shape allows it: B <= 32, L <= 128, default layer sizes) or as a launch per step (enable = 0).  Callers that drive one
  * handle from two streams at once (the host mirror does that for batches above 32 rows) must switch it off: the
- * resident kernel owns the handle's side stream for the whole loop.  Results are identical either way. */
+ * resident kernel owns the handle's side stream for the whole loop.  Results are identical either way.
+ * enable = 0 also marks the handle as one that shares the GPU with concurrent calls: the autoregressive loop then keeps its
+ * attention step a launch of its own instead of running it beside 256 partial-sum tiles (two such launches at once queue
+ * behind one another); results equal to fp32 rounding (the h_a columns are added in a different order). */
 int gvx_model_set_persistent_attention(gvx_model* model, int enable);
 
 /* Batch rows gvx_tacotron2_forward / gvx_decoder_teacher_forced serve best per call for rows of L tokens: 64 where the 64-row

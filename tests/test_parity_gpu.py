@@ -457,6 +457,57 @@ def test_autoregressive_resident_attention_equals_per_step(monkeypatch):
         assert max_abs_diff(got, want[k]) <= TOL, k
 
 
+def test_autoregressive_h_columns_beside_attention_equals_launch_per_step(monkeypatch):
+    """Default autoregressive step (one handle, <= 32 rows): the h_a(t) columns of both LSTM cells are summed by 256 tiles that
+    share the attention step's launch (ar_attn_tiles_kernel), launch C streams the context columns and adds those sums
+    (addend2 / mode-2 addends).  Against the round-2 schedule (GVX_AR_SPLIT_H=0: attention a launch of its own, launch C over
+    [h_a ; ctx]): ragged token lengths, rows that stop at different steps, 32 rows and 5 rows (padding blocks of the attention
+    grid), same frame counts, numbers equal to fp32 rounding, repeatable bit for bit; row 0 against a batch-1 oracle run."""
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
+    steps = 40
+    mc.max_decoder_steps = steps
+    sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+    for lens in ([50, 41, 33, 20, 9], [64 - b for b in range(32)]):
+        B, L = len(lens), max(lens)
+        tok = (gw.hashed_uniform(37, "arsplit", B * L) * tc.n_tokens).astype(np.int64).reshape(B, L)
+        for b, n in enumerate(lens):
+            tok[b, n:] = 0
+        masks = torch.from_numpy(gw.prenet_keep_masks(steps * B, mc.prenet_dim, seed=9)).reshape(2, steps, B, mc.prenet_dim)
+        inputs = {"tokens": torch.from_numpy(tok), "token_lengths": torch.tensor(lens), "prenet_keep_masks": masks}
+
+        def run(threshold):
+            mc.gate_threshold = threshold
+            m = Tacotron2(mc, ac, tc)
+            m.load_state_dict(sd)
+            m = m.to("cuda:0")
+            a = m.inference(inputs)
+            b = m.inference(inputs)
+            for k in KEYS:
+                assert torch.equal(a[k], b[k]), k
+            m.check_status()
+            return a
+
+        monkeypatch.setenv("GVX_AR_SPLIT_H", "1")
+        probe = run(1.0)
+        g = torch.sigmoid(probe["gate_outputs"][:, :8]).cpu()
+        thr = float(g.flatten().sort().values[g.numel() // 2])
+        new = run(thr)
+        monkeypatch.setenv("GVX_AR_SPLIT_H", "0")
+        old = run(thr)
+        assert new["mel_lengths"].cpu().tolist() == old["mel_lengths"].cpu().tolist()
+        assert int(new["mel_lengths"].min()) < steps   # at least one row stopped on its gate
+        for k in KEYS:
+            assert torch.isfinite(new[k]).all(), k
+            assert max_abs_diff(new[k], old[k]) <= 2e-5, k
+        if B == 5:
+            want = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(tok[:1]), masks[:, :, 0], thr, steps, token_length=lens[0])
+            nf = want["mel_outputs"].shape[2]
+            assert int(new["mel_lengths"][0]) == nf
+            for k in ("mel_outputs", "gate_outputs", "alignments"):
+                got = new[k][:1, ..., :nf] if k != "alignments" else new[k][:1, :nf]
+                assert max_abs_diff(got, want[k]) <= TOL, k
+
+
 def test_persistent_attention_long_rows_match_oracle():
     """LJSpeech transcripts reach ~190 characters: rows of 128 < L <= 256 positions run beside the SPLIT resident kernel (two
     workgroups per row that exchange softmax partials every step, attn_persist.hip) and the 192-workgroup launch layout

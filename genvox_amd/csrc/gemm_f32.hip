@@ -301,6 +301,9 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     // fewer than ~1.5 workgroups per CU with 128 x 128 tiles (encoder convolutions: 4096 x 512): halve the tile height so
     // that all 256 CUs get work
     const long n_tiles = (p.N + 127) / 128, tiles128 = (long)((p.M + 127) / 128) * n_tiles;
+    // and below ~0.75 per CU (the encoder convolutions themselves: 128 tiles) 64 x 64 tiles, two workgroups per CU: one
+    // 64 x 128 workgroup of four waves per CU left the matrix pipe waiting on its own loads (155 -> 115 us per convolution)
+    if (tiles128 < 192) return launch_cfg<2, 2, 1, 1>(p, s);
     if (tiles128 < 384) return launch_cfg<2, 2, 1, 2>(p, s);
     // Wave quantisation: 128 x 128 tiles run in rounds of 256 (one per CU); a last round with few tiles leaves most of the
     // chip idle for a whole tile time (the Postnet at 32 x 800 frames: 800 tiles = 3 rounds + 32 tiles, 78 % of 4 rounds).

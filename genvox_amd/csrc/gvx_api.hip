@@ -136,6 +136,7 @@ struct gvx_model {
     // (round 3, 200-step decodes) 49 vs 47 us per step at batch 1 and no gain at 2 x 32 rows - launch C then has 256 equal
     // tiles for 256 - B free CUs, so one CU streams two of them
     bool ar_resident = false;
+    bool enc_persistent = true;   // encoder BiLSTM recurrence as one resident launch (B <= 32, H = 256); GVX_ENC_PERSISTENT=0: launch per position
     bool ar_split_h = true;       // autoregressive step: the h_a(t) columns of both cells as partial sums beside the attention step
                                   // (GVX_AR_SPLIT_H=0: the round-2 schedule, attention as a launch of its own)
     // GVX_TF_ROWS64=1: batches of 33 .. 64 rows run as ONE call beside a 64-CU resident kernel (layout 3).  Off by default:
@@ -147,7 +148,7 @@ struct gvx_model {
     bool debug_skip_resident = false;  // GVX_DEBUG_SKIP_RESIDENT=1: never launch the resident attention kernel, so that every
                                        // wait of the loop runs into its limit (test of the time-out reporting only)
     hipStream_t pa_stream = nullptr;
-    hipEvent_t pa_fork = nullptr, pa_join = nullptr;
+    hipEvent_t pa_fork = nullptr, pa_join = nullptr, enc_mid = nullptr;
     // autoregressive loop: the all-rows-finished counter of chunk k is read (pinned slot k & 1, event k & 1) while chunk k + 1 runs
     int32_t* ar_done_host = nullptr;
     hipEvent_t ar_ev[2] = {nullptr, nullptr};
@@ -443,6 +444,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
             if (e[0] != '\0' && e[0] != '0') m->attn_persistent = false;
     if (const char* e = std::getenv("GVX_AR_RESIDENT")) m->ar_resident = e[0] == '1';
     if (const char* e = std::getenv("GVX_AR_SPLIT_H")) m->ar_split_h = e[0] != '0';
+    if (const char* e = std::getenv("GVX_ENC_PERSISTENT")) m->enc_persistent = e[0] != '0';
     if (const char* e = std::getenv("GVX_TF_ROWS64")) m->tf_rows64 = e[0] == '1';
     if (const char* e = std::getenv("GVX_PA_DEPTH")) m->pa_depth = std::atoi(e) == 6 ? 6 : 4;
     if (const char* e = std::getenv("GVX_HANDOFF_SPIN_LIMIT")) m->spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
@@ -465,6 +467,7 @@ void gvx_model_destroy(gvx_model* m) {
     // (pa_stream belongs to the process-wide side-stream pool)
     if (m->pa_fork) (void)hipEventDestroy(m->pa_fork);
     if (m->pa_join) (void)hipEventDestroy(m->pa_join);
+    if (m->enc_mid) (void)hipEventDestroy(m->enc_mid);
     if (m->ar_done_host) (void)hipHostFree(m->ar_done_host);
     for (hipEvent_t e : m->ar_ev)
         if (e) (void)hipEventDestroy(e);
@@ -804,7 +807,8 @@ int conv_layer(const gvx_model* m, const float* in, float* out, int B, int T, in
 // caller with batch statistics and dropout (gvx_conv_bn_act_train_forward); the embedding and the folded-BatchNorm
 // convolutions are then skipped and only the BiLSTM part runs
 int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, int B, int L, float* memory_out, void* ws,
-                 const WsPlan& wp, hipStream_t s, const float* conv_out = nullptr, float* c_seq_out = nullptr, float* xg_out = nullptr) {
+                 const WsPlan& wp, hipStream_t s, const float* conv_out = nullptr, float* c_seq_out = nullptr, float* xg_out = nullptr,
+                 hipEvent_t dense_done = nullptr) {   // dense_done: recorded on s behind the convolutions (see below)
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, H = E / 2, pe = (d.enc_kernel - 1) / 2;
     float* xa = ws_ptr<float>(ws, wp.xa);
@@ -830,6 +834,9 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
             float* t = cur; cur = nxt; nxt = t;
         }
     }
+    // (behind the convolutions, in front of the input projection: the caller's other dense products then end together with the
+    // recurrence - measured: encoder stage 1.37 ms with the event behind the projection, 1.32 ms here)
+    if (dense_done) HIP_TRY(hipEventRecord(dense_done, s));
     {   // LSTM input projection for both directions: xg[b][l][dir*4H + 4j+gate]
         GemmParams g{};
         g.A = cur + (long)pe * E; g.amap = RowMap{L, (long)(L + 2 * pe) * E, (long)E};
@@ -875,9 +882,24 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
         }
         return GVX_OK;
     };
-    const gvx_model::LoopKey key{ws, mem_ws, m->dev_blob, B, L, 0, lengths != nullptr};
-    const int rc = run_chunk(m, m->use_graph && !c_seq_out ? touch_graph_set(m, m->enc_graphs, key) : nullptr, 0, s, enqueue);
-    if (rc != GVX_OK) return rc;
+    if (m->enc_persistent && encoder_persistent_supported(B, H)) {
+        // one resident launch for the whole recurrence (skinny.hip, encoder_lstm_persistent_kernel); a hand-off that times out
+        // leaves NaN in the encoder output and raises the sticky status word, like the resident decoder loops
+        unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
+        HIP_TRY(zero_async(sync, HANDOFF_WORDS * sizeof(unsigned), s));
+        EncPersistParams ep{};
+        ep.Wp[0] = m->dev_blob + m->blob.enc_whh_frag[0]; ep.Wp[1] = m->dev_blob + m->blob.enc_whh_frag[1];
+        ep.xg = xg; ep.lengths = len_ws; ep.hx = enc_h; ep.seq_out = mem_ws; ep.c_seq_out = c_seq_out;
+        ep.sync = sync; ep.spin_limit = m->spin_limit; ep.B = B; ep.L = L; ep.H = H;
+        HIP_TRY(launch_encoder_persistent(ep, s));
+        float* outs[2] = {mem_ws, c_seq_out};
+        const size_t counts[2] = {(size_t)B * L * E, (size_t)B * L * E};
+        HIP_TRY(launch_poison_on_timeout(sync + HANDOFF_TIMEOUT, flags + FLAG_TIMEOUT, outs, counts, c_seq_out ? 2 : 1, s));
+    } else {
+        const gvx_model::LoopKey key{ws, mem_ws, m->dev_blob, B, L, 0, lengths != nullptr};
+        const int rc = run_chunk(m, m->use_graph && !c_seq_out ? touch_graph_set(m, m->enc_graphs, key) : nullptr, 0, s, enqueue);
+        if (rc != GVX_OK) return rc;
+    }
     if (xg_out) HIP_TRY(hipMemcpyAsync(xg_out, xg, (size_t)B * L * 8 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (memory_out != mem_ws)
         HIP_TRY(hipMemcpyAsync(memory_out, mem_ws, (size_t)B * L * E * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1011,6 +1033,7 @@ int ensure_side_stream(gvx_model* m) {
     if (!m->pa_fork) {
         HIP_TRY(hipEventCreateWithFlags(&m->pa_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m->pa_join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->enc_mid, hipEventDisableTiming));
     }
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -1565,9 +1588,13 @@ int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* to
         if (rc != GVX_OK) return rc;
         HIP_TRY(hipEventRecord(m->pa_fork, s));
         HIP_TRY(hipStreamWaitEvent(m->pa_stream, m->pa_fork, 0));
-        rc = encoder_impl(m, tokens, token_lengths, B, L, memory, ws, wp, m->pa_stream);
+        // The Prenet products start when the encoder's convolutions (~0.35 ms with the chip to themselves) are through: side by
+        // side from the start, the two sets of GEMMs only slowed each other 3x and left the second half of the recurrence - a
+        // quarter of the chip, latency bound - alone on an idle GPU (kernel timeline, tools/kernel_timeline.py, round 3)
+        rc = encoder_impl(m, tokens, token_lengths, B, L, memory, ws, wp, m->pa_stream, nullptr, nullptr, nullptr, m->enc_mid);
         if (rc != GVX_OK) return rc;
         HIP_TRY(hipEventRecord(m->pa_join, m->pa_stream));
+        HIP_TRY(hipStreamWaitEvent(s, m->enc_mid, 0));
         rc = decoder_prenet_part(m, B, L, mel_in, T, keep_masks, ws, wp, s);
         if (rc != GVX_OK) return rc;
         HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));

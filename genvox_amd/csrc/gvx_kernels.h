@@ -142,6 +142,23 @@ struct AttnParams;
 // autoregressive loop: the one-launch attention step (attention.hip) and partial-sum tiles that only need h_a(t) in ONE launch -
 // the attention workgroups first, then the tiles of `jobs` (B <= 32, attention dim <= 128)
 hipError_t launch_skinny_attn(const SkinnyJob* jobs, int njobs, const AttnParams& ap, hipStream_t s);
+// Encoder BiLSTM recurrence as ONE resident launch (skinny.hip, encoder_lstm_persistent_kernel): 2 directions x 32 tiles, every
+// workgroup keeps its 32 KB of W_hh in registers for the whole sequence and its cell states in registers; the hidden state goes
+// round through a double-buffered blocked vector (write-through stores, sc1 loads) with one counter per direction.  B <= 32,
+// H = 256 (the default layer size); packed-sequence semantics as the launch-per-step loop.
+struct EncPersistParams {
+    const float* Wp[2];        // packed fragments of W_hh per direction [H/8 tiles][H/8 k-groups][64][4]
+    const float* xg;           // input projections incl. biases [B][L][2 * 4H] (direction-major inside a position)
+    const int32_t* lengths;    // [B] or nullptr (all rows L)
+    float* hx;                 // exchange buffers [2 directions][2][H/8][B][8]
+    float* seq_out;            // [B][L][2H]: direction d writes columns d*H ..
+    float* c_seq_out;          // training tape: the cell state of every position, same layout, or nullptr
+    unsigned* sync;            // HANDOFF_WORDS words (zeroed by the caller): counters at HANDOFF_CNT_Q / HANDOFF_CNT_CTX, time-out word
+    unsigned spin_limit;
+    int B, L, H;
+};
+bool encoder_persistent_supported(int B, int H);
+hipError_t launch_encoder_persistent(const EncPersistParams& p, hipStream_t s);
 // teacher-forced step beside the persistent attention kernel: attention-LSTM (+ decoder-LSTM of the previous step) dealt to
 // 96 (224) workgroups of equal weight (skinny.hip); default layer sizes, B <= 32
 // layout 1: 224 (96) workgroups beside a 32-CU resident kernel; layout 2: 192 (64) workgroups beside a 64-CU one (skinny.hip)

@@ -745,6 +745,103 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_ker
     if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }
     skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
 }
+// ---- Encoder BiLSTM recurrence, resident for the whole sequence (EncPersistParams, gvx_kernels.h).
+// The launch-per-step loop pays a dispatch, a first-byte round trip for 32 KB of L2-resident weights and a kernel-end write-back
+// per position (7.3 us of kernel + 1.5 us of gap for ~1 us of work).  Here workgroup (direction, tile) holds its weight
+// fragments (4 k-groups per wave = 16 VGPRs), its cell states and its previous hidden values in registers; per position it
+// waits for the direction's counter (all 32 tiles have published h(t-1)), reads the 32 KB vector with sc1 loads, runs 16
+// MFMAs per wave, sums the K slices through LDS, finishes the cells of its 8 hidden units, stores h(t) write-through and adds
+// one to the counter.  Buffer parity: h(t) goes to buffer (t+1) & 1, which position t-1's readers have left - they all
+// published h(t-1) before anybody could pass the wait of position t.  Every wait is bounded (handoff_wait): after a time-out
+// all waits return at once, the grid drains, and the caller's poison launch overwrites the output with NaN.
+__global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(EncPersistParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;   // [SK_WAVES][16][64]
+    const int tiles = p.H >> 3;                       // 32-row tiles per direction (4H / 32)
+    // (one direction per XCD - blocks i % 8 == d of a grid of 8 x 32, the rest leaving at once - was tried: 1.97 instead of
+    // 1.78 ms for the encoder stage; the exchange goes through memory either way and 32 workgroups then share one XCD's L2)
+    const int dir = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - dir * tiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bl = lane & 31, h = lane >> 5;
+    const int B = p.B, L = p.L, H = p.H, nkg = H >> 3;
+    const unsigned blk = (unsigned)B * 8u;
+    constexpr int KPW = 4;                            // k-groups per wave (H = 256)
+    float4 wv[KPW];
+    {
+        const float4* wp = reinterpret_cast<const float4*>(p.Wp[dir]) + ((long)tile * nkg + wave * KPW) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) wv[i] = wp[i * 64];
+    }
+    const bool cell_wave = wave < 4;
+    const int g = wave & 3, jloc = 2 * g + h, j = tile * 8 + jloc;
+    const bool row = bl < B;
+    const int len = row ? (p.lengths ? p.lengths[bl] : L) : 0;
+    float c_state = 0.f, h_state = 0.f;
+    unsigned* cnt = p.sync + (dir ? HANDOFF_CNT_CTX : HANDOFF_CNT_Q);
+    unsigned* tmo = p.sync + HANDOFF_TIMEOUT;
+    const long E2 = 2L * H;
+    const float* xg_row = p.xg + (long)(row ? bl : 0) * L * 4 * E2 + (long)dir * 4 * H + tile * 32 + 8 * g + 4 * h;
+    float* out_row = p.seq_out + (long)(row ? bl : 0) * L * E2 + (long)dir * H + j;
+    float* cs_row = p.c_seq_out ? p.c_seq_out + (long)(row ? bl : 0) * L * E2 + (long)dir * H + j : nullptr;
+    const unsigned x_off = ((unsigned)(row ? bl : 0) * 8u + 4u * (unsigned)h) * 4u;
+    for (int step = 0; step < L; ++step) {
+        // the position's input projection (known since before the launch): fetched before the wait
+        const bool active = cell_wave && row && step < len;
+        const int tb = dir ? (len - 1 - step) : step;
+        float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) ad = *reinterpret_cast<const float4*>(xg_row + (long)tb * 4 * E2);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        if (step > 0) {   // h(-1) = 0: nothing to multiply at the first position
+            if (tid == 0) handoff_wait<true>(cnt, 4u * (unsigned)tiles * (unsigned)step, tmo, 0x400u + (unsigned)dir, p.spin_limit);
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.hx + ((long)dir * 2 + (step & 1)) * H * B);
+            float4 xv[KPW];
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) xv[i] = load_sc1(rx, x_off + (unsigned)(wave * KPW + i) * blk * 4u);
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i].x, xv[i].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i].y, xv[i].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i].z, xv[i].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i].w, xv[i].w, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + lane] = acc[q];
+        __syncthreads();
+        if (cell_wave) {
+            float s[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < SK_WAVES; ++w) t += red[(w * 16 + 4 * g + qq) * 64 + lane];
+                s[qq] = t;
+            }
+            if (active) {
+                const float p0 = s[0] + ad.x, p1 = s[1] + ad.y, p2 = s[2] + ad.z, p3 = s[3] + ad.w;
+                c_state = sigmoidf_(p1) * c_state + sigmoidf_(p0) * tanhf_(p2);
+                h_state = sigmoidf_(p3) * tanhf_(c_state);
+                out_row[(long)tb * E2] = h_state;
+                if (cs_row) cs_row[(long)tb * E2] = c_state;
+            }
+            if (row) {   // inactive rows carry their state (packed-sequence semantics); rows past B are never read
+                const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.hx + ((long)dir * 2 + ((step + 1) & 1)) * H * B);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h_state), rh, (int)(((unsigned)tile * blk + (unsigned)bl * 8u + (unsigned)jloc) * 4u), 0, 16);
+            }
+        }
+        // every cell wave publishes for itself (4 per tile and position): no second barrier - `red` is not written again
+        // before the next position's barrier, which these waves reach after their reads
+        if (cell_wave) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores of this wave have left
+            if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // autoregressive launch B: the attention step of the row slices (attn_step_body.h) in the first `n_attn` workgroups, behind them
 // the partial sums that only need h_a(t) - they stream while the attention's latency chain runs
 __global__ __launch_bounds__(SK_THREADS, 4) void ar_attn_tiles_kernel(SkinnyJobs jobs, AttnParams ap) {   // 4 waves per SIMD: two workgroups per CU
@@ -881,6 +978,15 @@ hipError_t launch_skinny(const SkinnyJob* jobs, int njobs, int kind, hipStream_t
             ar_lstm_defer_kernel<<<grid, block, lds, s>>>(js);
         } else ar_lstm_step_kernel<1><<<grid, block, lds, s>>>(js);
     }
+    return hipGetLastError();
+}
+
+bool encoder_persistent_supported(int B, int H) { return B >= 1 && B <= 32 && H == 256; }
+
+hipError_t launch_encoder_persistent(const EncPersistParams& p, hipStream_t s) {
+    if (!encoder_persistent_supported(p.B, p.H) || p.L < 1 || !p.Wp[0] || !p.Wp[1] || !p.xg || !p.hx || !p.seq_out || !p.sync) return hipErrorInvalidValue;
+    const int tiles = p.H / 8;   // per direction
+    encoder_lstm_persistent_kernel<<<dim3(2 * tiles), dim3(SK_THREADS), (size_t)SK_WAVES * 16 * 64 * sizeof(float), s>>>(p);
     return hipGetLastError();
 }
 

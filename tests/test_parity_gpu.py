@@ -508,6 +508,38 @@ def test_autoregressive_h_columns_beside_attention_equals_launch_per_step(monkey
                 assert max_abs_diff(got, want[k]) <= TOL, k
 
 
+def test_resident_encoder_recurrence_equals_launch_per_position(monkeypatch):
+    """The encoder's BiLSTM recurrence runs as ONE resident launch (encoder_lstm_persistent_kernel: weights and cell states in
+    registers, the hidden state handed round through a double-buffered vector and one counter per direction) when B <= 32 and
+    H = 256; GVX_ENC_PERSISTENT=0 keeps the launch per position.  Ragged lengths (packed-sequence semantics: the backward
+    direction starts at each row's own last token, padded positions stay zero), 1 / 5 / 32 rows, a one-token row: equal to
+    rounding (the K walk of a wave's slice differs), repeatable bit for bit, no time-out; against the oracle's encoder."""
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
+    sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+    for lens in ([17], [50, 41, 33, 20, 1], [96 - 3 * b for b in range(32)]):
+        B, L = len(lens), max(lens)
+        tok = (gw.hashed_uniform(41, "encres", B * L) * tc.n_tokens).astype(np.int64).reshape(B, L)
+        for b, n in enumerate(lens):
+            tok[b, n:] = 0
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("GVX_ENC_PERSISTENT", mode)
+            m = Tacotron2(mc, ac, tc)
+            m.load_state_dict(sd)
+            m = m.to("cuda:0").eval()
+            a = m.encode(torch.from_numpy(tok), torch.tensor(lens))
+            b2 = m.encode(torch.from_numpy(tok), torch.tensor(lens))
+            assert torch.equal(a, b2)
+            m.check_status()
+            outs[mode] = a
+        assert torch.isfinite(outs["1"]).all()
+        assert max_abs_diff(outs["1"], outs["0"]) <= 2e-6
+        for b, n in enumerate(lens):
+            assert torch.all(outs["1"][b, n:] == 0)
+        want = tacotron2_ref.encoder(sd, torch.from_numpy(tok), torch.tensor(lens))
+        assert max_abs_diff(outs["1"], want) <= TOL
+
+
 def test_persistent_attention_long_rows_match_oracle():
     """LJSpeech transcripts reach ~190 characters: rows of 128 < L <= 256 positions run beside the SPLIT resident kernel (two
     workgroups per row that exchange softmax partials every step, attn_persist.hip) and the 192-workgroup launch layout

@@ -132,7 +132,10 @@ int gvx_teacher_forced_rows_per_call(const gvx_model* model, int L);
 /* ---- Encoder: embedding + conv/BN/relu stack + BiLSTM with packed-sequence semantics.
  * Replaces nn.Embedding + Encoder.forward / Encoder.inference (models/tts/tacotron2.py:459,
  * :231-246, :248-256).  tokens: int64 [B, L]; lengths: int32 [B] or NULL (= all L);
- * memory_out: [B, L, embed_dim], zero past each row's length. */
+ * memory_out: [B, L, embed_dim], zero past each row's length.
+ * For B <= 32 and the default layer sizes the recurrence (:239-245) is ONE resident launch whose 64 workgroups hand the hidden
+ * state round through the workspace (bounded waits: a time-out leaves NaN in memory_out and raises status word [1] of
+ * gvx_workspace_status); other shapes run a launch per token position.  Same results to fp32 rounding. */
 int gvx_encoder_forward(gvx_model* model, const int64_t* tokens, const int32_t* lengths, int B, int L,
                         float* memory_out, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -181,7 +181,12 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 //   blocks [0, 64):   attention-LSTM tiles 2 m, 2 m + 1   (448 KB of weights + 224 KB of x)
 //   blocks [64, 192): decoder-LSTM tiles                   (320 KB of weights + 320 KB of x)
 // - about equal bytes through every CU's load path.  One batch tile only (MT = 1), no half tiles.
-template <int MT, int DEPTH, bool XH = false, bool DEFER = false, int RT = 1>
+// ARX: the autoregressive loop's extras - a second addend for the cells, addends on partial-sum jobs, tiles that start at
+// block `block0` of a launch shared with attention workgroups.  A template parameter so that the teacher-forced kernels keep
+// the instruction stream they were tuned with: as run-time branches these moved the dominant launch by +0.25 us (the kernel's
+// time follows the compiler's schedule, not its instruction count - compiling the training / encoder branches OUT of the
+// inference kernel made it 0.2-0.3 us slower, measured the same way; A/B of whole libraries on one box, GVX_LIB).
+template <int MT, int DEPTH, bool XH = false, bool DEFER = false, int RT = 1, bool ARX = false>
 __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     static_assert(RT == 1 || (RT == 2 && MT == 1 && !XH), "two row tiles: one batch tile, no half tile");
     constexpr int NT = MT * RT;   // accumulator tiles per wave; t = rt (RT = 2) or mt (MT = 2)
@@ -190,7 +195,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
     float* hs = smem + SK_WAVES * NT * 16 * 64;          // [MT*32][RT*8] h' of this workgroup's hidden units (LSTM + q slabs)
     float* red2 = hs + NT * 32 * 8;                      // XH: [SK_WAVES][8][64] of the extra half tile, then its h' [32][4]
 
-    int jsel = 0, tile = (int)blockIdx.x - jobs.block0;
+    int jsel = 0, tile = (int)blockIdx.x - (ARX ? jobs.block0 : 0);
     int xt = -1, xhalf = 0;    // extra half tile: packed rows 16 xhalf .. 16 xhalf + 15 of tile xt
     if (jobs.pa_layout == 2) {
         const int bid = (int)blockIdx.x;
@@ -236,14 +241,14 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         if (J.addend && !J.seq_out && b_ < B) {
             const float4 ad = *reinterpret_cast<const float4*>(J.addend + (long)b_ * J.add_bs + tile_ * 32 + 8 * g_ + 4 * h);
             bias_pref.x += ad.x; bias_pref.y += ad.y; bias_pref.z += ad.z; bias_pref.w += ad.w;
-            if (J.addend2) {
+            if (ARX && J.addend2) {
                 const float4 a2 = *reinterpret_cast<const float4*>(J.addend2 + (long)b_ * J.add_bs + tile_ * 32 + 8 * g_ + 4 * h);
                 bias_pref.x += a2.x; bias_pref.y += a2.y; bias_pref.z += a2.z; bias_pref.w += a2.w;
             }
         }
     }
     // partial-sum jobs that continue somebody else's sums: the addends of the lane's four rows, fetched now as well
-    if (J.mode == 2 && J.addend && wave < 4 * NT) {
+    if (ARX && J.mode == 2 && J.addend && wave < 4 * NT) {
         const int t_ = wave >> 2, g_ = wave & 3;
         const int mt_ = RT > 1 ? 0 : t_, tile_ = tile + (RT > 1 ? t_ : 0);
         const int b_ = mt_ * 32 + bl;
@@ -581,7 +586,8 @@ __device__ __forceinline__ void skinny_body(const SkinnyJobs& jobs) {
         } else if (J.mode == 2) {
             // partial pre-activations of a column slice: raw sums, batch-major [B][N] (the layout `addend` is read in)
             if (b < B) *reinterpret_cast<float4*>(J.y + (long)b * J.N + n) =
-                make_float4(s[0] + bias_pref.x, s[1] + bias_pref.y, s[2] + bias_pref.z, s[3] + bias_pref.w);   // (zeros without addends)
+                ARX ? make_float4(s[0] + bias_pref.x, s[1] + bias_pref.y, s[2] + bias_pref.z, s[3] + bias_pref.w)   // (zeros without addends)
+                    : make_float4(s[0], s[1], s[2], s[3]);
         } else {
             if (b < B) {
 #pragma unroll
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(SK_THREADS, 4) void decoder_lstm_step_pa64_kernel(S
 __global__ __launch_bounds__(SK_THREADS) void decoder_lstm_drain_pa_kernel(SkinnyJobs jobs) { skinny_body<1, SK_DEPTH1, false, true>(jobs); }
 template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_kernel(SkinnyJobs jobs) {   // autoregressive launches A / C
     if ((int)blockIdx.x >= jobs.tiles) { loc_body(jobs.loc, (int)blockIdx.x - jobs.tiles); return; }
-    skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2)>(jobs);
+    skinny_body<MT, (MT == 1 ? SK_DEPTH1 : SK_DEPTH2), false, false, 1, true>(jobs);
 }
 // ---- Encoder BiLSTM recurrence, resident for the whole sequence (EncPersistParams, gvx_kernels.h).
 // The launch-per-step loop pays a dispatch, a first-byte round trip for 32 KB of L2-resident weights and a kernel-end write-back
@@ -846,7 +852,7 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
 // the partial sums that only need h_a(t) - they stream while the attention's latency chain runs
 __global__ __launch_bounds__(SK_THREADS, 4) void ar_attn_tiles_kernel(SkinnyJobs jobs, AttnParams ap) {   // 4 waves per SIMD: two workgroups per CU
     if ((int)blockIdx.x < jobs.block0) { attn_step_body<4, 4>(ap, (int)blockIdx.x); return; }   // uniform per workgroup
-    skinny_body<1, SK_DEPTH1>(jobs);
+    skinny_body<1, SK_DEPTH1, false, false, 1, true>(jobs);
 }
 // autoregressive launch C beside the resident attention kernel: the context of the step arrives inside the launch (deferred segment)
 __global__ __launch_bounds__(SK_THREADS) void ar_lstm_defer_kernel(SkinnyJobs jobs) { skinny_body<1, SK_DEPTH1, false, true>(jobs); }

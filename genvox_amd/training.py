@@ -20,6 +20,8 @@ re-packing), 0.031 s now (profiles/r03_train_step_timing.txt).
 """
 from __future__ import annotations
 
+import contextlib
+import os
 import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -223,6 +225,27 @@ class _Ops:
         return out
 
 
+_SIDE: Dict[str, object] = {}
+
+
+def _side_stream(dev):
+    """The second stream of the training backward (one per device), or None when switched off."""
+    if os.environ.get("GVX_TRAIN_SIDE_STREAM", "1") == "0":
+        return None
+    key = ("stream", str(dev))
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
+def _side_ops(dev) -> "_Ops":
+    """_Ops bound to the side stream (own split-K scratch); call with that stream current."""
+    key = ("ops", str(dev))
+    if key not in _SIDE:
+        _SIDE[key] = _Ops(dev)
+    return _SIDE[key]
+
+
 def _unblock(ops: _Ops, blocked: torch.Tensor, n_slots: int, B: int, K: int) -> torch.Tensor:
     out = ops.new(n_slots, B, K)
     _lib.check(ops.lib.gvx_train_unblock(_p(blocked), _p(out), n_slots, B, K, ops.st))
@@ -318,36 +341,51 @@ def _recurrent_backward(model, ops: "_Ops", ch: dict, dmel: torch.Tensor, dgate:
         _lib.check(1)
     ws_bptt = torch.empty(wsb, dtype=torch.uint8, device=dev)
     _lib.check(lib.gvx_train_decoder_bptt(C.byref(ba_), ws_bptt.data_ptr(), wsb, st))
-    # the Prenet columns of the attention LSTM are not on the recurrence: one product over all steps
-    dp2 = ops.zeros(T + 1, B, Pn)
-    ops.gemm_nt(dga_all.reshape(T * B, 4 * A), ops.transpose(Wia)[:Pn], out=dp2[:T].reshape(T * B, Pn))
-    # ---- weight gradients of the loop, one product over all (t, b) rows each
-    dga2, dgd2 = dga_all.reshape(T * B, 4 * A), dgd_all.reshape(T * B, 4 * D)
-    g["decoder.attention_rnn.weight_ih"], g["decoder.attention_rnn.weight_hh"] = ops.mm_tn(dga2, xa), ops.mm_tn(dga2, ha_prev.contiguous())
-    g["decoder.attention_rnn.bias_ih"] = ops.colsum(dga2)
-    g["decoder.attention_rnn.bias_hh"] = g["decoder.attention_rnn.bias_ih"].clone()
-    g["decoder.decoder_rnn.weight_ih"], g["decoder.decoder_rnn.weight_hh"] = ops.mm_tn(dgd2, xd), ops.mm_tn(dgd2, hd_prev)
-    g["decoder.decoder_rnn.bias_ih"] = ops.colsum(dgd2)
-    g["decoder.decoder_rnn.bias_hh"] = g["decoder.decoder_rnn.bias_ih"].clone()
-    g[att + "query_layer.linear_layer.weight"] = ops.mm_tn(dq_all.reshape(T * B, a), ha[1:].reshape(T * B, A).contiguous())
-    g[att + "v.linear_layer.weight"] = dv[None, :]
-    g[att + "location_layer.location_dense.linear_layer.weight"] = dld
-    g[att + "location_layer.location_conv.conv.weight"] = dlw
-    dpm2 = dpm.reshape(B * L, a)
-    g[att + "memory_layer.linear_layer.weight"] = ops.mm_tn(dpm2, memory.reshape(B * L, E))
+    # ---- Off the chain to the encoder: the loop's weight gradients and the whole Prenet backward (dense products, ~5 ms at
+    # 32 x 200 frames) go to a second stream; the caller's stream goes on with the memory gradient and the encoder's BiLSTM walk
+    # (a launch per position on a quarter of the chip) and waits for them at the end.  One fork and one join per chunk (an edge
+    # costs ~5 us: tools/micro/chain_sidestream_bench.hip); every tensor is produced by the same launches in the same order as on
+    # one stream, so results do not change.  GVX_TRAIN_SIDE_STREAM=0: everything on the caller's stream.
+    main_stream = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    if side is not None:
+        fork = torch.cuda.Event(); fork.record(main_stream)
+        side.wait_event(fork)
+    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        ops_s = _side_ops(dev) if side is not None else ops
+        st_s = ops_s.st
+        dpm2 = dpm.reshape(B * L, a)
+        # the Prenet columns of the attention LSTM are not on the recurrence: one product over all steps
+        dp2 = ops_s.zeros(T + 1, B, Pn)
+        ops_s.gemm_nt(dga_all.reshape(T * B, 4 * A), ops_s.transpose(Wia)[:Pn], out=dp2[:T].reshape(T * B, Pn))
+        # ---- weight gradients of the loop, one product over all (t, b) rows each
+        dga2, dgd2 = dga_all.reshape(T * B, 4 * A), dgd_all.reshape(T * B, 4 * D)
+        g["decoder.attention_rnn.weight_ih"], g["decoder.attention_rnn.weight_hh"] = ops_s.mm_tn(dga2, xa), ops_s.mm_tn(dga2, ha_prev.contiguous())
+        g["decoder.attention_rnn.bias_ih"] = ops_s.colsum(dga2)
+        g["decoder.attention_rnn.bias_hh"] = g["decoder.attention_rnn.bias_ih"].clone()
+        g["decoder.decoder_rnn.weight_ih"], g["decoder.decoder_rnn.weight_hh"] = ops_s.mm_tn(dgd2, xd), ops_s.mm_tn(dgd2, hd_prev)
+        g["decoder.decoder_rnn.bias_ih"] = ops_s.colsum(dgd2)
+        g["decoder.decoder_rnn.bias_hh"] = g["decoder.decoder_rnn.bias_ih"].clone()
+        g[att + "query_layer.linear_layer.weight"] = ops_s.mm_tn(dq_all.reshape(T * B, a), ha[1:].reshape(T * B, A).contiguous())
+        g[att + "v.linear_layer.weight"] = dv[None, :]
+        g[att + "location_layer.location_dense.linear_layer.weight"] = dld
+        g[att + "location_layer.location_conv.conv.weight"] = dlw
+        g[att + "memory_layer.linear_layer.weight"] = ops_s.mm_tn(dpm2, memory.reshape(B * L, E))
+        # ---- Prenet (relu then dropout, twice; models/tts/tacotron2.py:140-144)
+        pk = ch["prenet_keep"]                                        # [2, T+1, B, P] uint8
+        p1 = ch["p1"]
+        w1 = W("decoder.prenet.layers.1.linear_layer.weight")
+        n_rows = (T + 1) * B
+        dz2 = ops_s.new(n_rows, Pn)
+        _lib.check(lib.gvx_train_relu_dropout_backward(_p(dp2), _p(p2.contiguous()), _p(pk[1].contiguous()), 2.0, n_rows * Pn, _p(dz2), st_s))
+        g["decoder.prenet.layers.1.linear_layer.weight"] = ops_s.mm_tn(dz2, p1.reshape(n_rows, Pn).contiguous())
+        dp1 = ops_s.gemm_nt(dz2, ops_s.transpose(w1))
+        dz1 = ops_s.new(n_rows, Pn)
+        _lib.check(lib.gvx_train_relu_dropout_backward(_p(dp1), _p(p1.contiguous()), _p(pk[0].contiguous()), 2.0, n_rows * Pn, _p(dz1), st_s))
+        g["decoder.prenet.layers.0.linear_layer.weight"] = ops_s.mm_tn(dz1, ch["frames"].reshape(n_rows, M).contiguous())
+        if side is not None:
+            join = torch.cuda.Event(); join.record(side)
     dmemory = ops.axpby(dmemory.reshape(B * L, E), 1.0, ops.gemm_nt(dpm2, ops.transpose(wm)), 1.0).reshape(B, L, E)
-    # ---- Prenet (relu then dropout, twice; models/tts/tacotron2.py:140-144)
-    pk = ch["prenet_keep"]                                        # [2, T+1, B, P] uint8
-    p1 = ch["p1"]
-    w1 = W("decoder.prenet.layers.1.linear_layer.weight")
-    n_rows = (T + 1) * B
-    dz2 = ops.new(n_rows, Pn)
-    _lib.check(lib.gvx_train_relu_dropout_backward(_p(dp2), _p(p2.contiguous()), _p(pk[1].contiguous()), 2.0, n_rows * Pn, _p(dz2), st))
-    g["decoder.prenet.layers.1.linear_layer.weight"] = ops.mm_tn(dz2, p1.reshape(n_rows, Pn).contiguous())
-    dp1 = ops.gemm_nt(dz2, ops.transpose(w1))
-    dz1 = ops.new(n_rows, Pn)
-    _lib.check(lib.gvx_train_relu_dropout_backward(_p(dp1), _p(p1.contiguous()), _p(pk[0].contiguous()), 2.0, n_rows * Pn, _p(dz1), st))
-    g["decoder.prenet.layers.0.linear_layer.weight"] = ops.mm_tn(dz1, ch["frames"].reshape(n_rows, M).contiguous())
     # ---- encoder BiLSTM, packed-sequence semantics (models/tts/tacotron2.py:239-245): one C-ABI call, a launch per time step
     H = E // 2
     x = x.contiguous()
@@ -372,6 +410,8 @@ def _recurrent_backward(model, ops: "_Ops", ch: dict, dmel: torch.Tensor, dgate:
         g["encoder.lstm.bias_ih_l0" + sfx] = ops.colsum(dg2)
         g["encoder.lstm.bias_hh_l0" + sfx] = g["encoder.lstm.bias_ih_l0" + sfx].clone()
         dx_enc = ops.axpby(dx_enc, 1.0, ops.gemm_nt(dg2, ops.transpose(w_ih2[d_])), 1.0)
+    if side is not None:
+        main_stream.wait_event(join)
     return g, dx_enc
 
 

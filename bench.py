@@ -381,15 +381,19 @@ def main():
             lanes = getattr(model, "last_forward_lanes", False)
             st64, _ = model.stage_times_ms(lane=0 if lanes else None)
             model.enable_stage_timing(False)
+            seq32 = getattr(model, "last_forward_sequential32", False)
             if lanes:
                 execution = "2 chunks x 32 rows, concurrently on 2 HIP streams, one C-ABI call each (launch per attention step)"
+            elif seq32:
+                execution = ("2 chunks x 32 rows, one after the other on one stream, each beside the resident attention kernel "
+                             "(stage_ms: the second chunk's call)")
             else:
                 execution = ("ONE call: 64-row loop beside the resident attention kernel (64 CUs), 384-workgroup launches with two batch "
                              "tiles each - one pass over the recurrent weights per step for all 64 rows")
             e64 = {"mel_frames_per_s": round(64 * T / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": args.steps, "execution": execution,
                    "stage_ms": {k: round(v, 3) for k, v in st64.items()},
-                   "decoder_step_us_per_64_rows": round(st64["decoder_loop"] * 1e3 / T, 2)}
-            if not lanes:
+                   "decoder_step_us_per_64_rows": round(st64["decoder_loop"] * 1e3 / T * (2 if seq32 else 1), 2)}
+            if not lanes and not seq32:
                 e64["roofline"] = lstm_roofline(model, 64, b64, st64["decoder_loop"])
             extra["tf_b64x800"] = e64
             del b64

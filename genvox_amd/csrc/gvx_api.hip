@@ -1433,6 +1433,11 @@ int gvx_teacher_forced_rows_per_call(const gvx_model* m, int L) {
     return persistent_path(m, 64, L) ? 64 : 32;
 }
 
+int gvx_teacher_forced_resident(const gvx_model* m, int B, int L) {
+    if (!m || B < 1 || L < 1) return 0;
+    return persistent_path(m, B, L) ? 1 : 0;
+}
+
 int gvx_model_set_persistent_attention(gvx_model* m, int enable) {
     if (!m) return fail(GVX_ERR_INVALID_ARG, "null argument");
     m->attn_persistent = enable != 0;

@@ -363,10 +363,18 @@ class Tacotron2(nn.Module):
         if B > STREAM_ROWS and lib.gvx_teacher_forced_rows_per_call(self._handle, L) == MAX_CALL_BATCH:
             rows = MAX_CALL_BATCH
         self.last_forward_lanes = B > rows and rows == STREAM_ROWS   # (bench.py: whose stage timers hold the last call)
+        self.last_forward_sequential32 = False
         if B <= rows:
             run(0, B, self._get_workspace(B, L, T), self._handle)
             return out
-        if rows == MAX_CALL_BATCH:   # chunks of at most 64 rows, one after the other on the caller's stream
+        # 32-row chunks that take the resident-attention loop run one after the other on the caller's stream: that loop fills
+        # the chip by itself (2 x 18.7 ms for 64 x 800 frames), two concurrent lanes would have to give it up (39.3 ms).
+        # GVX_TF_LANES=1 forces the lanes (tests, A/B runs).
+        sequential = rows == MAX_CALL_BATCH or (os.environ.get("GVX_TF_LANES", "0") != "1"
+                                                and lib.gvx_teacher_forced_resident(self._handle, STREAM_ROWS, L) == 1)
+        self.last_forward_lanes = self.last_forward_lanes and not sequential
+        self.last_forward_sequential32 = sequential and rows == STREAM_ROWS
+        if sequential:   # chunks of at most `rows` rows, one after the other on the caller's stream
             n_chunks = -(-B // rows)
             bounds = [(B * i) // n_chunks for i in range(n_chunks + 1)]
             ws = self._get_workspace(max(hi - lo for lo, hi in zip(bounds, bounds[1:])), L, T)

@@ -125,9 +125,14 @@ int gvx_model_set_persistent_attention(gvx_model* model, int enable);
 
 /* Batch rows gvx_tacotron2_forward / gvx_decoder_teacher_forced serve best per call for rows of L tokens: 64 where the 64-row
  * loop beside the resident attention kernel applies (default layer sizes, L <= 128, resident attention enabled: one pass over
- * the recurrent weights per step for all 64 rows), else 32 (callers with more rows run 32-row chunks on two streams with a
+ * the recurrent weights per step for all 64 rows), else 32 (callers with more rows run 32-row chunks - in turn where gvx_teacher_forced_resident says 1, else on two streams with a
  * handle each, as the host mirror does).  Any B in [1, 64] is accepted by every call regardless. */
 int gvx_teacher_forced_rows_per_call(const gvx_model* model, int L);
+
+/* 1 if a teacher-forced call with B rows of L tokens runs its decoder loop beside the resident attention kernel (the fast path:
+ * such chunks are best run one after the other on one stream - 2 x 18.7 ms for 64 x 800 frames against 39.3 ms as two
+ * concurrent lanes of launch-per-step loops), 0 if it takes a launch per attention step (chunks then gain from two streams). */
+int gvx_teacher_forced_resident(const gvx_model* model, int B, int L);
 
 /* ---- Encoder: embedding + conv/BN/relu stack + BiLSTM with packed-sequence semantics.
  * Replaces nn.Embedding + Encoder.forward / Encoder.inference (models/tts/tacotron2.py:459,

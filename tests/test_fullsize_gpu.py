@@ -301,17 +301,20 @@ def test_config1_single_utterance_b1_l100_t568():
     assert float((got["alignments"].sum(dim=2) - 1).abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize("mode", ["one_call_64_rows", "two_lanes_of_32"])
+@pytest.mark.parametrize("mode", ["one_call_64_rows", "two_lanes_of_32", "two_chunks_of_32_in_turn"])
 def test_north_star_batch_64x800(mode, monkeypatch):
     """north_star's target batch (64 x 800 frames, 128 tokens) through Tacotron2.forward, both ways it can run: as ONE call -
     the 64-row loop beside the resident attention kernel (GVX_TF_ROWS64=1: two batch tiles per workgroup, decoder cell cut
-    along K and finished one launch later) - and, by default, as two 32-row chunks on two HIP streams with a C-ABI handle
-    each.  Deterministic, softmax rows sum to one, rows independent of the batch they run in
+    along K and finished one launch later) -, as two 32-row chunks on two HIP streams with a C-ABI handle each
+    (GVX_TF_LANES=1: launch-per-step attention) and, by default, as two 32-row chunks one after the other on the caller's
+    stream, each beside the resident attention kernel.  Deterministic, softmax rows sum to one, rows independent of the batch they run in
     (rows 0 / 32 / 63 run alone reproduce themselves), and the first 100 steps of rows 0 / 32 / 63 equal what the oracle
     gives on a 100-frame run (the teacher-forced decoder is causal; the Postnet prefix is compared where its receptive
     field - 5 layers x 2 frames - lies inside the prefix)."""
     if mode == "one_call_64_rows":
-        monkeypatch.setenv("GVX_TF_ROWS64", "1")   # opt-in (the lanes are faster: gvx_api.hip)
+        monkeypatch.setenv("GVX_TF_ROWS64", "1")   # opt-in (the chunks are faster: gvx_api.hip)
+    if mode == "two_lanes_of_32":
+        monkeypatch.setenv("GVX_TF_LANES", "1")
     mc, ac, tc = full_configs()
     sd = gw.generate_state_dict(mc, ac, tc, seed=0)
     m = Tacotron2(mc, ac, tc)
@@ -327,6 +330,7 @@ def test_north_star_batch_64x800(mode, monkeypatch):
     out = m.forward({**batch, "prenet_keep_masks": masks})
     m.check_status()
     assert m.last_forward_lanes == (mode == "two_lanes_of_32")
+    assert m.last_forward_sequential32 == (mode == "two_chunks_of_32_in_turn")
     out2 = m.forward({**batch, "prenet_keep_masks": masks})
     for k in KEYS:
         assert torch.isfinite(out[k]).all(), k

@@ -13,7 +13,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 // ---- the neighbour: 256 threads, 56 KB of LDS, each wave streams fragments out of LDS through the matrix pipe
-template <int MODE>   // 0: bf16 32x32x16, 1: fp32 32x32x2, 2: VALU only, 3: bf16 32x32x8 (older instruction), 4: bf16 16x16x32
+template <int MODE>   // 0: bf16 32x32x16, 1: fp32 32x32x2, 2: VALU only, 3: bf16 32x32x8 (older instruction), 4: bf16 16x16x32, 5: f16 32x32x16, 6: f16 16x16x32
 __global__ __launch_bounds__(256) void neighbour(float* sink, int iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -48,6 +48,21 @@ __global__ __launch_bounds__(256) void neighbour(float* sink, int iters) {
                 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][q], b[j][q], t, 0, 0, 0);
                 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2 - q], b[j][2 - q], t, 0, 0, 0);
                 acc[i][j][0] = t[0]; acc[i][j][1] = t[1]; acc[i][j][2] = t[2]; acc[i][j][3] = t[3];
+            } else if (MODE == 5 || MODE == 6) {   // the double-rate fp16 forms of gfx950 (same operand registers, read as 8 halves)
+                typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+                const f16x8_t ha = __builtin_bit_cast(f16x8_t, a[i][q]), hb = __builtin_bit_cast(f16x8_t, b[j][2 - q]);
+                if (MODE == 5) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, ha, acc[i][j], 0, 0, 0);
+                } else {
+                    typedef __attribute__((ext_vector_type(4))) float f32x4;
+                    f32x4 t = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb, ha, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, ha, t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb, hb, t, 0, 0, 0);
+                    acc[i][j][0] = t[0]; acc[i][j][1] = t[1]; acc[i][j][2] = t[2]; acc[i][j][3] = t[3];
+                }
             } else if (MODE == 1) {
                 const float4 fa = __builtin_bit_cast(float4, a[i][q]), fb = __builtin_bit_cast(float4, b[j][q]);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[i][j], 0, 0, 0);
@@ -302,6 +317,8 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbour<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbour<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbour<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbour<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbour<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     std::vector<float> hw(8192 * 4 + 65536 * 4), hx(128 * 80);
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xffff) / 65536.f - 0.5f; };
@@ -334,6 +351,8 @@ int main(int argc, char** argv) {
     if (trial_lds<0, 64>("LDS exchange only, 64 threads (one wave), next to bf16 mfma", sv, sn, outr, refr, sink, mism, rounds)) return 1;
     if (trial<3>("next to v_mfma_f32_32x32x8_bf16_1k", sv, sn, w, x, out, ref, sink, mism, rounds)) return 1;
     if (trial<4>("next to v_mfma_f32_16x16x32_bf16", sv, sn, w, x, out, ref, sink, mism, rounds)) return 1;
+    if (trial<5>("next to v_mfma_f32_32x32x16_f16", sv, sn, w, x, out, ref, sink, mism, rounds)) return 1;
+    if (trial<6>("next to v_mfma_f32_16x16x32_f16", sv, sn, w, x, out, ref, sink, mism, rounds)) return 1;
     if (trial_part<0, 0>("global 16-byte loads only, next to bf16 32x32x16", sv, sn, w, outr, refr, sink, mism, rounds)) return 1;
     if (trial_part<0, 1>("LDS 16-byte exchange in 54 KB, next to bf16 32x32x16", sv, sn, w, outr, refr, sink, mism, rounds)) return 1;
     if (trial_bcast<4, 0>("LDS 4-byte broadcast reads + fma, next to bf16 16x16x32", sv, sn, outr, refr, sink, mism, rounds)) return 1;

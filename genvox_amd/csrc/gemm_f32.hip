@@ -41,7 +41,7 @@ __device__ __forceinline__ long row_off(const RowMap& m, int row) {
 // KMAJ: both operands are K-major - element (m, k) of A at A + amap(k) + m, element (n, k) of W at W + wmap(k) + n - the
 // form of a weight gradient (sum over the rows of two activation matrices) without transposed copies.
 template <int WR, int WC, int TM, int TN, bool KMAJ = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int block_x) {
     constexpr int BM = WR * TM * 32;
     constexpr int BN = WC * TN * 32;
     constexpr int A_V4 = BM / 32;  // float4 loads per thread for the A tile
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int r = lane & 31, h = lane >> 5;
     // consecutive blocks share the W panel (same n-tile) -> neighbouring M tiles stay in one L2
     const int n_tiles = (p.N + BN - 1) / BN;
-    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x % n_tiles;
+    const int mt = block_x / n_tiles, nt = block_x % n_tiles;
     const int m0 = p.m_begin + mt * BM, n0 = nt * BN;
     // split-K: this workgroup's k range and partial output (the whole K and C itself when splitk == 1)
     const int k_begin = p.splitk > 1 ? (int)blockIdx.y * p.kchunk : 0;
@@ -246,6 +246,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
+template <int WR, int WC, int TM, int TN, bool KMAJ = false>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) { gemm_f32_body<WR, WC, TM, TN, KMAJ>(p, (int)blockIdx.x); }
+
+// Two tile shapes in ONE launch (the wave-quantisation cover of launch_gemm): the first `n_big` workgroups take the 128 x 128
+// tiles of the full rounds (params `big`), the others the 64 x 64 tiles of the remaining rows (`small`), which fill the CUs
+// as the last big round drains.  As two launches the remainder ran alone on half the chip behind a barrier (90 us per Postnet
+// convolution); Postnet at 32 x 800 frames 2.42 -> 2.21 ms (small tiles FIRST: 2.29).
+__global__ __launch_bounds__(256) void gemm_f32_two_shape_kernel(GemmParams big, GemmParams small, int n_big) {
+    const int bx = (int)blockIdx.x;   // (the branch is uniform per workgroup)
+    if (bx < n_big) gemm_f32_body<2, 2, 2, 2>(big, bx);
+    else gemm_f32_body<2, 2, 1, 1>(small, bx - n_big);
+}
+
 template <int WR, int WC, int TM, int TN>
 static size_t lds_bytes_cfg() { return (size_t)2 * (WR * TM * 32 + WC * TN * 32) * LDS_LD * sizeof(float); }
 
@@ -270,7 +283,10 @@ hipError_t gemm_init() {
     if (e != hipSuccess) return e;
     e = init_cfg<2, 2, 1, 2, true>();
     if (e != hipSuccess) return e;
-    return init_cfg<4, 1, 1, 1>();
+    e = init_cfg<4, 1, 1, 1>();
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_two_shape_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds_bytes_cfg<2, 2, 2, 2>());
 }
 
 template <int WR, int WC, int TM, int TN, bool KMAJ = false>
@@ -308,7 +324,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     // Wave quantisation: 128 x 128 tiles run in rounds of 256 (one per CU); a last round with few tiles leaves most of the
     // chip idle for a whole tile time (the Postnet at 32 x 800 frames: 800 tiles = 3 rounds + 32 tiles, 78 % of 4 rounds).
     // When the last round would be at most a quarter full, the rows of the full rounds get the big tiles and the remaining
-    // rows a second launch with 64 x 64 tiles (four times as many workgroups, a quarter of the time each).  Every output
+    // rows 64 x 64 tiles (four times as many workgroups, a quarter of the time each) behind them in the same launch.  Every output
     // element still sums its K products in the same order: results do not depend on the tile shape.
     const long rem = tiles128 % 256;
     if (p.splitk <= 1 && p.m_begin == 0 && rem > 0 && rem <= 64) {
@@ -317,6 +333,13 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
             GemmParams a = p, b = p;
             a.M = (int)rows_big;
             b.m_begin = (int)rows_big;
+            static const bool two_launches = [] { const char* e = std::getenv("GVX_GEMM_TWO_LAUNCHES"); return e && e[0] == '1'; }();   // (A/B)
+            if (!two_launches) {
+                const int n_small = ((p.M - b.m_begin + 63) / 64) * ((p.N + 63) / 64);
+                const int n_big = (a.M / 128) * (int)n_tiles;
+                gemm_f32_two_shape_kernel<<<dim3(n_big + n_small), dim3(256), lds_bytes_cfg<2, 2, 2, 2>(), s>>>(a, b, n_big);
+                return hipGetLastError();
+            }
             const hipError_t e = launch_cfg<2, 2, 2, 2>(a, s);
             if (e != hipSuccess) return e;
             return launch_cfg<2, 2, 1, 1>(b, s);

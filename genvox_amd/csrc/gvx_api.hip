@@ -1107,8 +1107,10 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         rc = decoder_prenet_part(m, B, L, mel_in, T, keep_masks, ws, wp, s);
         if (rc != GVX_OK) return rc;
     }
-    rc = decoder_init_states(m, memory, B, L, db, s);
-    if (rc != GVX_OK) return rc;
+    if (!prenet_done) {   // (the fused forward has run this behind its encoder, on the side stream, beside the Prenet products)
+        rc = decoder_init_states(m, memory, B, L, db, s);
+        if (rc != GVX_OK) return rc;
+    }
     if (timed) HIP_TRY(hipEventRecord(m->ev[2], s));
     // ---- T decoder steps.  Launch 1 of step t: attention-LSTM(t) together with decoder-LSTM(t-1), which is off
     // the critical chain (only the next step's projection needs it).  Launch 2: the attention step (energies, softmax, context;
@@ -1597,6 +1599,10 @@ int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* to
         // side from the start, the two sets of GEMMs only slowed each other 3x and left the second half of the recurrence - a
         // quarter of the chip, latency bound - alone on an idle GPU (kernel timeline, tools/kernel_timeline.py, round 3)
         rc = encoder_impl(m, tokens, token_lengths, B, L, memory, ws, wp, m->pa_stream, nullptr, nullptr, nullptr, m->enc_mid);
+        if (rc != GVX_OK) return rc;
+        // the decoder's zero states and the memory projection (needs the encoder output) right behind the encoder on its stream:
+        // they end under the tail of the Prenet products instead of between the join and the first step (~60 us)
+        rc = decoder_init_states(m, memory, B, L, decoder_buffers(ws, wp), m->pa_stream);
         if (rc != GVX_OK) return rc;
         HIP_TRY(hipEventRecord(m->pa_join, m->pa_stream));
         HIP_TRY(hipStreamWaitEvent(s, m->enc_mid, 0));

@@ -782,7 +782,7 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
     const bool cell_wave = wave < 4;
     const int g = wave & 3, jloc = 2 * g + h, j = tile * 8 + jloc;
     const bool row = bl < B;
-    const int len = row ? (p.lengths ? p.lengths[bl] : L) : 0;
+    const int len = row ? (p.lengths ? min(max(p.lengths[bl], 0), L) : L) : 0;   // (clamped: a bad length must not index past the row)
     float c_state = 0.f, h_state = 0.f;
     unsigned* cnt = p.sync + (dir ? HANDOFF_CNT_CTX : HANDOFF_CNT_Q);
     unsigned* tmo = p.sync + HANDOFF_TIMEOUT;

@@ -756,8 +756,9 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_ker
 // per position (7.3 us of kernel + 1.5 us of gap for ~1 us of work).  Here workgroup (direction, tile) holds its weight
 // fragments (4 k-groups per wave = 16 VGPRs), its cell states and its previous hidden values in registers; per position it
 // waits for the direction's counter (all 32 tiles have published h(t-1)), reads the 32 KB vector with sc1 loads, runs 16
-// MFMAs per wave, sums the K slices through LDS, finishes the cells of its 8 hidden units, stores h(t) write-through and adds
-// one to the counter.  Buffer parity: h(t) goes to buffer (t+1) & 1, which position t-1's readers have left - they all
+// MFMAs per wave, sums the K slices through LDS, finishes the cells of its 8 hidden units, stores h(t) write-through and raises
+// its flags (one word per cell wave, plain stores: 128 adds per position to ONE counter word serialised at the memory side -
+// 529 us for 128 positions with the counter, tools/micro/handoff_latency.hip for the parts of a hand-off).  Buffer parity: h(t) goes to buffer (t+1) & 1, which position t-1's readers have left - they all
 // published h(t-1) before anybody could pass the wait of position t.  Every wait is bounded (handoff_wait): after a time-out
 // all waits return at once, the grid drains, and the caller's poison launch overwrites the output with NaN.
 __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(EncPersistParams p) {
@@ -801,7 +802,22 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
         if (step > 0) {   // h(-1) = 0: nothing to multiply at the first position
-            if (tid == 0) handoff_wait<true>(cnt, 4u * (unsigned)tiles * (unsigned)step, tmo, 0x400u + (unsigned)dir, p.spin_limit);
+            if (wave == 0) {   // every lane watches two of the direction's 4 * tiles flags: one 16-byte-per-lane look covers them all
+                const unsigned nflag = 4u * (unsigned)tiles;
+                const unsigned f0 = (unsigned)lane < nflag ? (unsigned)lane : 0u, f1 = (unsigned)lane + 64u < nflag ? (unsigned)lane + 64u : 0u;
+                const unsigned limit = (p.spin_limit ? p.spin_limit : HANDOFF_SPIN_LIMIT) * 16u;
+                unsigned spins = 0;
+                while (true) {
+                    const unsigned v0 = __hip_atomic_load(cnt + f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned v1 = __hip_atomic_load(cnt + f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(v0 >= (unsigned)step && v1 >= (unsigned)step)) break;
+                    if ((++spins & 127u) == 1u) {   // (after a time-out every wait gives up at its first look)
+                        if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                        if (spins > limit) { if (lane == 0) __hip_atomic_store(tmo, 0x400u + (unsigned)dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
             __syncthreads();
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.hx + ((long)dir * 2 + (step & 1)) * H * B);
             float4 xv[KPW];
@@ -843,7 +859,7 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
         // before the next position's barrier, which these waves reach after their reads
         if (cell_wave) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores of this wave have left
-            if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(cnt + 4 * tile + wave, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -82,6 +82,19 @@ __device__ __forceinline__ void attn_step_body(const AttnParams& p, const int bl
     // Block -> (row, slice) mapping: workgroups are dealt round-robin over the 8 XCDs (blocks i and i + 8 share an L2), and
     // the G slices of a row all read the same 128 KB (query slabs + ploc).  Slices of one row therefore take block ids that
     // are congruent mod 8: the row's bytes are fetched into that XCD's L2 once.  (Speed only - nothing depends on placement.)
+    // prefetch for the next launch (AttnParams.pf_*): this wave's first four k-groups of tile `block_id`, as that launch will read them
+    float4 pfv0 = make_float4(0.f, 0.f, 0.f, 0.f), pfv1 = pfv0;
+    const bool pf = p.pf_w[0] != nullptr && block_id < p.pf_tiles;
+    if (pf) {
+        const int j = block_id >= p.pf_tiles0, t = block_id - (j ? p.pf_tiles0 : 0);
+        const int nkg = p.pf_nkg[j], per = (nkg + 7) >> 3;
+        const int w_ = (int)threadIdx.x >> 6, kb = min(w_ * per, nkg - 1);
+        const float4* wp = reinterpret_cast<const float4*>(p.pf_w[j]) + ((long)t * nkg + kb) * 64 + (threadIdx.x & 63);
+        pfv0 = wp[0];
+        pfv1 = wp[kb + 1 < nkg ? 64 : 0];
+        const float4 c2 = wp[kb + 2 < nkg ? 128 : 0], c3 = wp[kb + 3 < nkg ? 192 : 0];
+        pfv0.y += c2.x; pfv1.y += c3.x;
+    }
     const int xcd = block_id & 7, jb = block_id >> 3;
     const int b = (jb / p.G) * 8 + xcd, g = jb % p.G;
     if (b >= B) return;   // uniform per workgroup (padding blocks when B is not a multiple of 8)
@@ -249,6 +262,7 @@ __device__ __forceinline__ void attn_step_body(const AttnParams& p, const int bl
         }
         if (c0 + CC < c_end) __syncthreads();
     }
+    if (pf) asm volatile("" :: "v"(pfv0.x), "v"(pfv0.w), "v"(pfv1.x), "v"(pfv1.w));   // (the loads only have to have happened)
     GVX_STAMP(1, 5);
 }
 

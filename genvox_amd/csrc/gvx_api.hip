@@ -1212,6 +1212,15 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
             HIP_TRY(launch_skinny(jobs, t > 0 ? 2 : 1, SK_DECODER, st, &lq));
             AttnParams ap;
             fill_attn(m, ap, memory, len_ws, t, B, L, db.align_tm, (long)L, (long)B * L, db);
+            {   // the attention launch has the chip to itself: block i pulls the first k-groups of tile i of the NEXT launch into
+                // its XCD's L2 (both grids are dealt round-robin over the XCDs) - loop 20.27 -> 20.06 ms at 32 x 800
+                // (GVX_ATTN_PREFETCH=0: off); the rotated K walk (GVX_SK_ROT, an A/B knob) is not followed
+                static const bool prefetch = [] { const char* e = std::getenv("GVX_ATTN_PREFETCH"); return !e || e[0] != '0'; }();
+                if (prefetch && m->attn_one_launch && B <= 32) {
+                    ap.pf_w[0] = m->dev_blob + m->blob.att_frag; ap.pf_w[1] = m->dev_blob + m->blob.dec_frag;
+                    ap.pf_nkg[0] = (d.prenet_dim + E + d.att_rnn_dim) / 8; ap.pf_nkg[1] = (d.att_rnn_dim + E + D) / 8;
+                    ap.pf_tiles0 = 4 * d.att_rnn_dim / 32; ap.pf_tiles = ap.pf_tiles0 + 4 * D / 32;
+                } }
             HIP_TRY(launch_attn(m, ap, st));
             launches += m->attn_one_launch ? 2 : 3;
         }

@@ -185,6 +185,10 @@ struct AttnParams {
     float* w_out; long w_out_bs;            // new alignment row b -> w_out + b*bs   (length L)
     float* ctx_out;                         // blocked context vector [E/8][B][8]
     int B, L, a, F, kl, E, G;
+    // (teacher-forced launch-per-step loop; GVX_ATTN_PREFETCH=0: off) first k-groups of the NEXT weight-streaming launch, pulled into this XCD's L2 by the
+    // block with the same index (blocks of both launches are dealt round-robin over the XCDs): fragment-packed matrices of that
+    // launch's jobs 0 / 1, their k-groups per tile, tiles of job 0, tiles in all
+    const float* pf_w[2]; int pf_nkg[2]; int pf_tiles0, pf_tiles;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);   // energy + context kernels (p.loc = location features)
 // one launch: energies of the whole row (redundantly per slice), softmax, context slice; p.loc = pm + location features

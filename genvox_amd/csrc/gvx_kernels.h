@@ -144,7 +144,7 @@ struct AttnParams;
 hipError_t launch_skinny_attn(const SkinnyJob* jobs, int njobs, const AttnParams& ap, hipStream_t s);
 // Encoder BiLSTM recurrence as ONE resident launch (skinny.hip, encoder_lstm_persistent_kernel): 2 directions x 32 tiles, every
 // workgroup keeps its 32 KB of W_hh in registers for the whole sequence and its cell states in registers; the hidden state goes
-// round through a double-buffered blocked vector (write-through stores, sc1 loads) with one counter per direction.  B <= 32,
+// round through a double-buffered blocked vector (write-through stores, sc1 loads) with one flag word per cell wave.  B <= 32,
 // H = 256 (the default layer size); packed-sequence semantics as the launch-per-step loop.
 struct EncPersistParams {
     const float* Wp[2];        // packed fragments of W_hh per direction [H/8 tiles][H/8 k-groups][64][4]
@@ -153,7 +153,8 @@ struct EncPersistParams {
     float* hx;                 // exchange buffers [2 directions][2][H/8][B][8]
     float* seq_out;            // [B][L][2H]: direction d writes columns d*H ..
     float* c_seq_out;          // training tape: the cell state of every position, same layout, or nullptr
-    unsigned* sync;            // HANDOFF_WORDS words (zeroed by the caller): counters at HANDOFF_CNT_Q / HANDOFF_CNT_CTX, time-out word
+    unsigned* sync;            // HANDOFF_WORDS words (zeroed by the caller): flags from HANDOFF_CNT_Q / HANDOFF_CNT_CTX on (one
+                               // direction each, 4 x H/8 words), time-out word
     unsigned spin_limit;
     int B, L, H;
 };

@@ -65,6 +65,28 @@ def test_weight_generator_is_deterministic():
     assert a.min() >= 0 and a.max() < 1
 
 
+def test_resident_loop_policy_queries():
+    """Which teacher-forced shapes run beside the resident attention kernel (host-side policy, no GPU needed): default layer
+    sizes up to 32 rows x 256 tokens do, longer rows / reduced layer sizes / a handle marked as sharing the GPU do not; the
+    64-row loop is opt-in, so 32 rows per call is what callers should send."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    d = dims_from_configs(Tacotron2Config(), AudioConfig(), TextConfig(n_tokens=40))
+    assert lib.gvx_model_create(C.byref(d), C.byref(h)) == 0
+    assert lib.gvx_teacher_forced_resident(h, 32, 128) == 1 and lib.gvx_teacher_forced_resident(h, 1, 190) == 1
+    assert lib.gvx_teacher_forced_resident(h, 32, 300) == 0 and lib.gvx_teacher_forced_resident(h, 64, 128) == 0
+    assert lib.gvx_teacher_forced_resident(h, 0, 128) == 0 and lib.gvx_teacher_forced_resident(None, 32, 128) == 0
+    assert lib.gvx_teacher_forced_rows_per_call(h, 128) == 32
+    assert lib.gvx_model_set_persistent_attention(h, 0) == 0
+    assert lib.gvx_teacher_forced_resident(h, 32, 128) == 0
+    lib.gvx_model_destroy(h)
+    from tests.golden.cases import TF_CASES, case_configs
+    d = dims_from_configs(*case_configs(TF_CASES["tf_small"]))
+    assert lib.gvx_model_create(C.byref(d), C.byref(h)) == 0
+    assert lib.gvx_teacher_forced_resident(h, 4, 16) == 0   # reduced layer sizes: launch per attention step
+    lib.gvx_model_destroy(h)
+
+
 def test_pack_weights_errors_and_unsupported_dims():
     lib = _lib.load()
     mc, ac, tc = Tacotron2Config(prenet_dim=100), AudioConfig(), TextConfig(n_tokens=10)

@@ -891,6 +891,7 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
         ep.Wp[0] = m->dev_blob + m->blob.enc_whh_frag[0]; ep.Wp[1] = m->dev_blob + m->blob.enc_whh_frag[1];
         ep.xg = xg; ep.lengths = len_ws; ep.hx = enc_h; ep.seq_out = mem_ws; ep.c_seq_out = c_seq_out;
         ep.sync = sync; ep.spin_limit = m->spin_limit; ep.B = B; ep.L = L; ep.H = H;
+        { const char* e = std::getenv("GVX_DEBUG_ENC_SKIP_BLOCK"); ep.debug_skip_block = e ? std::atoi(e) : -1; }   // (tests: forced time-out)
         HIP_TRY(launch_encoder_persistent(ep, s));
         float* outs[2] = {mem_ws, c_seq_out};
         const size_t counts[2] = {(size_t)B * L * E, (size_t)B * L * E};

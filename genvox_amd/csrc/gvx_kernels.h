@@ -157,6 +157,7 @@ struct EncPersistParams {
                                // direction each, 4 x H/8 words), time-out word
     unsigned spin_limit;
     int B, L, H;
+    int debug_skip_block;      // tests: this workgroup leaves at once (its flags never go up: every wait on them times out); -1 = none
 };
 bool encoder_persistent_supported(int B, int H);
 hipError_t launch_encoder_persistent(const EncPersistParams& p, hipStream_t s);

@@ -768,6 +768,7 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
     // (one direction per XCD - blocks i % 8 == d of a grid of 8 x 32, the rest leaving at once - was tried: 1.97 instead of
     // 1.78 ms for the encoder stage; the exchange goes through memory either way and 32 workgroups then share one XCD's L2)
     const int dir = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - dir * tiles;
+    if ((int)blockIdx.x == p.debug_skip_block) return;   // (tests of the time-out path; uniform per workgroup)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bl = lane & 31, h = lane >> 5;

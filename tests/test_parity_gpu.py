@@ -349,6 +349,30 @@ def test_handoff_timeout_is_loud(monkeypatch):
         assert max_abs_diff(got[k], want[k]) <= TOL, k
 
 
+def test_encoder_handoff_timeout_is_loud(monkeypatch):
+    """The resident encoder recurrence hands its hidden state round through flags in the workspace; a workgroup that never
+    publishes (forced: GVX_DEBUG_ENC_SKIP_BLOCK makes one of the 64 leave at once, the waits give up after a few polls) must not
+    leave numbers that look like an encoder output: every element is NaN, check_status() raises and clears the sticky word,
+    and a handle created without the knobs gives the oracle's numbers right afterwards."""
+    monkeypatch.setenv("GVX_DEBUG_ENC_SKIP_BLOCK", "5")
+    monkeypatch.setenv("GVX_HANDOFF_SPIN_LIMIT", "40")
+    bad, sd, (mc, ac, tc) = _default_model()
+    lens = [23, 17, 9]
+    tok = (gw.hashed_uniform(43, "enctmo", 3 * 23) * tc.n_tokens).astype(np.int64).reshape(3, 23)
+    out = bad.encode(torch.from_numpy(tok), torch.tensor(lens))
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all(), "the output of a timed-out encoder call must be NaN"
+    with pytest.raises(RuntimeError, match="hand-off"):
+        bad.check_status()
+    bad.check_status()
+    monkeypatch.delenv("GVX_DEBUG_ENC_SKIP_BLOCK")
+    monkeypatch.delenv("GVX_HANDOFF_SPIN_LIMIT")
+    good, _, _ = _default_model()
+    got = good.encode(torch.from_numpy(tok), torch.tensor(lens))
+    good.check_status()
+    assert max_abs_diff(got, tacotron2_ref.encoder(sd, torch.from_numpy(tok), torch.tensor(lens))) <= TOL
+
+
 def test_serialized_kernels_switch_the_resident_kernel_off(monkeypatch):
     """Under AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING the resident attention kernel and the launches it feeds could never
     overlap: a handle created in such a process runs the launch-per-step loop (same numbers, no hand-off to time out).

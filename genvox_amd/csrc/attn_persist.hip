@@ -88,6 +88,31 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
+// One WAVE waits until every one of the n (<= 128) flag words reads >= target: two words per lane per look.  Bounded like
+// handoff_wait<true>; returns false (wave-uniform) when the wait was given up, by a time-out here or anywhere else, or by the
+// host's stop word.
+__device__ __forceinline__ bool flags_wait(const unsigned* flags, int n, unsigned target, unsigned* tmo, unsigned code, unsigned limit,
+                                           const unsigned* stop) {
+    if (limit == 0u) limit = HANDOFF_SPIN_LIMIT;
+    const int lane = threadIdx.x & 63;
+    const int i0 = lane < n ? lane : 0, i1 = lane + 64 < n ? lane + 64 : 0;
+    unsigned spins = 0;
+    while (true) {
+        const unsigned v0 = __hip_atomic_load(flags + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned v1 = __hip_atomic_load(flags + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v0 >= target && v1 >= target)) return true;
+        if ((++spins & 127u) == 1u) {
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > 16u * limit) {
+                if (lane == 0) __hip_atomic_store(tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 }  // namespace
 
 // SPG: query slabs per group of 32 threads (32 groups): 3 = the 96 slabs of the teacher-forced launch, 4 = the 128 of the
@@ -101,6 +126,9 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // weights and those of the partner's 15 positions next to the cut (the halo of the location convolution) as
 // exp(e - M) / S.  Half 0 publishes the context.  The softmax equals the reference's (models/tts/tacotron2.py:126) up to
 // rounding (1e-7 relative).
+#ifdef GVX_STAMPS
+namespace { __device__ unsigned long long pa_row_stamps[64][8]; }   // per resident workgroup: the phase stamps of step 20
+#endif
 template <int SPG, bool SPLIT>
 __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersistParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -209,7 +237,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
 
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q_slab);
 #ifdef GVX_STAMPS
-#define PA_STAMP(i) do { if (t == 20) GVX_STAMP(0, i); } while (0)
+#define PA_STAMP(i) do { if (t == 20) { GVX_STAMP(0, i); if (tid == 0 && (i) < 8) pa_row_stamps[blockIdx.x & 63][i] = wall_clock64(); } } while (0)
 #else
 #define PA_STAMP(i) do { } while (0)
 #endif
@@ -220,7 +248,10 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         // adds too).  Then sum the partial slabs (fixed order)
         // A wait that returns without its word (the host has ended the loop early - autoregressive decode, every row has
         // stopped - or some wait has timed out) ends the kernel: nothing it could still compute would be used
-        if (tid == 0 && !handoff_wait<true>(cnt_q, (unsigned)t + p.q_first, tmo, 0x100u + (unsigned)b, p.spin_limit, stop)) *leave = 1;
+        if (p.q_flags) {
+            // beside the resident decoder kernel: one flag per producing workgroup (value = steps published), watched by one wave
+            if (wave == 0 && !flags_wait(p.q_flags, p.n_q_flags, (unsigned)t + 1u, tmo, 0x100u + (unsigned)b, p.spin_limit, stop) && (tid & 63) == 0) *leave = 1;
+        } else if (tid == 0 && !handoff_wait<true>(cnt_q, (unsigned)t + p.q_first, tmo, 0x100u + (unsigned)b, p.spin_limit, stop)) *leave = 1;
         __syncthreads();
         if (*leave) break;
         PA_STAMP(1);
@@ -367,7 +398,10 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        if (tid == 0 && hf == 0) __hip_atomic_fetch_add(cnt_ctx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && hf == 0) {
+            if (p.ctx_flags) __hip_atomic_store(p.ctx_flags + b, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(cnt_ctx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         PA_STAMP(5);
         // ---- off the chain: location features of step t + 1
         if (t + 1 < p.T) location_features();
@@ -412,6 +446,9 @@ hipError_t launch_handoff_set(unsigned* word, hipStream_t s) {
 }
 
 #ifdef GVX_STAMPS
+hipError_t read_row_stamps_persist(unsigned long long* host512) {
+    return hipMemcpyFromSymbol(host512, HIP_SYMBOL(pa_row_stamps), sizeof(unsigned long long) * 512);
+}
 hipError_t read_stamps_persist(unsigned long long* host96) {
     return hipMemcpyFromSymbol(host96, HIP_SYMBOL(gvx_stamps), sizeof(unsigned long long) * 96);
 }

@@ -31,6 +31,9 @@ hipError_t read_stamps_skinny(unsigned long long* host96);
 hipError_t read_stamps_attention(unsigned long long* host96);
 hipError_t read_stamps_persist(unsigned long long* host96);
 hipError_t read_wg_spans(unsigned long long* host1024);
+hipError_t read_stamps_resident(unsigned long long* host480);
+hipError_t read_wg_stamps_resident(unsigned long long* host896);
+hipError_t read_row_stamps_persist(unsigned long long* host512);
 #endif
 hipError_t skinny_init();
 hipError_t gemm_init();
@@ -143,6 +146,9 @@ struct gvx_model {
     // with two batch tiles per workgroup the fp32 matrix pipe sets the launch length (37 us per 64-row step, MFMA pipe 54 %
     // busy on the 192 CUs, round 3) and two 32-row lanes on two streams are faster (40.1 vs 44.4 us per 64-row step)
     bool tf_rows64 = false;
+    // teacher-forced loop as ONE resident weight-streaming kernel beside the resident attention kernel (dec_resident.hip):
+    // B <= 32, L <= 128, inference mode; opt-in (GVX_TF_RESIDENT=1) until it beats the launch per step
+    bool tf_resident = false;
     int pa_depth = 4;                  // GVX_PA_DEPTH=6: prefetch depth of the launch beside the resident kernel (tests, A/B runs)
     unsigned spin_limit = 0;           // GVX_HANDOFF_SPIN_LIMIT: polls before an in-launch wait gives up (0 = the built-in limit)
     bool debug_skip_resident = false;  // GVX_DEBUG_SKIP_RESIDENT=1: never launch the resident attention kernel, so that every
@@ -254,7 +260,7 @@ WsPlan make_ws_plan(const gvx_model* m, int B, int L, int T, int mode = WS_TEACH
     w.frames = take((size_t)(T + 1) * B * M);
     w.pre1 = take((size_t)(T + 1) * B * P);
     w.prenet = take((size_t)(T + 1) * B * P);
-    w.h_a = take((size_t)2 * B * A);
+    w.h_a = take((size_t)RS_HA_SLOTS * B * A);   // ping-pong of the launch-per-step loops; ring of the resident loop (dec_resident.hip)
     w.c_a = take((size_t)B * A);
     w.c_d = take((size_t)B * D);
     w.hc = take((size_t)(T + 1) * B * (D + E));
@@ -446,6 +452,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     if (const char* e = std::getenv("GVX_AR_SPLIT_H")) m->ar_split_h = e[0] != '0';
     if (const char* e = std::getenv("GVX_ENC_PERSISTENT")) m->enc_persistent = e[0] != '0';
     if (const char* e = std::getenv("GVX_TF_ROWS64")) m->tf_rows64 = e[0] == '1';
+    if (const char* e = std::getenv("GVX_TF_RESIDENT")) m->tf_resident = e[0] != '0';
     if (const char* e = std::getenv("GVX_PA_DEPTH")) m->pa_depth = std::atoi(e) == 6 ? 6 : 4;
     if (const char* e = std::getenv("GVX_HANDOFF_SPIN_LIMIT")) m->spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("GVX_DEBUG_SKIP_RESIDENT")) m->debug_skip_resident = e[0] == '1';
@@ -757,6 +764,7 @@ int gvx_model_bind_blob(gvx_model* m, const void* device_blob) {
     HIP_TRY(skinny_init());
     HIP_TRY(attention_init());
     HIP_TRY(attention_persistent_init());
+    HIP_TRY(decoder_resident_init());
     return GVX_OK;
 }
 
@@ -931,7 +939,7 @@ DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
 int decoder_init_states(gvx_model* m, const float* memory, int B, int L, const DecoderBuffers& db, hipStream_t s) {
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim;
-    HIP_TRY(zero_async(db.h_a, (size_t)2 * B * A * sizeof(float), s));
+    HIP_TRY(zero_async(db.h_a, (size_t)RS_HA_SLOTS * B * A * sizeof(float), s));
     HIP_TRY(zero_async(db.c_a, (size_t)B * A * sizeof(float), s));
     HIP_TRY(zero_async(db.c_d, (size_t)B * D * sizeof(float), s));
     HIP_TRY(zero_async(db.hc, (size_t)B * (D + E) * sizeof(float), s));  // slot 0
@@ -1139,6 +1147,8 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     const int pa_layout = attention_persistent_layout(B, L);   // 1: L <= 128 (32 CUs, 224 workgroups); 2: L <= 256 (64 CUs, 192
                                                                // workgroups); 3: 33 .. 64 rows (64 CUs, 384 workgroups, two per CU)
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
+    // ... and the LSTM launches as ONE resident kernel too (dec_resident.hip): inference mode, one batch tile, L <= 128
+    const bool resident = pa && pa_layout == 1 && m->tf_resident && !train && decoder_resident_supported(B, L);
     if (pa && !prenet_done) {   // (the fused forward has taken a side stream for this call already: the encoder ran on it)
         rc = ensure_side_stream(m);
         if (rc != GVX_OK) return rc;
@@ -1175,6 +1185,10 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         pp.ctx_base = db.hc + (size_t)B * (D + E) + (size_t)D * B; pp.ctx_ts = (long)B * (D + E);   // slot t + 1
         pp.sync = sync; pp.B = B; pp.L = L; pp.T = T; pp.kl = d.att_loc_kernel;
         pp.spin_limit = m->spin_limit; pp.q_first = 2;   // (launch 0 announces its start too)
+        if (resident) {   // beside the resident decoder kernel: flags per producer instead of the two counters
+            pp.q_flags = sync + RS_FLAG_ATT; pp.n_q_flags = pp.n_slabs;
+            pp.ctx_flags = sync + RS_FLAG_CTX;
+        }
         if (!m->debug_skip_resident) HIP_TRY(launch_attention_persistent(pp, m->pa_stream));
         HIP_TRY(hipEventRecord(m->pa_join, m->pa_stream));
         return GVX_OK;
@@ -1293,7 +1307,26 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         rc = pa_begin(s);   // (the hand-off words were zeroed at the top of this call)
         if (rc != GVX_OK) return rc;
     }
-    if (pa && pa_layout == 3) {
+    if (resident) {
+        // one launch for the whole loop: attention LSTM (t) and decoder LSTM (t) of every step, hand-offs by flags
+        DecResidentParams rp{};
+        rp.att_frag = m->dev_blob + m->blob.att_frag; rp.att_bias = m->dev_blob + m->blob.att_bias; rp.wq_t = m->dev_blob + m->blob.wq_t;
+        rp.dec_frag = m->dev_blob + m->blob.dec_frag; rp.dec_bias = m->dev_blob + m->blob.dec_bias;
+        rp.pre_gate = db.pre_gate; rp.h_a = db.h_a; rp.hc = db.hc; rp.q_slab = db.q_slab; rp.c_a = db.c_a; rp.c_d = db.c_d;
+        rp.sync = sync;
+        rp.att_frag_bytes = (unsigned)(frag_floats(4 * d.att_rnn_dim, P + E + d.att_rnn_dim) * sizeof(float));
+        rp.dec_frag_bytes = (unsigned)(frag_floats(4 * D, d.att_rnn_dim + E + D) * sizeof(float));
+        rp.B = B; rp.T = T; rp.spin_limit = m->spin_limit;
+        { static const int dbg = [] { const char* e = std::getenv("GVX_RS_DEBUG"); return e ? std::atoi(e) : 0; }(); rp.debug = dbg; }
+        if (kt) HIP_TRY(hipEventRecord(m->kev[0], s));
+        HIP_TRY(launch_decoder_resident(rp, s));
+        if (kt) {
+            HIP_TRY(hipEventRecord(m->kev[1], s));
+            HIP_TRY(hipEventRecord(m->kev[2], s));
+            m->n_lstm_ev = T; m->n_attn_ev = 0;   // (the kernel's duration over its T steps)
+        }
+        launches = 1;
+    } else if (pa && pa_layout == 3) {
         if (m->use_graph && !kt) {
             const gvx_model::LoopKey key{ws, memory, m->dev_blob, B, L, T, lengths != nullptr, 0.f, 48};
             rc = run_chunk(m, touch_graph_set(m, m->loop_graphs, key), 0, s, enqueue_loop64);
@@ -1313,7 +1346,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));
         ++launches;
     }
-    if (kt) {
+    if (kt && !resident) {
         // Per-kernel duration for the roofline figure: the launch of a mid-sequence step replayed back to back between
         // two events on this stream (bracketing every launch of the real loop with events measures launch gaps, not
         // the kernel).  The replays scribble over the recurrent state, which nobody reads after this point of an
@@ -1996,6 +2029,17 @@ int gvx_debug_read_stamps_persist(unsigned long long* host96) {
 int gvx_debug_read_wg_spans(unsigned long long* host1024) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(gvx::read_wg_spans(host1024));
+    return GVX_OK;
+}
+int gvx_debug_read_stamps_resident(unsigned long long* host480) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(gvx::read_stamps_resident(host480));
+    return GVX_OK;
+}
+int gvx_debug_read_wg_stamps_resident(unsigned long long* host896, unsigned long long* rows512) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(gvx::read_wg_stamps_resident(host896));
+    HIP_TRY(gvx::read_row_stamps_persist(rows512));
     return GVX_OK;
 }
 int gvx_debug_read_stamps(unsigned long long* host96) {

@@ -222,7 +222,39 @@ struct AttnPersistParams {
     float* xchg;                            // split kernel (L > 128): exchange buffers of the row halves, attention_persistent_xchg_floats(B)
     unsigned q_first;                       // step t waits for the query counter to reach t + q_first (teacher-forced loop: 2 -
                                             // launch 0 signals too; autoregressive loop: 1 - one signalling launch per step)
+    // beside the resident decoder kernel (dec_resident.hip): the slabs of step t are there when every one of the n_q_flags
+    // producer flags reads >= t + 1 (in place of the query counter), and row b announces its context of step t by storing
+    // t + 1 into ctx_flags[b] (in place of the context counter); nullptr otherwise
+    const unsigned* q_flags; int n_q_flags;
+    unsigned* ctx_flags;
 };
+// ---------------------------------------------------------------------------------------------
+// Teacher-forced decoder loop as ONE resident weight-streaming kernel beside the resident attention kernel (dec_resident.hip):
+// 224 workgroups keep both LSTM cells' weight streams running through the steps' hand-offs (LDS-DMA loader ring per
+// workgroup); default layer sizes, B <= 32, L <= 128.  Flag words (values = completed steps) live in the hand-off block:
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_FLAG_ATT = 6144;         // [96]  attention-LSTM workgroup i has published h_a and its query slab of steps < value
+constexpr int RS_FLAG_DEC = 6144 + 256;   // [128] decoder-LSTM workgroup i has published h_d of steps < value
+constexpr int RS_FLAG_CTX = 6144 + 512;   // [32]  attention row b has published its context of steps < value
+constexpr int RS_HA_SLOTS = 4;            // ring of h_a vectors: h_a(t) in slot (t + 1) % RS_HA_SLOTS, slot 0 = the zero state
+struct DecResidentParams {
+    const float* att_frag; const float* att_bias; const float* wq_t;   // packed [128][224][64][4], [4A] packed row order, [A/8][a][8]
+    const float* dec_frag; const float* dec_bias;                      // packed [128][320][64][4], [4D]
+    const float* pre_gate;          // [T][B][4A] Prenet columns of the attention LSTM applied to all steps (bias not included)
+    float* h_a;                     // [RS_HA_SLOTS][A/8][B][8]
+    float* hc;                      // [T+1][(D+E)/8][B][8]: slot t + 1 = [h_d(t) ; ctx(t)]
+    float* q_slab;                  // [96][B][a]
+    float* c_a; float* c_d;         // [B][A], [B][D] cell states: read at the start, written at the end
+    unsigned* sync;                 // HANDOFF_WORDS words, zeroed by the caller
+    unsigned att_frag_bytes, dec_frag_bytes;   // bounds of the loader's buffer descriptors
+    int B, T;
+    unsigned spin_limit;            // polls without progress before the poller gives up (0 = HANDOFF_SPIN_LIMIT)
+    int debug;                      // timing experiments only (GVX_RS_DEBUG; wrong results): 1 consumers ignore the gates, 2 ignore `landed`, 4 no DMA
+};
+bool decoder_resident_supported(int B, int L);
+hipError_t decoder_resident_init();
+hipError_t launch_decoder_resident(const DecResidentParams& p, hipStream_t s);
+
 bool attention_persistent_supported(int B, int L, int a, int F, int kl, int E, int att_rnn_dim, int dec_rnn_dim);
 int attention_persistent_layout(int B, int L);      // 0: not served; 1 / 2 / 3: see attn_persist.hip
 int attention_persistent_slabs(int layout);         // query slabs of the launch layout

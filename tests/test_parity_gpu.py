@@ -315,6 +315,34 @@ def _ragged_batch(mc, ac, tc, B, L, T, seed):
     return batch
 
 
+@pytest.mark.parametrize("B,L,T", [(7, 100, 33), (32, 128, 24), (1, 1, 1), (32, 5, 2), (17, 127, 9), (3, 64, 70)])
+def test_resident_decoder_equals_launch_per_step(B, L, T, monkeypatch):
+    """The teacher-forced loop as ONE resident weight-streaming kernel (dec_resident.hip: loader ring in LDS, hand-offs by
+    flags; the default for B <= 32, L <= 128) against the same loop as a launch per step (GVX_TF_RESIDENT=0: skinny.hip beside
+    the resident attention kernel).  Same tiles, K slices and summation order: the outputs must agree BIT FOR BIT, repeatably,
+    with a clear hand-off status word - and match the oracle (models/tts/tacotron2.py:365-388) within 1e-3."""
+    monkeypatch.setenv("GVX_TF_RESIDENT", "1")
+    res, sd, (mc, ac, tc) = _default_model()
+    batch = _ragged_batch(mc, ac, tc, B, L, T, seed=B + L + T)
+    out = {k: v.clone() for k, v in res.forward(batch).items()}
+    res.check_status()
+    out2 = res.forward(batch)
+    res.check_status()
+    monkeypatch.setenv("GVX_TF_RESIDENT", "0")
+    per, _, _ = _default_model()
+    ref = per.forward(batch)
+    per.check_status()
+    for k in KEYS:
+        assert torch.isfinite(out[k]).all(), k
+        assert torch.equal(out[k], out2[k]), f"{k}: two runs differ by {max_abs_diff(out[k], out2[k])}"
+        assert torch.equal(out[k], ref[k]), f"{k}: resident loop differs from the launch-per-step loop by {max_abs_diff(out[k], ref[k])}"
+    if B * T <= 300:
+        P = mc.prenet_dim
+        want = tacotron2_ref.tacotron2_forward(sd, batch, batch["prenet_keep_masks"].reshape(2, -1, P), mask_padding=True)
+        for k in KEYS:
+            assert max_abs_diff(out[k], want[k]) <= TOL, k
+
+
 def test_handoff_timeout_is_loud(monkeypatch):
     """A hand-off of the resident-attention loop that times out must not return numbers that look like results
     (round-2 verdict: the loop drained with rc 0 and wrong mels).  The time-out is forced: the resident kernel is never

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer diagnostic (GPU box): phase timestamps of the resident decoder kernel (dec_resident.hip) at decoder step 20, one
-workgroup of each kind, every consumer wave; the loader's wait totals; the attention kernel's phases of the same step.
+workgroup of each kind, every wave; the attention kernel's phases of the same step.
     python -m genvox_amd.build --stamps && GVX_LIB=libgenvox_amd_stamps.so GVX_TF_RESIDENT=1 python tools/stamps_resident.py [B] [T]"""
 import ctypes as C
 import os
@@ -37,8 +37,6 @@ for k in range(3):
         v = [buf[(k * 10 + w) * 16 + e] for e in range(10)]
         print(f"   wave {w}: " + "  ".join(f"{(x - base) * 10:6d}" for x in v))
     print("   events:  " + " | ".join(ev))
-    lo = [buf[(k * 10 + 8) * 16 + e] for e in range(3)]
-    print(f"   loader: flow-control wait {lo[0] * 10 / 1000 / T:.2f} us/step, counted-vmcnt wait {lo[1] * 10 / 1000 / T:.2f} us/step, loop {lo[2] * 10 / 1000 / T:.2f} us/step")
 pb = (C.c_ulonglong * 96)()
 assert lib.gvx_debug_read_stamps_persist(pb) == 0
 names = ["step begins", "slabs flagged + barrier", "q summed", "energies", "softmax + context partials", "context published", "location features"]

@@ -76,6 +76,8 @@ constexpr unsigned RS_WATCHDOG = 1u << 24;
 constexpr int RS_STAMP_T = 20;
 __device__ unsigned long long rs_stamps[3][10][16];
 __device__ unsigned long long rs_wg_stamps[224][4];
+__device__ unsigned long long rs_poll_log[3][64];   // [class][k]: return time of the k-th poll of block 64 during step RS_STAMP_T
+__device__ int rs_poll_n[3];
 #define RS_STAMP(ev) do { if (stamp_wg && t == RS_STAMP_T && lane == 0) rs_stamps[KIND][wave][ev] = wall_clock64(); } while (0)
 #define RS_WGSTAMP(i) do { if (t == RS_STAMP_T && tid == 0) rs_wg_stamps[bid][i] = wall_clock64(); } while (0)
 #else
@@ -89,39 +91,46 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 struct RsPoll {   // what a poll needs: the flag words, the status word, sizes
     const unsigned* f_att; const unsigned* f_dec; const unsigned* f_ctx; unsigned* tmo;
     unsigned limit; int B, T, bid;
+    int sleep;   // s_sleep units between two looks of the polling wave (GVX_RS_DEBUG experiments)
 };
 
-// One look at every producer's flag (one round trip: five lines + the status word) by the wave that holds the lock; "steps
-// everybody has published" per class by ballots (a count only moves up).  Gives up - status word, abort word, every gate open -
-// after `limit` looks in a row that moved nothing, or when anybody else has given up.
-__device__ __forceinline__ void rs_poll_once(int* ctrl, const RsPoll& q, int lane) {
-    const unsigned a0 = __hip_atomic_load(q.f_att + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned a1 = lane < 32 ? __hip_atomic_load(q.f_att + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-    const unsigned d0 = __hip_atomic_load(q.f_dec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned d1 = __hip_atomic_load(q.f_dec + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned c0 = lane < q.B ? __hip_atomic_load(q.f_ctx + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-    const unsigned t0 = __hip_atomic_load(q.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned va = min(a0, a1), vd = min(d0, d1);
+// One look at the flags of ONE producer class (the class whose word the caller waits for: fewer loads on the hot lines) by the wave
+// that holds the lock; "steps everybody has published" by ballots (a count only moves up).  Every 16th fruitless look also reads the
+// call's status word.  Gives up - status word, abort word - after `limit` looks in a row that moved nothing, or when anybody else has.
+__device__ __forceinline__ void rs_poll_once(int* ctrl, const RsPoll& q, int lane, int word) {
+    unsigned v;
+    if (word == RC_HA) {
+        const unsigned a0 = __hip_atomic_load(q.f_att + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned a1 = lane < 32 ? __hip_atomic_load(q.f_att + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        v = min(a0, a1);
+    } else if (word == RC_HD) {
+        const unsigned d0 = __hip_atomic_load(q.f_dec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned d1 = __hip_atomic_load(q.f_dec + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = min(d0, d1);
+    } else {
+        v = lane < q.B ? __hip_atomic_load(q.f_ctx + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: nothing below moves above the loads
+#ifdef GVX_STAMPS
+    if (q.bid == 64 && lane == 0 && __hip_atomic_load(ctrl + RC_HA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == RS_STAMP_T + (word == RC_HA ? 0 : 1)) {
+        const int cls = word == RC_HA ? 0 : (word == RC_CTX ? 1 : 2);
+        const int k = rs_poll_n[cls];
+        if (k < 64) { rs_poll_log[cls][k] = (wall_clock64() << 8) | (v & 0xff); rs_poll_n[cls] = k + 1; }
+    }
+#endif
     const unsigned Tu = (unsigned)q.T;
-    const unsigned sa = (unsigned)__hip_atomic_load(ctrl + RC_HA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const unsigned sc = (unsigned)__hip_atomic_load(ctrl + RC_CTX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const unsigned sd = (unsigned)__hip_atomic_load(ctrl + RC_HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    unsigned na = sa, nc = sc, nd = sd;
-    while (na < Tu && __all(va > na)) ++na;
-    while (nc < Tu && __all(c0 > nc)) ++nc;
-    while (nd < Tu && __all(vd > nd)) ++nd;
-    const bool progress = na != sa || nc != sc || nd != sd;
+    const unsigned s0 = (unsigned)__hip_atomic_load(ctrl + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned n = s0;
+    while (n < Tu && __all(v > n)) ++n;
     int idle = 0;
     if (lane == 0) {
-        if (nc != sc) __hip_atomic_store(ctrl + RC_CTX, (int)nc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (na != sa) __hip_atomic_store(ctrl + RC_HA, (int)na, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (nd != sd) __hip_atomic_store(ctrl + RC_HD, (int)nd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        idle = progress ? 0 : __hip_atomic_load(ctrl + RC_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+        if (n != s0) __hip_atomic_store(ctrl + word, (int)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        idle = n != s0 ? 0 : __hip_atomic_load(ctrl + RC_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
         __hip_atomic_store(ctrl + RC_IDLE, idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     idle = __builtin_amdgcn_readfirstlane(idle);
-    bool give_up = __builtin_amdgcn_readfirstlane(t0) != 0u;   // somebody else (a workgroup of this kernel or the attention kernel) has timed out
+    if (idle == 0 || (idle & 15) != 0) return;
+    bool give_up = __hip_atomic_load(q.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // somebody else has timed out (wave-uniform address)
     if ((unsigned)idle > q.limit) {
         if (lane == 0) __hip_atomic_store(q.tmo, 0x500u + (unsigned)(q.bid & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         give_up = true;
@@ -140,8 +149,10 @@ __device__ __forceinline__ void rs_gate(int* ctrl, int word, int need, const RsP
             got = __hip_atomic_compare_exchange_strong(ctrl + RC_LOCK, &expect, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
         }
         if (__builtin_amdgcn_readfirstlane(got)) {
-            rs_poll_once(ctrl, q, lane);
+            rs_poll_once(ctrl, q, lane, word);
             if (lane == 0) __hip_atomic_store(ctrl + RC_LOCK, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (q.sleep == 8) __builtin_amdgcn_s_sleep(8);
+            else if (q.sleep == 32) __builtin_amdgcn_s_sleep(32);
         } else {
             __builtin_amdgcn_s_sleep(1);
         }
@@ -201,8 +212,10 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
     const int B = p.B, T = p.T;
     const unsigned blkb = (unsigned)B * 32u;   // bytes per k-group of a blocked vector
     unsigned* const tmo_w = p.sync + HANDOFF_TIMEOUT;
-    const RsPoll poll{p.sync + RS_FLAG_ATT, p.sync + RS_FLAG_DEC, p.sync + RS_FLAG_CTX, tmo_w,
-                      (p.spin_limit ? p.spin_limit : HANDOFF_SPIN_LIMIT) * 8u, B, T, bid};
+    const int rep = bid % RS_REP;   // the flag replica this workgroup reads
+    const RsPoll poll{p.sync + RS_FLAG_ATT + rep * 128, p.sync + RS_FLAG_DEC + rep * 128, p.sync + RS_FLAG_CTX + rep * 32, tmo_w,
+                      (p.spin_limit ? p.spin_limit : HANDOFF_SPIN_LIMIT) * 16u, B, T, bid,
+                      (!ATT && (p.debug & 16)) ? 32 : ((p.debug & 8) ? 8 : 0)};
     const int bl = lane & 31, h = lane >> 5;
     const bool x_mine = ((lane >> 4) & 1) == xhalf;
     const int mlane = x_mine ? lane : (lane ^ 16);   // the lane whose half-tile fragment this lane multiplies with
@@ -321,7 +334,11 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         // behind RC_CTX >= t + 1 (decoder LSTM)
         {
             const float* xsrc = p.hc + (long)(ATT ? t : t + 1) * B * (RS_D + RS_E) + (long)RS_D * B + (long)(8 * wave) * B * 8;
-            rs_gate(ctrl, RC_CTX, ATT ? t : t + 1, poll, lane);
+            // (decoder LSTM: "every attention-LSTM workgroup has published step t + 1" implies ctx(t) - they consumed it - and keeps
+            // its 128 workgroups off the context flags' line, which the step's chain waits on; the last step has no successor)
+            if (ATT) rs_gate(ctrl, RC_CTX, t, poll, lane);
+            else if (t + 2 <= T) rs_gate(ctrl, RC_HA, t + 2, poll, lane);
+            else rs_gate(ctrl, RC_CTX, t + 1, poll, lane);
             RS_STAMP(3);
             RS_WGSTAMP(2);
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(xsrc);
@@ -452,7 +469,8 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         RS_STAMP(8);
         rs_cbar(ctrl, nbar, el, tmo_w);
         RS_STAMP(9);
-        if (tid == 0) __hip_atomic_store(p.sync + (ATT ? RS_FLAG_ATT + bid : RS_FLAG_DEC + (bid - 96)), (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // one wave instruction: lane r stores the workgroup's flag into replica r
+        if (tid < RS_REP) __hip_atomic_store(p.sync + (ATT ? RS_FLAG_ATT + bid : RS_FLAG_DEC + (bid - 96)) + tid * 128, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         RS_WGSTAMP(3);
     }
     // final cell states (the launch-per-step loop keeps them in memory; callers that continue a sequence read them there)
@@ -477,6 +495,14 @@ hipError_t read_stamps_resident(unsigned long long* host480) {
 }
 hipError_t read_wg_stamps_resident(unsigned long long* host896) {
     return hipMemcpyFromSymbol(host896, HIP_SYMBOL(rs_wg_stamps), sizeof(unsigned long long) * 896);
+}
+hipError_t read_poll_log_resident(unsigned long long* host192, int* n3) {
+    hipError_t e = hipMemcpyFromSymbol(host192, HIP_SYMBOL(rs_poll_log), sizeof(unsigned long long) * 192);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(n3, HIP_SYMBOL(rs_poll_n), sizeof(int) * 3);
+    if (e != hipSuccess) return e;
+    const int z[3] = {0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(rs_poll_n), z, sizeof z);
 }
 #endif
 

@@ -33,6 +33,7 @@ hipError_t read_stamps_persist(unsigned long long* host96);
 hipError_t read_wg_spans(unsigned long long* host1024);
 hipError_t read_stamps_resident(unsigned long long* host480);
 hipError_t read_wg_stamps_resident(unsigned long long* host896);
+hipError_t read_poll_log_resident(unsigned long long* host192, int* n3);
 hipError_t read_row_stamps_persist(unsigned long long* host512);
 #endif
 hipError_t skinny_init();
@@ -147,8 +148,8 @@ struct gvx_model {
     // busy on the 192 CUs, round 3) and two 32-row lanes on two streams are faster (40.1 vs 44.4 us per 64-row step)
     bool tf_rows64 = false;
     // teacher-forced loop as ONE resident weight-streaming kernel beside the resident attention kernel (dec_resident.hip):
-    // B <= 32, L <= 128, inference mode; opt-in (GVX_TF_RESIDENT=1) until it beats the launch per step
-    bool tf_resident = false;
+    // B <= 32, L <= 128, inference mode; GVX_TF_RESIDENT=0 keeps the launch per step
+    bool tf_resident = true;
     int pa_depth = 4;                  // GVX_PA_DEPTH=6: prefetch depth of the launch beside the resident kernel (tests, A/B runs)
     unsigned spin_limit = 0;           // GVX_HANDOFF_SPIN_LIMIT: polls before an in-launch wait gives up (0 = the built-in limit)
     bool debug_skip_resident = false;  // GVX_DEBUG_SKIP_RESIDENT=1: never launch the resident attention kernel, so that every
@@ -1186,8 +1187,9 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         pp.sync = sync; pp.B = B; pp.L = L; pp.T = T; pp.kl = d.att_loc_kernel;
         pp.spin_limit = m->spin_limit; pp.q_first = 2;   // (launch 0 announces its start too)
         if (resident) {   // beside the resident decoder kernel: flags per producer instead of the two counters
-            pp.q_flags = sync + RS_FLAG_ATT; pp.n_q_flags = pp.n_slabs;
+            pp.q_flags = sync + RS_FLAG_ATT; pp.n_q_flags = pp.n_slabs;   // (row b polls replica b % RS_REP: attn_persist.hip)
             pp.ctx_flags = sync + RS_FLAG_CTX;
+            { static const int dbg = [] { const char* e = std::getenv("GVX_RS_DEBUG"); return e ? std::atoi(e) : 0; }(); pp.debug = dbg; }
         }
         if (!m->debug_skip_resident) HIP_TRY(launch_attention_persistent(pp, m->pa_stream));
         HIP_TRY(hipEventRecord(m->pa_join, m->pa_stream));
@@ -1481,6 +1483,12 @@ int gvx_teacher_forced_rows_per_call(const gvx_model* m, int L) {
 int gvx_teacher_forced_resident(const gvx_model* m, int B, int L) {
     if (!m || B < 1 || L < 1) return 0;
     return persistent_path(m, B, L) ? 1 : 0;
+}
+
+int gvx_teacher_forced_loop_kind(const gvx_model* m, int B, int L) {
+    if (!m || B < 1 || L < 1) return 0;
+    if (!persistent_path(m, B, L)) return 0;
+    return m->tf_resident && attention_persistent_layout(B, L) == 1 && decoder_resident_supported(B, L) ? 2 : 1;
 }
 
 int gvx_model_set_persistent_attention(gvx_model* m, int enable) {
@@ -2040,6 +2048,11 @@ int gvx_debug_read_wg_stamps_resident(unsigned long long* host896, unsigned long
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(gvx::read_wg_stamps_resident(host896));
     HIP_TRY(gvx::read_row_stamps_persist(rows512));
+    return GVX_OK;
+}
+int gvx_debug_read_poll_log_resident(unsigned long long* host192, int* n3) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(gvx::read_poll_log_resident(host192, n3));
     return GVX_OK;
 }
 int gvx_debug_read_stamps(unsigned long long* host96) {

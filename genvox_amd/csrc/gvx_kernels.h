@@ -208,7 +208,7 @@ bool attention_supported(int L, int a, int F, int kl, int E);
 constexpr int HANDOFF_CNT_Q = 0, HANDOFF_CNT_CTX = 1024, HANDOFF_READY = 2048, HANDOFF_TIMEOUT = 3072;
 constexpr int HANDOFF_STOP = 3072 + 512;   // the host's "the loop has ended early" word (autoregressive decode): the resident kernel leaves
 constexpr int HANDOFF_PAIR = 4096;   // split resident kernel: flag word of half hf of row b at HANDOFF_PAIR + (2 b + hf) * 32
-constexpr int HANDOFF_WORDS = 8192;
+constexpr int HANDOFF_WORDS = 18432;   // (the last 10240: flag replicas of the resident decoder loop, RS_FLAG_* below)
 constexpr unsigned HANDOFF_SPIN_LIMIT = 200000u;   // polls with ~2 us of s_sleep between them (a few hundred ms), then the wait gives up
 struct AttnPersistParams {
     const float* q_slab; int n_slabs;       // [n_slabs][B][a], rewritten (sc1) by the attention-LSTM tiles every step
@@ -225,17 +225,24 @@ struct AttnPersistParams {
     // beside the resident decoder kernel (dec_resident.hip): the slabs of step t are there when every one of the n_q_flags
     // producer flags reads >= t + 1 (in place of the query counter), and row b announces its context of step t by storing
     // t + 1 into ctx_flags[b] (in place of the context counter); nullptr otherwise
-    const unsigned* q_flags; int n_q_flags;
-    unsigned* ctx_flags;
+    const unsigned* q_flags; int n_q_flags;   // this row's replica of the producers' flags
+    unsigned* ctx_flags;                      // replica r of row b's flag at ctx_flags[r * 32 + b], r < RS_REP
+    int debug;   // timing experiments (GVX_RS_DEBUG & 32: no sleep between looks at the flags)
 };
 // ---------------------------------------------------------------------------------------------
 // Teacher-forced decoder loop as ONE resident weight-streaming kernel beside the resident attention kernel (dec_resident.hip):
 // 224 workgroups keep both LSTM cells' weight streams running through the steps' hand-offs (LDS-DMA loader ring per
 // workgroup); default layer sizes, B <= 32, L <= 128.  Flag words (values = completed steps) live in the hand-off block:
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_FLAG_ATT = 6144;         // [96]  attention-LSTM workgroup i has published h_a and its query slab of steps < value
-constexpr int RS_FLAG_DEC = 6144 + 256;   // [128] decoder-LSTM workgroup i has published h_d of steps < value
-constexpr int RS_FLAG_CTX = 6144 + 512;   // [32]  attention row b has published its context of steps < value
+// Every flag exists in RS_REP replicas on lines of their own: operations on one line are served one after the other at the memory
+// side (~15 ns each), so 224 workgroups polling the line that the producers are storing into took 2.5 us per look (round 4,
+// profiles/r04_stamps_resident_stationary_v1.txt).  A producer stores its flag into every replica with ONE wave instruction (lane r
+// -> replica r); a reader polls the replica of its index modulo RS_REP: 7 readers per line.
+constexpr int RS_REP = 32;
+constexpr int RS_FLAG_ATT = 8192;                        // [RS_REP][128] attention-LSTM workgroup i (< 96) has published h_a and its query slab of steps < value
+constexpr int RS_FLAG_DEC = RS_FLAG_ATT + RS_REP * 128;  // [RS_REP][128] decoder-LSTM workgroup i has published h_d of steps < value
+constexpr int RS_FLAG_CTX = RS_FLAG_DEC + RS_REP * 128;  // [RS_REP][32]  attention row b has published its context of steps < value
+static_assert(RS_FLAG_CTX + RS_REP * 32 <= HANDOFF_WORDS, "flag replicas inside the hand-off block");
 constexpr int RS_HA_SLOTS = 4;            // ring of h_a vectors: h_a(t) in slot (t + 1) % RS_HA_SLOTS, slot 0 = the zero state
 struct DecResidentParams {
     const float* att_frag; const float* att_bias; const float* wq_t;   // packed [128][224][64][4], [4A] packed row order, [A/8][a][8]

@@ -307,6 +307,13 @@ class Tacotron2(nn.Module):
         self._ensure_packed()
         _lib.check(_lib.load().gvx_kernel_timing_enable(self._handle, int(enable)))
 
+    def loop_kind(self, B: int, L: int) -> int:
+        """How a teacher-forced inference call of this shape runs its decoder loop (gvx_teacher_forced_loop_kind): 2 = one resident
+        weight-stationary kernel, 1 = a weight-streaming launch per step beside the resident attention kernel, 0 = a launch pair
+        per step."""
+        self._ensure_packed()
+        return int(_lib.load().gvx_teacher_forced_loop_kind(self._handle, B, L))
+
     def kernel_times_ms(self):
         a, b, n = C.c_float(), C.c_float(), C.c_int()
         _lib.check(_lib.load().gvx_kernel_times_ms(self._handle, C.byref(a), C.byref(b), C.byref(n)))

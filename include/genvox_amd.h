@@ -134,6 +134,12 @@ int gvx_teacher_forced_rows_per_call(const gvx_model* model, int L);
  * concurrent lanes of launch-per-step loops), 0 if it takes a launch per attention step (chunks then gain from two streams). */
 int gvx_teacher_forced_resident(const gvx_model* model, int B, int L);
 
+/* How the decoder loop of a teacher-forced inference call with B rows of L tokens runs (models/tts/tacotron2.py:365-388):
+ * 2 = ONE resident weight-stationary kernel for all T steps beside the resident attention kernel (dec_resident.hip: default layer
+ *     sizes, B <= 32, L <= 128; the LSTM matrices stay in registers and LDS, hand-offs by flags),
+ * 1 = one weight-streaming launch per step beside the resident attention kernel, 0 = a launch pair per step. */
+int gvx_teacher_forced_loop_kind(const gvx_model* model, int B, int L);
+
 /* ---- Encoder: embedding + conv/BN/relu stack + BiLSTM with packed-sequence semantics.
  * Replaces nn.Embedding + Encoder.forward / Encoder.inference (models/tts/tacotron2.py:459,
  * :231-246, :248-256).  tokens: int64 [B, L]; lengths: int32 [B] or NULL (= all L);

@@ -321,7 +321,6 @@ def test_resident_decoder_equals_launch_per_step(B, L, T, monkeypatch):
     flags; the default for B <= 32, L <= 128) against the same loop as a launch per step (GVX_TF_RESIDENT=0: skinny.hip beside
     the resident attention kernel).  Same tiles, K slices and summation order: the outputs must agree BIT FOR BIT, repeatably,
     with a clear hand-off status word - and match the oracle (models/tts/tacotron2.py:365-388) within 1e-3."""
-    monkeypatch.setenv("GVX_TF_RESIDENT", "1")
     res, sd, (mc, ac, tc) = _default_model()
     batch = _ragged_batch(mc, ac, tc, B, L, T, seed=B + L + T)
     out = {k: v.clone() for k, v in res.forward(batch).items()}

@@ -23,6 +23,9 @@ Rank 0 prints ONE JSON line.
                 boundaries) taken from HIP events recorded around the decoder loop INSIDE the timed region.  `traffic` is
                 null here: HBM bytes come from separate rocprofv3 --pmc passes (profiles/README.md), never from a file.
   cpu_baseline  the oracle (CPU restatement of the reference) on the host cores, bounded sample of the same workload.
+                Every timed forward is `forward(batch, strict=False)`: the mirror's default (strict=True) synchronises after each
+                call to look at the hand-off status; here nothing may synchronise inside the timed region, and the status is
+                checked right after it instead (next entry).
   validated     the run checks what it times: device status words after the timed region and after every leg (a hand-off
                 time-out or a bad token id fails the run), and the last timed forward must equal an un-timed run with the
                 same Prenet-mask seed bit for bit.
@@ -218,17 +221,17 @@ def main():
     # the same outputs bit for bit (fixed reduction orders everywhere); the oracle pins this path in tests/, not here.
     VALID_SEED = 1234567 + rank
     torch.manual_seed(VALID_SEED)
-    ref = {k: v.clone() for k, v in model.forward(batch).items()}
+    ref = {k: v.clone() for k, v in model.forward(batch, strict=False).items()}
     model.check_status()
     for _ in range(max(args.warmup, 0)):
-        model.forward(batch)
+        model.forward(batch, strict=False)
     sync_all()
     log("timed region")
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - 1:
             torch.manual_seed(VALID_SEED)
-        out = model.forward(batch)
+        out = model.forward(batch, strict=False)
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -246,7 +249,7 @@ def main():
     def lstm_roofline(m, b, batch_b, loop_ms):
         """Roofline of the decoder loop's dominant kernel at batch b (instrumented pass, see module docstring)."""
         m.enable_kernel_timing(True)
-        m.forward(batch_b)
+        m.forward(batch_b, strict=False)
         torch.cuda.synchronize()
         kt = m.kernel_times_ms()
         m.enable_kernel_timing(False)
@@ -375,7 +378,7 @@ def main():
             log("extra: teacher-forced single utterance, 1 x 568 frames, 100 tokens")
             L1, T1 = 100, 568
             c1 = {k: torch.from_numpy(v).to(dev) for k, v in gw.synthetic_inputs(1, L1, T1, tc.n_tokens, ac.n_mels, seed=3).items()}
-            dt = timed(torch, lambda: model.forward(c1), 2, args.steps)
+            dt = timed(torch, lambda: model.forward(c1, strict=False), 2, args.steps)
             model.check_status()
             e = {"ms_per_utterance": round(dt * 1e3, 3), "mel_frames_per_s": round(T1 / dt, 1),
                  "rtf": round(dt / (T1 * audio_s_per_frame), 6), "steps": args.steps,
@@ -394,7 +397,7 @@ def main():
             log("extra: teacher-forced batch 64 x 800")
             b64 = {k: torch.from_numpy(v).to(dev) for k, v in gw.synthetic_inputs(64, L, T, tc.n_tokens, ac.n_mels, seed=3).items()}
             model.enable_stage_timing(True)
-            dt = timed(torch, lambda: model.forward(b64), 2, args.steps)
+            dt = timed(torch, lambda: model.forward(b64, strict=False), 2, args.steps)
             model.check_status()
             lanes = getattr(model, "last_forward_lanes", False)
             st64, _ = model.stage_times_ms(lane=0 if lanes else None)

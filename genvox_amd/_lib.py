@@ -104,6 +104,7 @@ SIGNATURES = {
     "gvx_wav_finalize": (_i, [_vp, _i, C.c_long, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _i, _vp, _vp, _vp]),
     "gvx_kernel_timing_enable": (_i, [_vp, _i]),
     "gvx_model_set_persistent_attention": (_i, [_vp, _i]),
+    "gvx_model_set_resident_kernels": (_i, [_vp, _i]),
     "gvx_teacher_forced_rows_per_call": (_i, [_vp, _i]),
     "gvx_teacher_forced_resident": (_i, [_vp, _i, _i]),
     "gvx_teacher_forced_loop_kind": (_i, [_vp, _i, _i]),

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgenvox_amd.so")
-SOURCES = ["gemm_f32.hip", "gemm_bx3.hip", "skinny.hip", "dec_resident.hip", "attention.hip", "attn_persist.hip", "misc.hip", "griffinlim.hip", "train.hip", "gvx_api.hip"]
+SOURCES = ["gemm_f32.hip", "skinny.hip", "dec_resident.hip", "attention.hip", "attn_persist.hip", "misc.hip", "griffinlim.hip", "train.hip", "gvx_api.hip"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

@@ -28,10 +28,11 @@ namespace gvx {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int BK = 32;
-// gemm_bx3.hip: the same products on the bf16 matrix pipe through an exact three-way split of every fp32 operand
-hipError_t launch_gemm_bx3(const GemmParams& p, hipStream_t s);
-bool gemm_bx3_serves(const GemmParams& p);
-hipError_t gemm_bx3_init();
+// (Rounds 1-3 carried a second version of these products on the bf16 matrix pipe - every fp32 operand split exactly into three bf16
+// pieces, six v_mfma_f32_32x32x16_bf16 per 16 k - which was 19 % faster on the Postnet and parity-green.  Retired in round 4: the
+// double-rate 16-bit MFMA forms of gfx950 corrupt fp32 kernels that run on the SAME OR A NEIGHBOURING CU at the same time
+// (tools/micro/mfma_bf16_neighbour.hip, profiles/r04_mfma_bf16_neighbour_cumask.txt: 0 wrong words on disjoint halves of the CU
+// mask, thousands on shared or interleaved CUs), and a library cannot choose its neighbours on the chip.)
 constexpr int LDS_LD = 36;
 
 __device__ __forceinline__ long row_off(const RowMap& m, int row) {
@@ -269,9 +270,7 @@ static hipError_t init_cfg() {
 }
 
 hipError_t gemm_init() {
-    hipError_t e = gemm_bx3_init();
-    if (e != hipSuccess) return e;
-    e = init_cfg<2, 2, 2, 2>();
+    hipError_t e = init_cfg<2, 2, 2, 2>();
     if (e != hipSuccess) return e;
     e = init_cfg<2, 2, 1, 2>();
     if (e != hipSuccess) return e;
@@ -297,15 +296,8 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-static bool bx3_enabled() {   // GVX_GEMM_BX3=1: dense products on the bf16 matrix pipe (opt-in, see gemm_bx3.hip)
-    static const bool on = [] { const char* e = std::getenv("GVX_GEMM_BX3"); return e && e[0] == '1'; }();
-    return on;
-}
-
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
-    static const int bx3_min_rows = [] { const char* e = std::getenv("GVX_GEMM_BX3_MINROWS"); return e ? std::atoi(e) : 0; }();   // (diagnostics)
-    if (bx3_enabled() && p.M >= bx3_min_rows && gemm_bx3_serves(p)) return launch_gemm_bx3(p, s);
     if (p.kmajor) {   // K-major operands (weight gradients): the two square-ish tile shapes only, any K; 16-byte pieces along m / n
         if ((p.M & 3) || (p.N & 3) || p.M < 4 || p.N < 4 || ((p.amap.s0 | p.amap.s1 | p.wmap.s0 | p.wmap.s1) & 3)) return hipErrorInvalidValue;
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);

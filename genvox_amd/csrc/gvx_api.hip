@@ -1039,6 +1039,33 @@ struct SidePool { hipStream_t s[2] = {nullptr, nullptr}; unsigned next = 0; };
 std::mutex g_pool_mutex;
 std::unordered_map<int, SidePool> g_side_pools;
 
+// Resident loops take turns on a device.  A loop whose kernels wait for each other (the resident attention kernel beside LSTM
+// launches, or beside the resident decoder kernel: 32 + 224 workgroups that must ALL be on the chip) cannot share the chip with a
+// second one: dispatched at the same time from two streams, each could get half of its workgroups a CU and both would spin
+// until their limits.  So every such loop is enqueued under this mutex, behind an event the previous one recorded at its join -
+// ordering on the device, no host wait - and its kernels reach the shared side stream in turn order.
+struct ResidentTurn { hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned n = 0; };
+std::mutex g_turn_mutex;
+std::unordered_map<int, ResidentTurn> g_turns;
+
+int turn_begin(hipStream_t s) {   // caller holds g_turn_mutex
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    ResidentTurn& t = g_turns[dev];
+    if (!t.ev[0])
+        for (auto& e : t.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (t.n > 0) HIP_TRY(hipStreamWaitEvent(s, t.ev[(t.n - 1) & 3], 0));
+    return GVX_OK;
+}
+int turn_end(hipStream_t s) {     // caller holds g_turn_mutex
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    ResidentTurn& t = g_turns[dev];
+    HIP_TRY(hipEventRecord(t.ev[t.n & 3], s));
+    ++t.n;
+    return GVX_OK;
+}
+
 int ensure_side_stream(gvx_model* m) {
     if (!m->pa_fork) {
         HIP_TRY(hipEventCreateWithFlags(&m->pa_fork, hipEventDisableTiming));
@@ -1305,7 +1332,11 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         }
         return GVX_OK;
     };
+    std::unique_lock<std::mutex> turn;   // held while the loop is enqueued (released on every return path)
     if (pa) {
+        turn = std::unique_lock<std::mutex>(g_turn_mutex);
+        rc = turn_begin(s);
+        if (rc != GVX_OK) return rc;
         rc = pa_begin(s);   // (the hand-off words were zeroed at the top of this call)
         if (rc != GVX_OK) return rc;
     }
@@ -1347,6 +1378,9 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     if (pa) {
         HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));
         ++launches;
+        rc = turn_end(s);
+        if (rc != GVX_OK) return rc;
+        turn.unlock();
     }
     if (kt && !resident) {
         // Per-kernel duration for the roofline figure: the launch of a mid-sequence step replayed back to back between
@@ -1494,6 +1528,13 @@ int gvx_teacher_forced_loop_kind(const gvx_model* m, int B, int L) {
 int gvx_model_set_persistent_attention(gvx_model* m, int enable) {
     if (!m) return fail(GVX_ERR_INVALID_ARG, "null argument");
     m->attn_persistent = enable != 0;
+    return GVX_OK;
+}
+
+int gvx_model_set_resident_kernels(gvx_model* m, int enable) {
+    if (!m) return fail(GVX_ERR_INVALID_ARG, "null argument");
+    m->attn_persistent = m->enc_persistent = m->tf_resident = enable != 0;
+    if (!enable) m->ar_resident = false;
     return GVX_OK;
 }
 

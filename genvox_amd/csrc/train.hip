@@ -12,6 +12,7 @@
 // elementwise.  Correctness first: these kernels are not tuned (the slice exists to pin the training semantics).
 #include "../../include/genvox_amd.h"
 #include "gvx_kernels.h"
+#include <cmath>
 
 #include <cstdio>
 #include <cstring>
@@ -598,7 +599,8 @@ size_t gvx_train_sqnorm_scratch_bytes(int n_tensors) { return n_tensors < 1 ? 0 
 int gvx_train_adam_step_many(const gvx_adam_ref* refs_device, int n_tensors, float grad_scale, float lr, float weight_decay, float beta1,
                              float beta2, float eps, int step, void* stream) {
     if (!refs_device || n_tensors < 1 || step < 1) return tfail(GVX_ERR_INVALID_ARG, "adam_step_many: bad argument");
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    // (bias corrections in double, as torch.optim.Adam computes them in Python: 1 - 0.999f in fp32 is 1.3e-5 off at step 1)
+    const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step)), bc2s = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adam_many_kernel, dim3(128, n_tensors), dim3(256), 0, (hipStream_t)stream, refs_device, grad_scale, lr, weight_decay, beta1, beta2,
                        eps, bc1, bc2s);
     TR_TRY(hipGetLastError());

@@ -78,8 +78,8 @@ def gather_mels(mel: torch.Tensor, mel_lengths: torch.Tensor, t_max: int) -> Lis
     rank, world = _world_info()
     pad = torch.zeros(mel.shape[0], mel.shape[1], t_max, dtype=mel.dtype, device=mel.device)
     pad[:, :, : mel.shape[2]] = mel
-    if world == 1:
-        return [pad]
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return [pad]   # (an initialised one-rank group still runs the collectives: the RCCL path is then exercised end to end)
     sizes = [torch.zeros(1, dtype=torch.long, device=mel.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([mel.shape[0]], device=mel.device))
     bmax = int(max(int(s.item()) for s in sizes))

@@ -7,12 +7,16 @@ tree, and ``forward`` / ``inference`` hand device pointers to the HIP library th
 (include/genvox_amd.h).  PyTorch is used for allocation, streams and the user-visible tensors only.
 
 Differences from the reference, on purpose:
-  * inference only: no autograd through ``forward`` (training is out of scope, SURVEY.md section 8);
+  * no autograd: ``forward`` builds no graph in either mode; the training step (``train_step``)
+    runs an explicit backward through the whole model (genvox_amd/training.py);
   * the Prenet's always-on dropout (tacotron2.py:143) takes explicit keep masks when the caller
     supplies ``batch["prenet_keep_masks"]`` (parity tests); otherwise masks are drawn on the device
     from a seed taken from torch's RNG, so ``torch.manual_seed`` still makes runs repeatable;
   * ``inference`` accepts a batch (the reference is batch-1 only, tacotron2.py:405) and then also
-    returns ``mel_lengths``.
+    returns ``mel_lengths``;
+  * ``forward(batch, strict=True)`` synchronises once per call to make sure the call's in-launch hand-offs all happened, and
+    runs the call again on the launch-per-step kernels if they did not (``strict=False``: fully asynchronous; a timed-out
+    call then returns NaN in every output and ``check_status()`` raises).
 """
 from __future__ import annotations
 
@@ -95,6 +99,9 @@ class Tacotron2(nn.Module):
         self._lane_streams = None
         self._lane_handles = [None, None]   # autoregressive lanes run on host threads: one C-ABI handle each (same blob)
         self._timing = False
+        self._sticky_bad = False        # host-side copies of the device status words (a replaced workspace takes its words with it)
+        self._sticky_stalled = False
+        self._resident_off = False      # a hand-off timed out once: this model runs on the launch-per-step kernels from then on
         self.eval()
 
     # child() for the root, which is not a _Node
@@ -229,9 +236,16 @@ class Tacotron2(nn.Module):
         self._packed_key = self._weights_key()
 
     def _get_workspace(self, B: int, L: int, T: int) -> torch.Tensor:
-        need = _lib.load().gvx_workspace_bytes(self._handle, B, L, T)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != self._device():
-            self._workspace = self._new_workspace(need, self._device())
+        return self._workspace_of(_lib.load().gvx_workspace_bytes(self._handle, B, L, T))
+
+    def _workspace_of(self, need: int) -> torch.Tensor:
+        """The main workspace, grown to `need` bytes.  The status words live at its front: before a workspace is replaced they
+        are read into the host-side sticky flags, so that an error raised by an earlier call survives until somebody looks."""
+        dev = self._device()
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            if self._workspace is not None:
+                self._poll_status()
+            self._workspace = self._new_workspace(need, dev)
         return self._workspace
 
     def _stream(self) -> int:
@@ -245,24 +259,51 @@ class Tacotron2(nn.Module):
         ws[:65536].zero_()
         return ws
 
-    def check_status(self) -> None:
-        """Read and clear the sticky device-side status words of every call since the last check (synchronises the stream):
-        raises IndexError for a token id outside the embedding table, which is what nn.Embedding does in the reference
-        (models/tts/tacotron2.py:459), RuntimeError when an in-launch hand-off of a teacher-forced loop timed out (that
-        call's outputs are all NaN, so they cannot be mistaken for results even without this check).
-        Not called by forward() - it costs a synchronisation; one check after a batch of calls is enough."""
+    def _poll_status(self) -> None:
+        """Read and clear the device status words of every workspace into the host-side sticky flags (synchronises the stream)."""
         out = (C.c_int32 * 2)()
-        bad = stalled = False
         for ws in [self._workspace] + self._lane_ws:
             if ws is None:
                 continue
             _lib.check(_lib.load().gvx_workspace_status(self._handle, ws.data_ptr(), ws.numel(), self._stream(), out))
-            bad |= bool(out[0])
-            stalled |= bool(out[1])
+            self._sticky_bad |= bool(out[0])
+            self._sticky_stalled |= bool(out[1])
+
+    def check_status(self) -> None:
+        """Report and clear the sticky status of every call since the last check (synchronises the stream): raises IndexError
+        for a token id outside the embedding table, which is what nn.Embedding does in the reference
+        (models/tts/tacotron2.py:459), RuntimeError when an in-launch hand-off of a resident loop timed out (that call's
+        outputs are all NaN, so they cannot be mistaken for results even without this check).
+        ``forward(strict=False)`` does not call it - it costs a synchronisation; one check after a batch of calls is enough."""
+        self._poll_status()
+        bad, stalled = self._sticky_bad, self._sticky_stalled
+        self._sticky_bad = self._sticky_stalled = False
         if stalled:
             raise RuntimeError("genvox_amd: an in-launch hand-off of the decoder loop timed out; the last outputs are invalid")
         if bad:
             raise IndexError("genvox_amd: token id outside [0, n_tokens)")
+
+    def _stalled_once(self) -> bool:
+        """After a call that has been synchronised: did one of its in-launch hand-offs time out?  If so - the resident kernels
+        could not run at the same time here (CU masking, a serialising profiler, a co-tenant on the GPU) - this model switches
+        to the launch-per-step kernels for good (gvx_model_set_resident_kernels; same results, no kernel waits for another
+        one) and the caller runs the call again.  A second time-out in a row cannot happen on that path."""
+        self._poll_status()
+        if not self._sticky_stalled:
+            return False
+        self._sticky_stalled = False
+        if self._resident_off:
+            raise RuntimeError("genvox_amd: a hand-off timed out although the resident kernels are switched off")
+        import warnings
+
+        warnings.warn("genvox_amd: an in-launch hand-off of a resident kernel timed out (the kernels could not run at the same "
+                      "time on this GPU); switching this model to the launch-per-step kernels and running the call again")
+        lib = _lib.load()
+        for h in [self._handle] + self._lane_handles:
+            if h is not None:
+                _lib.check(lib.gvx_model_set_resident_kernels(h, 0))
+        self._resident_off = True
+        return True
 
     def _ensure_lane_handles(self) -> None:
         """One C-ABI handle per chunk lane, bound to the same weight blob (a handle is not re-entrant: the lanes run
@@ -275,6 +316,8 @@ class Tacotron2(nn.Module):
                 dims = dims_from_configs(self.model_config, self.audio_config, self.text_config)
                 _lib.check(lib.gvx_model_create(C.byref(dims), C.byref(h)))
                 _lib.check(lib.gvx_model_set_persistent_attention(h.value, 0))
+                if self._resident_off:
+                    _lib.check(lib.gvx_model_set_resident_kernels(h.value, 0))
                 _lib.check(lib.gvx_model_bind_blob(h.value, self._blob.data_ptr()))
                 if self._timing:
                     _lib.check(lib.gvx_stage_timing_enable(h.value, 1))
@@ -286,6 +329,8 @@ class Tacotron2(nn.Module):
             self._lane_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         for i in range(2):
             if self._lane_ws[i] is None or self._lane_ws[i].numel() < need_bytes or self._lane_ws[i].device != dev:
+                if self._lane_ws[i] is not None:
+                    self._poll_status()   # (the replaced workspace takes its status words with it)
                 self._lane_ws[i] = self._new_workspace(need_bytes, dev)
         return self._lane_streams, self._lane_ws
 
@@ -330,11 +375,23 @@ class Tacotron2(nn.Module):
         return m
 
     # ------------------------------------------------------------------ reference surface
-    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def forward(self, batch: Dict[str, torch.Tensor], strict: bool = True) -> Dict[str, torch.Tensor]:
         """Teacher-forced text->mel (reference: models/tts/tacotron2.py:450-481).  No autograd graph is built in either
         mode.  Under ``.train()`` the forward is the reference's training-mode forward - BatchNorm batch statistics (and the
         running-statistics update), dropout after the encoder / Postnet convolutions and on both LSTM cells' outputs - see
-        ``_forward_train`` (the backward through the whole model is genvox_amd.training.train_backward; ``train_step`` runs both)."""
+        ``_forward_train`` (the backward through the whole model is genvox_amd.training.train_backward; ``train_step`` runs both).
+
+        strict (default): like the reference, the call always returns numbers - it synchronises once, and if an in-launch
+        hand-off of its resident kernels timed out (they could not run at the same time on this GPU) it is run again on the
+        launch-per-step kernels, which this model keeps from then on.  strict=False: nothing synchronises; a timed-out call
+        returns NaN in every output and raises at the next ``check_status()``."""
+        out = self._forward_once(batch)
+        if strict and not self.training and self._stalled_once():
+            out = self._forward_once(batch)
+            self._stalled_once()   # (raises if the second run reports a time-out as well)
+        return out
+
+    def _forward_once(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         dev = self._require_gpu()
         if self.training:
             return self._forward_train(batch)[0]
@@ -441,6 +498,10 @@ class Tacotron2(nn.Module):
         masks = self._keep_masks(pk.to(device=dev, dtype=torch.uint8).reshape(2, T + 1, B, P).contiguous() if pk is not None else None,
                                  2 * (T + 1) * B * P, dev).reshape(2, T + 1, B, P)
         # encoder: embedding, training-mode convolution stack on the WHOLE batch (BatchNorm batch statistics), parameters in place
+        # (nn.Embedding raises IndexError for an id outside the table, :459; checked here, before anything mutates model state -
+        # an out-of-range torch index would trip a device-side assert and leave the HIP context unusable)
+        if bool(((tokens < 0) | (tokens >= self.text_config.n_tokens)).any()):
+            raise IndexError("genvox_amd: token id outside [0, n_tokens)")
         emb = self.embedding.weight.data[tokens].transpose(1, 2).contiguous()          # [B, E, L]  (:459)
         conv_out, enc_tape = training.convstack_train_forward(self, "encoder.convolutions", training.encoder_acts(self), emb, enc_keep)
         st = self._stream()
@@ -450,36 +511,45 @@ class Tacotron2(nn.Module):
         ops = training._Ops(dev)
         # The recurrent part - BiLSTM and decoder loop - never mixes rows: batches above 32 rows (the reference's trainer
         # defaults to 64, its run.py uses 256) go through it in chunks of at most 32 rows, each with its own tape
-        chunks = []
-        for lo in range(0, B, STREAM_ROWS):
-            hi = min(B, lo + STREAM_ROWS)
-            Bc = hi - lo
-            ws = self._get_workspace(Bc, L, T)
-            tl_c = tok_len[lo:hi].contiguous()
-            memory = torch.empty(Bc, L, E, device=dev)
-            enc_c = torch.empty(Bc, L, E, device=dev)
-            _lib.check(lib.gvx_encoder_lstm_forward(self._handle, conv_out[lo:hi].data_ptr(), tl_c.data_ptr(), Bc, L, memory.data_ptr(),
-                                                    enc_c.data_ptr(), None, ws.data_ptr(), ws.numel(), st))
-            ha_blk = torch.empty((T + 1) * Bc * A, device=dev)
-            c_a_all, c_d_all = torch.empty(T + 1, Bc, A, device=dev), torch.empty(T + 1, Bc, D, device=dev)
-            hc_blk = torch.empty((T + 1) * Bc * (D + E), device=dev)
-            pre_a, pre_d = torch.empty(T, Bc, A, 4, device=dev), torch.empty(T, Bc, D, 4, device=dev)   # gate pre-activations of both cells
-            whole = lo == 0 and hi == B
-            mk = masks if whole else masks[:, :, lo:hi].contiguous()
-            ak = att_keep if whole else att_keep[:, lo:hi].contiguous()
-            dk = dec_keep if whole else dec_keep[:, lo:hi].contiguous()
-            _lib.check(lib.gvx_decoder_teacher_forced_train(
-                self._handle, memory.data_ptr(), tl_c.data_ptr(), Bc, L, mel_in[lo:hi].data_ptr(), T, mk.data_ptr(), ak.data_ptr(),
-                dk.data_ptr(), float(mc.p_attention_dropout), float(mc.p_decoder_dropout), dec_mel[lo:hi].data_ptr(), gate[lo:hi].data_ptr(),
-                align[lo:hi].data_ptr(), ha_blk.data_ptr(), c_a_all.data_ptr(), c_d_all.data_ptr(), hc_blk.data_ptr(), pre_a.data_ptr(), pre_d.data_ptr(),
-                ws.data_ptr(), ws.numel(), st))
-            # the rest of the chunk's tape: per-step vectors as plain rows, the Prenet activations and the processed memory
-            export = lambda what, shape: (lambda t: (_lib.check(lib.gvx_train_export(self._handle, ws.data_ptr(), ws.numel(), Bc, L, T, what, t.data_ptr(), st)), t)[1])(torch.empty(*shape, device=dev))
-            chunks.append({"rows": (lo, hi), "token_lengths": tl_c, "memory": memory, "enc_cell_states": enc_c,
-                           "h_a_all": training._unblock(ops, ha_blk, T + 1, Bc, A), "hc_all": training._unblock(ops, hc_blk, T + 1, Bc, D + E),
-                           "c_a_all": c_a_all, "c_d_all": c_d_all, "pre_a": pre_a, "pre_d": pre_d, "frames": export(0, (T + 1, Bc, M)),
-                           "p1": export(1, (T + 1, Bc, P)), "p2": export(2, (T + 1, Bc, P)), "pm": export(3, (Bc, L, mc.attention_dim)),
-                           "att_keep": ak, "dec_keep": dk, "prenet_keep": mk})
+        def run_chunks():
+            chunks = []
+            for lo in range(0, B, STREAM_ROWS):
+                hi = min(B, lo + STREAM_ROWS)
+                Bc = hi - lo
+                ws = self._get_workspace(Bc, L, T)
+                tl_c = tok_len[lo:hi].contiguous()
+                memory = torch.empty(Bc, L, E, device=dev)
+                enc_c = torch.empty(Bc, L, E, device=dev)
+                _lib.check(lib.gvx_encoder_lstm_forward(self._handle, conv_out[lo:hi].data_ptr(), tl_c.data_ptr(), Bc, L, memory.data_ptr(),
+                                                        enc_c.data_ptr(), None, ws.data_ptr(), ws.numel(), st))
+                ha_blk = torch.empty((T + 1) * Bc * A, device=dev)
+                c_a_all, c_d_all = torch.empty(T + 1, Bc, A, device=dev), torch.empty(T + 1, Bc, D, device=dev)
+                hc_blk = torch.empty((T + 1) * Bc * (D + E), device=dev)
+                pre_a, pre_d = torch.empty(T, Bc, A, 4, device=dev), torch.empty(T, Bc, D, 4, device=dev)   # gate pre-activations of both cells
+                whole = lo == 0 and hi == B
+                mk = masks if whole else masks[:, :, lo:hi].contiguous()
+                ak = att_keep if whole else att_keep[:, lo:hi].contiguous()
+                dk = dec_keep if whole else dec_keep[:, lo:hi].contiguous()
+                _lib.check(lib.gvx_decoder_teacher_forced_train(
+                    self._handle, memory.data_ptr(), tl_c.data_ptr(), Bc, L, mel_in[lo:hi].data_ptr(), T, mk.data_ptr(), ak.data_ptr(),
+                    dk.data_ptr(), float(mc.p_attention_dropout), float(mc.p_decoder_dropout), dec_mel[lo:hi].data_ptr(), gate[lo:hi].data_ptr(),
+                    align[lo:hi].data_ptr(), ha_blk.data_ptr(), c_a_all.data_ptr(), c_d_all.data_ptr(), hc_blk.data_ptr(), pre_a.data_ptr(), pre_d.data_ptr(),
+                    ws.data_ptr(), ws.numel(), st))
+                # the rest of the chunk's tape: per-step vectors as plain rows, the Prenet activations and the processed memory
+                export = lambda what, shape: (lambda t: (_lib.check(lib.gvx_train_export(self._handle, ws.data_ptr(), ws.numel(), Bc, L, T, what, t.data_ptr(), st)), t)[1])(torch.empty(*shape, device=dev))
+                chunks.append({"rows": (lo, hi), "token_lengths": tl_c, "memory": memory, "enc_cell_states": enc_c,
+                               "h_a_all": training._unblock(ops, ha_blk, T + 1, Bc, A), "hc_all": training._unblock(ops, hc_blk, T + 1, Bc, D + E),
+                               "c_a_all": c_a_all, "c_d_all": c_d_all, "pre_a": pre_a, "pre_d": pre_d, "frames": export(0, (T + 1, Bc, M)),
+                               "p1": export(1, (T + 1, Bc, P)), "p2": export(2, (T + 1, Bc, P)), "pm": export(3, (Bc, L, mc.attention_dim)),
+                               "att_keep": ak, "dec_keep": dk, "prenet_keep": mk})
+            return chunks
+
+        chunks = run_chunks()
+        # A resident loop whose hand-off timed out left NaN in dec_mel: it must not reach the Postnet's BatchNorm statistics
+        # (updated in place below).  One synchronisation; on a time-out the recurrent part runs again on the launch-per-step kernels
+        if self._stalled_once():
+            chunks = run_chunks()
+            self._stalled_once()
         post_y, post_tape = training.convstack_train_forward(self, "postnet.convolutions", training.postnet_acts(self), dec_mel, post_keep)
         mel_out, mel_post = dec_mel.clone(), dec_mel + post_y
         if mc.mask_padding:
@@ -544,10 +614,7 @@ class Tacotron2(nn.Module):
         n_chunks = -(-B // STREAM_ROWS)
         seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(n_chunks)]  # CPU generator: manual_seed repeats runs
         if n_chunks == 1:
-            need = lib.gvx_workspace_bytes_autoregressive(self._handle, B, L, S)
-            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-                self._workspace = self._new_workspace(need, dev)
-            run(0, B, self._handle, self._workspace, seeds[0])
+            run(0, B, self._handle, self._workspace_of(lib.gvx_workspace_bytes_autoregressive(self._handle, B, L, S)), seeds[0])
         else:
             import threading
 
@@ -579,6 +646,8 @@ class Tacotron2(nn.Module):
             if errors:
                 raise errors[0]
         n_host = n_frames.cpu()
+        if not inputs.get("_retried") and self._stalled_once():   # (a resident encoder / attention kernel could not overlap its partners)
+            return self.inference({**inputs, "_retried": True})
         self.check_status()   # the decoder calls have synchronised already: a bad token id raises here like nn.Embedding does
         Tn = int(n_host.max())
         if max(steps_run) >= S and int((n_host >= S).sum()) > 0:
@@ -586,10 +655,7 @@ class Tacotron2(nn.Module):
         mel_out = mel_out[:, :, :Tn].contiguous()
         mel_post = torch.empty_like(mel_out)
         # every row is post-processed as a sequence of its own length (what a batch-1 run of the reference sees)
-        need = lib.gvx_postnet_workspace_bytes(self._handle, B, Tn)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-            self._workspace = self._new_workspace(need, dev)
-        ws = self._workspace
+        ws = self._workspace_of(lib.gvx_postnet_workspace_bytes(self._handle, B, Tn))
         _lib.check(lib.gvx_postnet_forward(self._handle, mel_out.data_ptr(), n_frames.data_ptr() if B > 1 else None, B, Tn,
                                            mel_post.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         out = {"mel_outputs": mel_out, "mel_outputs_postnet": mel_post,
@@ -619,10 +685,7 @@ class Tacotron2(nn.Module):
         B, M, T = mel.shape
         lens = mel_lengths.to(device=dev, dtype=torch.int32).contiguous() if mel_lengths is not None else None
         lib = _lib.load()
-        need = lib.gvx_postnet_workspace_bytes(self._handle, B, T)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-            self._workspace = self._new_workspace(need, dev)
-        ws = self._workspace
+        ws = self._workspace_of(lib.gvx_postnet_workspace_bytes(self._handle, B, T))
         out = torch.empty_like(mel)
         _lib.check(lib.gvx_postnet_forward(self._handle, mel.data_ptr(), lens.data_ptr() if lens is not None else None, B, T,
                                            out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
@@ -676,18 +739,23 @@ class Tacotron2(nn.Module):
 
         if optimizer is None:
             raise ValueError("train_step needs the optimizer dict of get_optimizer()")
+        was_training = self.training   # (the reference's train_step does not switch modes: its trainer calls .train() once)
         self.train()
-        outputs, tape = self._forward_train(batch)
-        loss = (criterion or self.get_criterion())["loss"](batch, outputs)
-        self.loss_items = {key: val.item() for key, val in loss.items()}
-        # (the .item() calls have synchronised: a token id outside the table or a timed-out hand-off of the forward raises HERE,
-        # before NaN gradients could reach the weights)
-        self.check_status()
-        grads = training.train_backward(self, batch, outputs, tape)
-        self.grad_norm_val, scale = training.clip_grad_norm(grads, self.model_config.grad_clip_thresh)
-        optimizer["optimizer"].step(grads, scale)
-        self._packed_key = None
-        self.last_grads = grads   # (kept for inspection / tests; the reference keeps them in .grad)
+        try:
+            outputs, tape = self._forward_train(batch)
+            loss = (criterion or self.get_criterion())["loss"](batch, outputs)
+            self.loss_items = {key: val.item() for key, val in loss.items()}
+            # (a token id outside the table raised before the forward touched anything; a hand-off time-out was caught - and the
+            # recurrent part re-run - before the Postnet's BatchNorm update; this is the last look before gradients reach the weights)
+            self.check_status()
+            grads = training.train_backward(self, batch, outputs, tape)
+            self.grad_norm_val, scale = training.clip_grad_norm(grads, self.model_config.grad_clip_thresh)
+            optimizer["optimizer"].step(grads, scale)
+            self._packed_key = None
+            self.last_grads = grads   # (kept for inspection / tests; the reference keeps them in .grad)
+        finally:
+            if not was_training:
+                self.eval()
 
     def get_train_step_logs(self) -> Dict:
         """Reference: tacotron2.py:553-560."""

@@ -123,6 +123,14 @@ int gvx_workspace_status(const gvx_model* model, void* workspace, size_t workspa
  * behind one another); results equal to fp32 rounding (the h_a columns are added in a different order). */
 int gvx_model_set_persistent_attention(gvx_model* model, int enable);
 
+/* enable = 0: no kernel of this handle waits for another one inside a launch any more - the encoder recurrence becomes a launch
+ * per position, the teacher-forced decoder loop a launch pair per step (no resident attention / decoder kernel).  Same results
+ * (to fp32 rounding), slower.  What a caller switches to when a call came back with the hand-off time-out status (NaN outputs,
+ * gvx_workspace_status): the resident kernels could not run at the same time on this GPU (CU masking, a serialising profiler, a
+ * co-tenant holding CUs) - the host mirror does exactly this and runs the call again (genvox_amd/tacotron2.py, forward(strict=True)).
+ * enable = 1 restores the defaults (environment knobs are not re-read). */
+int gvx_model_set_resident_kernels(gvx_model* model, int enable);
+
 /* Batch rows gvx_tacotron2_forward / gvx_decoder_teacher_forced serve best per call for rows of L tokens: 64 where the 64-row
  * loop beside the resident attention kernel applies (default layer sizes, L <= 128, resident attention enabled: one pass over
  * the recurrent weights per step for all 64 rows), else 32 (callers with more rows run 32-row chunks - in turn where gvx_teacher_forced_resident says 1, else on two streams with a

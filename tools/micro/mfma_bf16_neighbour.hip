@@ -310,8 +310,59 @@ template <int MODE> static int trial(const char* name, hipStream_t sv, hipStream
     return 0;
 }
 
+// which XCDs a stream's workgroups land on (CU-masked streams: MASK=... below)
+__global__ void where_kernel(unsigned* xcc_bits) {
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) atomicOr(xcc_bits, 1u << (xcc & 0xf));
+}
+
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 4096;
+    // MASK=halves | xcds | same: victim and neighbour on CU-masked streams (hipExtStreamCreateWithCUMask) -
+    //   halves: CU bits [0, 128) / [128, 256);  xcds: bits with (i % 8) < 4 / >= 4;  same: both on bits [0, 128) (control)
+    // Round 4: is the disturbance a per-CU matter (it vanishes on disjoint CUs) or chip-wide?
+    const char* mask_mode = getenv("MASK");
+    if (mask_mode) {
+        hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        std::vector<uint32_t> mv(words, 0), mn(words, 0);
+        for (int i = 0; i < ncu; ++i) {
+            bool v, n;
+            if (mask_mode[0] == 'h') { v = i < ncu / 2; n = !v; }
+            else if (mask_mode[0] == 'x') { v = (i % 8) < 4; n = !v; }
+            else { v = i < ncu / 2; n = v; }
+            if (v) mv[i / 32] |= 1u << (i % 32);
+            if (n) mn[i / 32] |= 1u << (i % 32);
+        }
+        for (int m = 0; m < 7; ++m) {
+            const void* f = m == 0 ? (const void*)neighbour<0> : m == 1 ? (const void*)neighbour<1> : m == 2 ? (const void*)neighbour<2> : m == 3 ? (const void*)neighbour<3>
+                          : m == 4 ? (const void*)neighbour<4> : m == 5 ? (const void*)neighbour<5> : (const void*)neighbour<6>;
+            CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        std::vector<float> hw(8192 * 4 + 65536 * 4), hx(128 * 80);
+        unsigned s = 12345u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+        for (auto& v : hw) v = rnd();
+        for (auto& v : hx) v = rnd();
+        float *w, *x, *out, *ref, *sink; unsigned* mism; unsigned* bits;
+        CK(hipMalloc(&w, hw.size() * 4)); CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&out, 128 * 64 * 4)); CK(hipMalloc(&ref, 128 * 64 * 4));
+        CK(hipMalloc(&sink, 800 * 256 * 4)); CK(hipMalloc(&mism, 4)); CK(hipMalloc(&bits, 8)); CK(hipMemset(bits, 0, 8));
+        CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        hipStream_t sv, sn;
+        CK(hipExtStreamCreateWithCUMask(&sv, words, mv.data())); CK(hipExtStreamCreateWithCUMask(&sn, words, mn.data()));
+        where_kernel<<<2048, 64, 0, sv>>>(bits); where_kernel<<<2048, 64, 0, sn>>>(bits + 1);
+        CK(hipDeviceSynchronize());
+        unsigned hb[2]; CK(hipMemcpy(hb, bits, 8, hipMemcpyDeviceToHost));
+        printf("MASK=%s: victim stream ran on XCDs 0x%02x, neighbour stream on XCDs 0x%02x\n", mask_mode, hb[0], hb[1]);
+        victim<<<128, 1024, 0, sv>>>(w, x, ref);
+        CK(hipDeviceSynchronize());
+        if (trial<-1>("alone", sv, sn, w, x, out, ref, sink, mism, rounds)) return 1;
+        if (trial<1>("next to v_mfma_f32_32x32x2_f32", sv, sn, w, x, out, ref, sink, mism, rounds)) return 1;
+        if (trial<0>("next to v_mfma_f32_32x32x16_bf16", sv, sn, w, x, out, ref, sink, mism, rounds)) return 1;
+        if (trial<4>("next to v_mfma_f32_16x16x32_bf16", sv, sn, w, x, out, ref, sink, mism, rounds)) return 1;
+        if (trial<6>("next to v_mfma_f32_16x16x32_f16", sv, sn, w, x, out, ref, sink, mism, rounds)) return 1;
+        return 0;
+    }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbour<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbour<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(neighbour<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

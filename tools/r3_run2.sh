@@ -1,6 +1,8 @@
 #!/bin/bash
+set -u
 # GPU run 2 of round 3: MFMA query slabs A/B, stamps, SQ / TCC counters of the pa kernel
 set -o pipefail
+: "${GRAFT_REPO_ROOT:?}"
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3_run2; mkdir -p $O
 python -m pytest tests/test_parity_gpu.py -q -x -k "persistent or handoff or depth6 or fixture" > $O/tests.log 2>&1 || { tail -20 $O/tests.log; exit 1; }

@@ -1,6 +1,8 @@
 #!/bin/bash
+set -u
 # GPU run 3 of round 3: autoregressive loop beside the resident attention kernel - parity, A/B, kernel stats
 set -o pipefail
+: "${GRAFT_REPO_ROOT:?}"
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3_run3; mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_parity_gpu.py tests/test_fullsize_gpu.py tests/test_synthesizer_gpu.py -q -x -k "autoregressive or config3 or synthesizer or graph_replay or rebinding" > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }

@@ -1,6 +1,8 @@
 #!/bin/bash
+set -u
 # GPU run 4 of round 3: rows of up to 256 positions beside the split resident kernel
 set -o pipefail
+: "${GRAFT_REPO_ROOT:?}"
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3_run4; mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_parity_gpu.py -q -x -k "persistent or handoff or depth6" > $O/tests_pa.log 2>&1 || { tail -40 $O/tests_pa.log; exit 1; }

@@ -1,6 +1,8 @@
 #!/bin/bash
+set -u
 # GPU run 5 of round 3: 64-row teacher-forced loop beside the resident attention kernel
 set -o pipefail
+: "${GRAFT_REPO_ROOT:?}"
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3_run5; mkdir -p $O
 timeout -k 10 300 python -m pytest tests/test_parity_gpu.py -q -x -k "shapes_against_oracle" > $O/tests_shapes.log 2>&1 || { tail -40 $O/tests_shapes.log; exit 1; }

@@ -1,5 +1,7 @@
 #!/bin/bash
+set -u
 set -o pipefail
+: "${GRAFT_REPO_ROOT:?}"
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3_run6; mkdir -p $O
 for rot in 0 1 3 7 0 3; do

@@ -1,5 +1,7 @@
 #!/bin/bash
+set -u
 set -o pipefail
+: "${GRAFT_REPO_ROOT:?}"
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r3_run7
 export TMPDIR=/tmp

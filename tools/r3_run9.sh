@@ -1,6 +1,8 @@
 #!/bin/bash
+set -u
 # GPU run 9 of round 3: profiles of the final-ish tree
 set -o pipefail
+: "${GRAFT_REPO_ROOT:?}"
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3_run9; mkdir -p $O
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }

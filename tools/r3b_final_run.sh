@@ -1,4 +1,5 @@
 O=gpurun_out/r3b_final; mkdir -p $O
+set -u
 timeout -k 10 800 python -m pytest tests -m gpu -x -q > $O/tests_all.log 2>&1; rc=$?; tail -4 $O/tests_all.log
 if [ $rc -ge 124 ]; then echo "tests were killed (rc $rc): no further GPU step in this call"; exit $rc; fi
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; rc=$?; tail -2 $O/bench.err

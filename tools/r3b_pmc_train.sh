@@ -1,4 +1,5 @@
 #!/bin/bash
+set -u
 # HBM traffic of the training step's kernels: FETCH_SIZE / WRITE_SIZE in separate --pmc passes (counter collection serialises
 # kernels, so the training forward takes the launch-per-attention-step loop here: GVX_TRAIN_RESIDENT=0)
 set -o pipefail

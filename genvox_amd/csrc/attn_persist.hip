@@ -88,14 +88,14 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
-// One WAVE waits until every one of the n (<= 128) flag words reads >= target: two words per lane per look.  Bounded like
+// One WAVE waits until every one of the n (<= 128) flag words (one per 128-byte line) reads >= target: two words per lane per look.  Bounded like
 // handoff_wait<true>; returns false (wave-uniform) when the wait was given up, by a time-out here or anywhere else, or by the
 // host's stop word.
 __device__ __forceinline__ bool flags_wait(const unsigned* flags, int n, unsigned target, unsigned* tmo, unsigned code, unsigned limit,
                                            const unsigned* stop, bool nosleep) {
     if (limit == 0u) limit = HANDOFF_SPIN_LIMIT;
     const int lane = threadIdx.x & 63;
-    const int i0 = lane < n ? lane : 0, i1 = lane + 64 < n ? lane + 64 : 0;
+    const int i0 = (lane < n ? lane : 0) * 32, i1 = (lane + 64 < n ? lane + 64 : 0) * 32;   // (a flag per 128-byte line)
     unsigned spins = 0;
     while (true) {
         const unsigned v0 = __hip_atomic_load(flags + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         // stopped - or some wait has timed out) ends the kernel: nothing it could still compute would be used
         if (p.q_flags) {
             // beside the resident decoder kernel: one flag per producing workgroup (value = steps published), watched by one wave
-            if (wave == 0 && !flags_wait(p.q_flags + (b % RS_REP) * 128, p.n_q_flags, (unsigned)t + 1u, tmo, 0x100u + (unsigned)b, p.spin_limit, stop, (p.debug & 32) != 0) && (tid & 63) == 0) *leave = 1;
+            if (wave == 0 && !flags_wait(p.q_flags + (b % RS_REP1) * p.n_q_flags * 32, p.n_q_flags, (unsigned)t + 1u, tmo, 0x100u + (unsigned)b, p.spin_limit, stop, (p.debug & 32) != 0) && (tid & 63) == 0) *leave = 1;
         } else if (tid == 0 && !handoff_wait<true>(cnt_q, (unsigned)t + p.q_first, tmo, 0x100u + (unsigned)b, p.spin_limit, stop)) *leave = 1;
         __syncthreads();
         if (*leave) break;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         }
         __syncthreads();
         if (p.ctx_flags) {   // one wave instruction: lane r stores the row's flag into replica r
-            if (tid < RS_REP && hf == 0) __hip_atomic_store(p.ctx_flags + tid * 32 + b, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < RS_REP1 && hf == 0) __hip_atomic_store(p.ctx_flags + (tid * 32 + b) * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (tid == 0 && hf == 0) __hip_atomic_fetch_add(cnt_ctx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PA_STAMP(5);
 #ifdef GVX_STAMPS

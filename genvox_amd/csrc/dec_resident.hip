@@ -108,7 +108,7 @@ __device__ __forceinline__ void rs_poll_once(int* ctrl, const RsPoll& q, int lan
         const unsigned d1 = __hip_atomic_load(q.f_dec + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         v = min(d0, d1);
     } else {
-        v = lane < q.B ? __hip_atomic_load(q.f_ctx + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        v = lane < q.B ? __hip_atomic_load(q.f_ctx + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;   // (a flag per 128-byte line)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: nothing below moves above the loads
 #ifdef GVX_STAMPS
@@ -213,7 +213,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
     const unsigned blkb = (unsigned)B * 32u;   // bytes per k-group of a blocked vector
     unsigned* const tmo_w = p.sync + HANDOFF_TIMEOUT;
     const int rep = bid % RS_REP;   // the flag replica this workgroup reads
-    const RsPoll poll{p.sync + RS_FLAG_ATT + rep * 128, p.sync + RS_FLAG_DEC + rep * 128, p.sync + RS_FLAG_CTX + rep * 32, tmo_w,
+    const RsPoll poll{p.sync + RS_FLAG_ATT + rep * 128, p.sync + RS_FLAG_DEC + rep * 128, p.sync + RS_FLAG_CTX + (bid % RS_REP1) * 32 * 32, tmo_w,
                       (p.spin_limit ? p.spin_limit : HANDOFF_SPIN_LIMIT) * 16u, B, T, bid,
                       (!ATT && (p.debug & 16)) ? 32 : ((p.debug & 8) ? 8 : 0)};
     const int bl = lane & 31, h = lane >> 5;
@@ -471,6 +471,8 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         RS_STAMP(9);
         // one wave instruction: lane r stores the workgroup's flag into replica r
         if (tid < RS_REP) __hip_atomic_store(p.sync + (ATT ? RS_FLAG_ATT + bid : RS_FLAG_DEC + (bid - 96)) + tid * 128, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (ATT && tid < RS_REP + RS_REP1)   // ... and lanes 32 .. 39 the slab flags the attention rows watch (a line each)
+            __hip_atomic_store(p.sync + RS_FLAG_Q + ((tid - RS_REP) * 96 + bid) * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         RS_WGSTAMP(3);
     }
     // final cell states (the launch-per-step loop keeps them in memory; callers that continue a sequence read them there)

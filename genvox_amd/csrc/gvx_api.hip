@@ -1214,7 +1214,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         pp.sync = sync; pp.B = B; pp.L = L; pp.T = T; pp.kl = d.att_loc_kernel;
         pp.spin_limit = m->spin_limit; pp.q_first = 2;   // (launch 0 announces its start too)
         if (resident) {   // beside the resident decoder kernel: flags per producer instead of the two counters
-            pp.q_flags = sync + RS_FLAG_ATT; pp.n_q_flags = pp.n_slabs;   // (row b polls replica b % RS_REP: attn_persist.hip)
+            pp.q_flags = sync + RS_FLAG_Q; pp.n_q_flags = pp.n_slabs;   // (row b polls replica b % RS_REP1: attn_persist.hip)
             pp.ctx_flags = sync + RS_FLAG_CTX;
             { static const int dbg = [] { const char* e = std::getenv("GVX_RS_DEBUG"); return e ? std::atoi(e) : 0; }(); pp.debug = dbg; }
         }

@@ -208,7 +208,7 @@ bool attention_supported(int L, int a, int F, int kl, int E);
 constexpr int HANDOFF_CNT_Q = 0, HANDOFF_CNT_CTX = 1024, HANDOFF_READY = 2048, HANDOFF_TIMEOUT = 3072;
 constexpr int HANDOFF_STOP = 3072 + 512;   // the host's "the loop has ended early" word (autoregressive decode): the resident kernel leaves
 constexpr int HANDOFF_PAIR = 4096;   // split resident kernel: flag word of half hf of row b at HANDOFF_PAIR + (2 b + hf) * 32
-constexpr int HANDOFF_WORDS = 18432;   // (the last 10240: flag replicas of the resident decoder loop, RS_FLAG_* below)
+constexpr int HANDOFF_WORDS = 51200;   // (from 8192 on: flag replicas of the resident decoder loop, RS_FLAG_* below)
 constexpr unsigned HANDOFF_SPIN_LIMIT = 200000u;   // polls with ~2 us of s_sleep between them (a few hundred ms), then the wait gives up
 struct AttnPersistParams {
     const float* q_slab; int n_slabs;       // [n_slabs][B][a], rewritten (sc1) by the attention-LSTM tiles every step
@@ -225,8 +225,8 @@ struct AttnPersistParams {
     // beside the resident decoder kernel (dec_resident.hip): the slabs of step t are there when every one of the n_q_flags
     // producer flags reads >= t + 1 (in place of the query counter), and row b announces its context of step t by storing
     // t + 1 into ctx_flags[b] (in place of the context counter); nullptr otherwise
-    const unsigned* q_flags; int n_q_flags;   // this row's replica of the producers' flags
-    unsigned* ctx_flags;                      // replica r of row b's flag at ctx_flags[r * 32 + b], r < RS_REP
+    const unsigned* q_flags; int n_q_flags;   // producer i's flag for the rows of replica r at q_flags[(r * n_q_flags + i) * 32], r < RS_REP1
+    unsigned* ctx_flags;                      // replica r of row b's flag at ctx_flags[(r * 32 + b) * 32], r < RS_REP1
     int debug;   // timing experiments (GVX_RS_DEBUG & 32: no sleep between looks at the flags)
 };
 // ---------------------------------------------------------------------------------------------
@@ -241,8 +241,12 @@ struct AttnPersistParams {
 constexpr int RS_REP = 32;
 constexpr int RS_FLAG_ATT = 8192;                        // [RS_REP][128] attention-LSTM workgroup i (< 96) has published h_a and its query slab of steps < value
 constexpr int RS_FLAG_DEC = RS_FLAG_ATT + RS_REP * 128;  // [RS_REP][128] decoder-LSTM workgroup i has published h_d of steps < value
-constexpr int RS_FLAG_CTX = RS_FLAG_DEC + RS_REP * 128;  // [RS_REP][32]  attention row b has published its context of steps < value
-static_assert(RS_FLAG_CTX + RS_REP * 32 <= HANDOFF_WORDS, "flag replicas inside the hand-off block");
+// The two hand-offs ON the step's chain - contexts to the attention-LSTM workgroups, query slabs to the attention rows - use flags
+// on lines of their own (one writer per line: 32 stores into one line took up to 1 us to be acknowledged), in RS_REP1 replicas:
+constexpr int RS_REP1 = 8;
+constexpr int RS_FLAG_CTX = RS_FLAG_DEC + RS_REP * 128;             // [RS_REP1][32 rows][32 words]: attention row b has published its context of steps < value
+constexpr int RS_FLAG_Q = RS_FLAG_CTX + RS_REP1 * 32 * 32;          // [RS_REP1][96][32 words]: attention-LSTM workgroup i has published its query slab of steps < value
+static_assert(RS_FLAG_Q + RS_REP1 * 96 * 32 <= HANDOFF_WORDS, "flag replicas inside the hand-off block");
 constexpr int RS_HA_SLOTS = 4;            // ring of h_a vectors: h_a(t) in slot (t + 1) % RS_HA_SLOTS, slot 0 = the zero state
 struct DecResidentParams {
     const float* att_frag; const float* att_bias; const float* wq_t;   // packed [128][224][64][4], [4A] packed row order, [A/8][a][8]

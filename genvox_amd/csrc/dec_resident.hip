@@ -66,9 +66,6 @@ constexpr int RC_HD = 2;           // steps whose h_d every decoder-LSTM workgro
 constexpr int RC_ABORT = 3;        // != 0: a wait of this workgroup has given up - every wait returns at once, the workgroup drains
 constexpr int RC_LOCK = 4;         // the wave that holds it polls the global flags for the workgroup
 constexpr int RC_IDLE = 5;         // polls since the last one that moved a word (the bound of the waits)
-constexpr int RC_BAR = 8;          // barrier counter
-// Watchdog of the barrier (it depends on the gates' bounded polls only, so it never fires unless the kernel itself is wrong)
-constexpr unsigned RS_WATCHDOG = 1u << 24;
 
 #ifdef GVX_STAMPS
 // diagnostic build (tools/stamps_resident.py): wall-clock stamps (10 ns) of decoder step RS_STAMP_T in one workgroup of each kind
@@ -158,21 +155,14 @@ __device__ __forceinline__ void rs_gate(int* ctrl, int word, int need, const RsP
         }
     }
 }
-// Barrier of the workgroup's 8 waves as a counter in LDS (target = 8 x the number of barriers so far): unlike s_barrier it can be
-// left when the abort word goes up.  Workgroup-scope release / acquire; LDS traffic of a wave is processed in issue order.
-__device__ __forceinline__ void rs_cbar(int* ctrl, int& nbar, int lane, unsigned* tmo) {
-    ++nbar;
-    if (lane == 0) __hip_atomic_fetch_add(ctrl + RC_BAR, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    unsigned n = 0;
-    while (__hip_atomic_load(ctrl + RC_BAR, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < RS_WAVES * nbar) {
-        if (__hip_atomic_load(ctrl + RC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
-        if (++n > RS_WATCHDOG) {
-            __hip_atomic_store(ctrl + RC_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(tmo, 0x600u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        __builtin_amdgcn_s_sleep(0);
-    }
+// Barrier of the workgroup's 8 waves.  All of them reach every barrier of every step also after an abort (waits return at once,
+// nobody leaves the loop early), so the hardware barrier is safe; LDS traffic of the wave is retired first (the barrier itself
+// waits for no counter), vector memory is left alone (an earlier version - a counter in LDS polled with s_sleep - cost
+// 0.1-0.35 us per barrier, three per step on the chain).
+__device__ __forceinline__ void rs_cbar() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 #define RS_MFMA32(W, X)                                                   \
@@ -266,7 +256,6 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         bias4 = *reinterpret_cast<const float4*>(bias + xt * 32 + 4 * jloc2);
     }
     const bool slab_wave = ATT && wave < RS_ATT / 32;
-    int nbar = 0;
 
 #ifdef GVX_STAMPS
     const bool stamp_wg = bid == 0 || bid == 64 || bid == 96;
@@ -383,7 +372,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
 #pragma unroll
             for (int q = 0; q < 8; ++q) red2[(wave * 8 + q) * 64 + el] = acc2[q] + acc2[8 + q];
         }
-        rs_cbar(ctrl, nbar, el, tmo_w);
+        rs_cbar();
         RS_STAMP(5);
         if (cell2_wave) {
             const int rb = wave - 4;
@@ -421,7 +410,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
             }
             hs[ebl * 8 + 2 * g + eh] = hval;
         }
-        rs_cbar(ctrl, nbar, el, tmo_w);
+        rs_cbar();
         RS_STAMP(6);
 
         // ---- publication: h' as 16-byte write-through pieces, the query slab (attention LSTM), then the workgroup's flag
@@ -467,7 +456,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         RS_STAMP(7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the flag goes up
         RS_STAMP(8);
-        rs_cbar(ctrl, nbar, el, tmo_w);
+        rs_cbar();
         RS_STAMP(9);
         // one wave instruction: lane r stores the workgroup's flag into replica r
         if (tid < RS_REP) __hip_atomic_store(p.sync + (ATT ? RS_FLAG_ATT + bid : RS_FLAG_DEC + (bid - 96)) + tid * 128, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -45,20 +45,21 @@ constexpr int RS_KG0_ATT = RS_P / 8;                    // the Prenet columns ar
 // step in the part whose x is known early (NN: h_a / h_d columns) and in the context part (NC), how many of the former live in
 // registers (NRN; the context part always does), and the LDS layout (bytes)
 template <int KIND> struct RsCfg {
-    static constexpr bool XH = KIND == 0, ATT = KIND < 2;
+    static constexpr bool XH = KIND == 0, ATT = KIND != 2;
+    static constexpr int RT = KIND == 3 ? 2 : 1;                           // row tiles per workgroup (KIND 3: a pair of attention-LSTM tiles)
     static constexpr int NN = ATT ? 16 : 32, NC = 8;
-    static constexpr int NRN = KIND == 0 ? 7 : (KIND == 1 ? 16 : 17);
+    static constexpr int NRN = KIND == 0 ? 7 : (KIND == 1 ? 16 : (KIND == 2 ? 17 : 9));
     static constexpr int NLN = NN - NRN;                                   // k-groups per wave in LDS
-    static constexpr int WAVE_W = NLN * (XH ? 1536 : 1024);               // LDS bytes of a wave's fragments (+ 512 per half fragment)
-    static constexpr int OFF_RED = RS_WAVES * WAVE_W;                      // [8 waves][16][64] floats
+    static constexpr int WAVE_W = NLN * (XH ? 1536 : 1024 * RT);          // LDS bytes of a wave's fragments (+ 512 per half fragment)
+    static constexpr int OFF_RED = RS_WAVES * WAVE_W;                      // [8 waves][16][64] floats (KIND 3: one tile after the other)
     static constexpr int OFF_RED2 = OFF_RED + RS_WAVES * 16 * 64 * 4;      // [8][8][64] floats (half tile)
-    static constexpr int OFF_HS = OFF_RED2 + (XH ? RS_WAVES * 8 * 64 * 4 : 0);   // [32][8] h' of the tile's units
-    static constexpr int OFF_HS2 = OFF_HS + 32 * 8 * 4;                    // [32][4] h' of the half tile's units
+    static constexpr int OFF_HS = OFF_RED2 + (XH ? RS_WAVES * 8 * 64 * 4 : 0);   // [32][8 RT] h' of the workgroup's units
+    static constexpr int OFF_HS2 = OFF_HS + 32 * 8 * 4 * RT;               // [32][4] h' of the half tile's units
     static constexpr int OFF_CTRL = OFF_HS2 + 32 * 4 * 4;                  // control words
     static constexpr int LDS_BYTES = OFF_CTRL + 256;
 };
 constexpr int RS_LDS_BYTES = RsCfg<0>::LDS_BYTES > RsCfg<2>::LDS_BYTES ? RsCfg<0>::LDS_BYTES : RsCfg<2>::LDS_BYTES;
-static_assert(RS_LDS_BYTES <= 160 * 1024 && RsCfg<1>::LDS_BYTES <= RS_LDS_BYTES, "resident decoder LDS");
+static_assert(RS_LDS_BYTES <= 160 * 1024 && RsCfg<1>::LDS_BYTES <= RS_LDS_BYTES && RsCfg<3>::LDS_BYTES <= RS_LDS_BYTES, "resident decoder LDS");
 // control words (int index)
 constexpr int RC_HA = 0;           // steps whose h_a + slabs every attention-LSTM workgroup has published
 constexpr int RC_CTX = 1;          // steps whose context every attention row has published
@@ -71,7 +72,7 @@ constexpr int RC_IDLE = 5;         // polls since the last one that moved a word
 // diagnostic build (tools/stamps_resident.py): wall-clock stamps (10 ns) of decoder step RS_STAMP_T in one workgroup of each kind
 // (blocks 0 / 64 / 96): [kind][wave 0-7][event]; per workgroup (wave 0): step begins, gate 1, gate 2, flag stored
 constexpr int RS_STAMP_T = 20;
-__device__ unsigned long long rs_stamps[3][10][16];
+__device__ unsigned long long rs_stamps[4][10][16];
 __device__ unsigned long long rs_wg_stamps[224][4];
 __device__ unsigned long long rs_poll_log[3][64];   // [class][k]: return time of the k-th poll of block 64 during step RS_STAMP_T
 __device__ int rs_poll_n[3];
@@ -88,6 +89,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 struct RsPoll {   // what a poll needs: the flag words, the status word, sizes
     const unsigned* f_att; const unsigned* f_dec; const unsigned* f_ctx; unsigned* tmo;
     unsigned limit; int B, T, bid;
+    int n_att;   // attention-LSTM workgroups (96 in the 224-workgroup deal, 64 pairs in the 192-workgroup one)
     int sleep;   // s_sleep units between two looks of the polling wave (GVX_RS_DEBUG experiments)
 };
 
@@ -98,7 +100,7 @@ __device__ __forceinline__ void rs_poll_once(int* ctrl, const RsPoll& q, int lan
     unsigned v;
     if (word == RC_HA) {
         const unsigned a0 = __hip_atomic_load(q.f_att + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned a1 = lane < 32 ? __hip_atomic_load(q.f_att + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        const unsigned a1 = lane + 64 < q.n_att ? __hip_atomic_load(q.f_att + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
         v = min(a0, a1);
     } else if (word == RC_HD) {
         const unsigned d0 = __hip_atomic_load(q.f_dec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -170,6 +172,12 @@ __device__ __forceinline__ void rs_cbar() {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((W).y, (X).y, acc, 0, 0, 0); \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((W).z, (X).z, acc, 0, 0, 0); \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((W).w, (X).w, acc, 0, 0, 0);
+// (second row tile of a pair: the same x fragment, its own accumulator - acc2, which the half tiles use in the other kinds)
+#define RS_MFMA32B(W, X)                                                    \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((W).x, (X).x, acc2, 0, 0, 0); \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((W).y, (X).y, acc2, 0, 0, 0); \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((W).z, (X).z, acc2, 0, 0, 0); \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((W).w, (X).w, acc2, 0, 0, 0);
 #define RS_MFMA16(W, X)                                                     \
     acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32((W).x, (X).x, acc2, 0, 0, 0); \
     acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32((W).y, (X).y, acc2, 0, 0, 0); \
@@ -186,11 +194,16 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
     constexpr int NKGW = ATT ? RS_NKGW_ATT : RS_NKGW_DEC;
     constexpr int H = ATT ? RS_A : RS_D;
     constexpr int NRH = XH ? NRN : 1, NCH = XH ? NC : 1;   // half-tile fragments in registers
+    constexpr int RT = Cfg::RT;
+    constexpr int NR2 = RT == 2 ? NRN : 1, NC2 = RT == 2 ? NC : 1;   // second row tile's fragments in registers
 
+    // block -> tile(s): the 224-workgroup deal (one attention workgroup per row: L <= 128) or the 192-workgroup one (two per row)
+    const int dec0 = p.layout == 2 ? 64 : 96;   // first decoder-LSTM workgroup
     int tile, xt = 0, xhalf = 0;
     if (KIND == 0) { const int m = bid >> 1, odd = bid & 1; tile = 3 * m + 2 * odd; xt = 3 * m + 1; xhalf = odd; }
     else if (KIND == 1) tile = 96 + (bid - 64);
-    else tile = bid - 96;
+    else if (KIND == 3) tile = 2 * bid;
+    else tile = bid - dec0;
 
     int* ctrl = reinterpret_cast<int*>(smem + Cfg::OFF_CTRL);
     float* red = reinterpret_cast<float*>(smem + Cfg::OFF_RED);
@@ -204,7 +217,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
     unsigned* const tmo_w = p.sync + HANDOFF_TIMEOUT;
     const int rep = bid % RS_REP;   // the flag replica this workgroup reads
     const RsPoll poll{p.sync + RS_FLAG_ATT + rep * 128, p.sync + RS_FLAG_DEC + rep * 128, p.sync + RS_FLAG_CTX + (bid % RS_REP1) * 32 * 32, tmo_w,
-                      (p.spin_limit ? p.spin_limit : HANDOFF_SPIN_LIMIT) * 16u, B, T, bid,
+                      (p.spin_limit ? p.spin_limit : HANDOFF_SPIN_LIMIT) * 16u, B, T, bid, dec0,
                       (!ATT && (p.debug & 16)) ? 32 : ((p.debug & 8) ? 8 : 0)};
     const int bl = lane & 31, h = lane >> 5;
     const bool x_mine = ((lane >> 4) & 1) == xhalf;
@@ -219,30 +232,37 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
     const int kc0 = ATT ? RS_KG0_ATT + 8 * wave : 128 + 8 * wave;
     const float4* wt = wsrc + (long)tile * NKGW * 64 + lane;
     const float4* wx = wsrc + (long)xt * NKGW * 64 + mlane;
-    float4 wn[NRN], wc[NC], hn[NRH], hc[NCH];
+    float4 wn[NRN], wc[NC], hn[NRH], hc[NCH], wn2[NR2], wc2[NC2];
+    const float4* wt2 = wt + (long)NKGW * 64;   // the pair's second tile
 #pragma unroll
     for (int i = 0; i < NRN; ++i) wn[i] = wt[(long)(kn0 + i) * 64];
 #pragma unroll
     for (int i = 0; i < NC; ++i) wc[i] = wt[(long)(kc0 + i) * 64];
+#pragma unroll
+    for (int i = 0; i < NR2; ++i) wn2[i] = RT == 2 ? wt2[(long)(kn0 + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NC2; ++i) wc2[i] = RT == 2 ? wt2[(long)(kc0 + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NRH; ++i) hn[i] = XH ? wx[(long)(kn0 + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) hc[i] = XH ? wx[(long)(kc0 + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
     // the rest in LDS, private to the wave: [NLN][64 lanes] tile fragments, then [NLN][32] half fragments (written by the lanes
     // that own them, read by their partners too)
-    float4* lw = reinterpret_cast<float4*>(smem + wave * Cfg::WAVE_W);
+    float4* lw = reinterpret_cast<float4*>(smem + wave * Cfg::WAVE_W);   // [NLN][RT][64]
     float4* lh = lw + NLN * 64;
     const int hidx = (mlane & 15) + 16 * (mlane >> 5);
 #pragma unroll
     for (int i = 0; i < NLN; ++i) {
-        lw[i * 64 + lane] = wt[(long)(kn0 + NRN + i) * 64];
+        lw[i * RT * 64 + lane] = wt[(long)(kn0 + NRN + i) * 64];
+        if (RT == 2) lw[(i * RT + 1) * 64 + lane] = wt2[(long)(kn0 + NRN + i) * 64];
         if (XH && x_mine) lh[i * 32 + hidx] = wx[(long)(kn0 + NRN + i) * 64];
     }
 
     // per-lane constants of the epilogue: cell state (registers for the whole loop), bias, query-slab weights
-    const bool cell_wave = wave < 4;
+    const bool cell_wave = wave < 4 * RT;
     const bool cell2_wave = XH && (wave == 4 || wave == 5);
-    const int g = wave & 3, jloc = 2 * g + h, j = tile * 8 + jloc;
+    const int ctile = tile + (RT == 2 ? (wave >> 2) : 0);   // the row tile whose unit this wave finishes
+    const int g = wave & 3, jloc = 2 * g + h, j = ctile * 8 + jloc;
     const int b2 = (lane & 15) + 16 * (wave - 4), g2 = lane >> 4, jloc2 = 4 * xhalf + g2, j2 = xt * 8 + jloc2;
     float* c_mem = ATT ? p.c_a : p.c_d;
     const float* bias = ATT ? p.att_bias : p.dec_bias;
@@ -250,7 +270,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cell_wave) {
         if (bl < B) c_state = c_mem[(long)bl * H + j];
-        bias4 = *reinterpret_cast<const float4*>(bias + tile * 32 + 8 * g + 4 * h);
+        bias4 = *reinterpret_cast<const float4*>(bias + ctile * 32 + 8 * g + 4 * h);
     } else if (cell2_wave) {
         if (b2 < B) c_state = c_mem[(long)b2 * H + j2];
         bias4 = *reinterpret_cast<const float4*>(bias + xt * 32 + 4 * jloc2);
@@ -258,7 +278,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
     const bool slab_wave = ATT && wave < RS_ATT / 32;
 
 #ifdef GVX_STAMPS
-    const bool stamp_wg = bid == 0 || bid == 64 || bid == 96;
+    const bool stamp_wg = bid == 0 || bid == 64 || bid == dec0;
 #endif
     for (int t = 0; t < T; ++t) {
         RS_STAMP(0);
@@ -268,7 +288,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         float4 add4 = bias4;
         if (ATT) {
             if (cell_wave && bl < B) {
-                const float4 ad = *reinterpret_cast<const float4*>(p.pre_gate + ((long)t * B + bl) * 4 * RS_A + tile * 32 + 8 * g + 4 * h);
+                const float4 ad = *reinterpret_cast<const float4*>(p.pre_gate + ((long)t * B + bl) * 4 * RS_A + ctile * 32 + 8 * g + 4 * h);
                 add4.x += ad.x; add4.y += ad.y; add4.z += ad.z; add4.w += ad.w;
             } else if (cell2_wave && b2 < B) {
                 const float4 ad = *reinterpret_cast<const float4*>(p.pre_gate + ((long)t * B + b2) * 4 * RS_A + xt * 32 + 4 * jloc2);
@@ -292,7 +312,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
             RS_STAMP(1);
             RS_WGSTAMP(1);
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(xsrc);
-            constexpr int XG = XH ? 2 : 4;   // k-groups per x batch: the next batch loads while this one multiplies
+            constexpr int XG = (XH || RT == 2) ? 2 : 4;   // k-groups per x batch: the next batch loads while this one multiplies
             float4 xc[XG], xn[XG];
 #pragma unroll
             for (int u = 0; u < XG; ++u) xc[u] = load_sc1(rx, x_lane + (unsigned)u * blkb);
@@ -308,10 +328,12 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
                     if (i < NRN) {
                         RS_MFMA32(wn[i], xc[u])
                         if (XH) { RS_MFMA16(hn[i < NRH ? i : 0], xc[u]) }
+                        if (RT == 2) { RS_MFMA32B(wn2[i < NR2 ? i : 0], xc[u]) }
                     } else {
-                        const float4 wl = lw[(i - NRN) * 64 + lane];
+                        const float4 wl = lw[(i - NRN) * RT * 64 + lane];
                         RS_MFMA32(wl, xc[u])
                         if (XH) { const float4 hl = lh[(i - NRN) * 32 + hidx]; RS_MFMA16(hl, xc[u]) }
+                        if (RT == 2) { const float4 wl2 = lw[((i - NRN) * RT + 1) * 64 + lane]; RS_MFMA32B(wl2, xc[u]) }
                     }
                 }
 #pragma unroll
@@ -346,6 +368,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
                     const int i = XG * gi + u;
                     RS_MFMA32(wc[i], xc[u])
                     if (XH) { RS_MFMA16(hc[i < NCH ? i : 0], xc[u]) }
+                    if (RT == 2) { RS_MFMA32B(wc2[i < NC2 ? i : 0], xc[u]) }
                 }
 #pragma unroll
                 for (int u = 0; u < XG; ++u) xc[u] = xn[u];
@@ -359,12 +382,17 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         asm volatile("" : "+v"(te));
         const int el = te & 63, ebl = el & 31, eh = el >> 5;
         // query-slab weights of this wave's 32 attention dims: requested now, used after the cells (L2 hits)
-        float4 wq_a = make_float4(0.f, 0.f, 0.f, 0.f), wq_b = wq_a, wq_c = wq_a;
+        float4 wq_a = make_float4(0.f, 0.f, 0.f, 0.f), wq_b = wq_a, wq_c = wq_a, wq_d = wq_a;
         if (slab_wave) {
             const float* wq_l = p.wq_t + ((long)tile * RS_ATT + 32 * wave + ebl) * 8;
             wq_a = *reinterpret_cast<const float4*>(wq_l);
             wq_b = *reinterpret_cast<const float4*>(wq_l + 4);
             if (XH) wq_c = *reinterpret_cast<const float4*>(p.wq_t + ((long)xt * RS_ATT + 32 * wave + ebl) * 8 + 4 * xhalf);
+            if (RT == 2) {   // the pair's second tile: its 8 hidden units follow the first tile's in the slab's sum
+                const float* wq_l2 = p.wq_t + ((long)(tile + 1) * RS_ATT + 32 * wave + ebl) * 8;
+                wq_c = *reinterpret_cast<const float4*>(wq_l2);
+                wq_d = *reinterpret_cast<const float4*>(wq_l2 + 4);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + el] = acc[q];
@@ -393,22 +421,33 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
             }
             hs2[eb2 * 4 + eg2] = hval;
         }
-        if (cell_wave) {
-            float s[4];
+        // (a pair of tiles: `red` holds one tile's partial sums at a time - waves 0-3 finish the first tile's units, then every wave
+        // writes the second tile's sums and waves 4-7 finish those; 64 KB of `red` would push two k-groups per wave out of LDS)
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                float tt = 0.f;
+        for (int ph = 0; ph < RT; ++ph) {
+            if (ph == 1) {
+                rs_cbar();
 #pragma unroll
-                for (int w = 0; w < RS_WAVES; ++w) tt += red[(w * 16 + 4 * g + qq) * 64 + el];
-                s[qq] = tt;
+                for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + el] = acc2[q];
+                rs_cbar();
             }
-            float hval = 0.f;
-            if (ebl < B) {
-                const float p0 = s[0] + add4.x, p1 = s[1] + add4.y, p2 = s[2] + add4.z, p3 = s[3] + add4.w;
-                c_state = sigmoidf_(p1) * c_state + sigmoidf_(p0) * tanhf_(p2);
-                hval = sigmoidf_(p3) * tanhf_(c_state);
+            if (cell_wave && (wave >> 2) == ph) {
+                float s[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    float tt = 0.f;
+#pragma unroll
+                    for (int w = 0; w < RS_WAVES; ++w) tt += red[(w * 16 + 4 * g + qq) * 64 + el];
+                    s[qq] = tt;
+                }
+                float hval = 0.f;
+                if (ebl < B) {
+                    const float p0 = s[0] + add4.x, p1 = s[1] + add4.y, p2 = s[2] + add4.z, p3 = s[3] + add4.w;
+                    c_state = sigmoidf_(p1) * c_state + sigmoidf_(p0) * tanhf_(p2);
+                    hval = sigmoidf_(p3) * tanhf_(c_state);
+                }
+                hs[(ebl * RT + ph) * 8 + 2 * g + eh] = hval;
             }
-            hs[ebl * 8 + 2 * g + eh] = hval;
         }
         rs_cbar();
         RS_STAMP(6);
@@ -420,11 +459,17 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
             f32x16 qa;
 #pragma unroll
             for (int q = 0; q < 16; ++q) qa[q] = 0.f;
-            const float* hrow = hs + ebl * 8 + eh;
+            const float* hrow = hs + ebl * 8 * RT + eh;
             qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[0], eh ? wq_a.y : wq_a.x, qa, 0, 0, 0);
             qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[2], eh ? wq_a.w : wq_a.z, qa, 0, 0, 0);
             qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[4], eh ? wq_b.y : wq_b.x, qa, 0, 0, 0);
             qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[6], eh ? wq_b.w : wq_b.z, qa, 0, 0, 0);
+            if (RT == 2) {
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[8], eh ? wq_c.y : wq_c.x, qa, 0, 0, 0);
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[10], eh ? wq_c.w : wq_c.z, qa, 0, 0, 0);
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[12], eh ? wq_d.y : wq_d.x, qa, 0, 0, 0);
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[14], eh ? wq_d.w : wq_d.z, qa, 0, 0, 0);
+            }
             if (XH) {
                 const float* hrow2 = hs2 + ebl * 4 + eh;
                 qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow2[0], eh ? wq_c.y : wq_c.x, qa, 0, 0, 0);
@@ -447,7 +492,12 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         } else if (wave == 6) {
             if (ATT && t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);   // the slot's last reader, decoder LSTM (t - RS_HA_SLOTS), has finished
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(hdst + (long)tile * B * 8);
-            if (4 * el < 8 * B) store_sc1(rh, (unsigned)el * 16u, *reinterpret_cast<const float4*>(hs + 4 * el));
+            // (lane l: row l / 2, units 4 (l % 2) .. + 3 of the first tile; hs rows hold 8 RT units)
+            if (4 * el < 8 * B) store_sc1(rh, (unsigned)el * 16u, *reinterpret_cast<const float4*>(hs + (el >> 1) * 8 * RT + 4 * (el & 1)));
+        } else if (RT == 2 && wave == 7) {
+            if (t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);
+            const __amdgpu_buffer_rsrc_t rh = make_rsrc(hdst + (long)(tile + 1) * B * 8);
+            if (4 * el < 8 * B) store_sc1(rh, (unsigned)el * 16u, *reinterpret_cast<const float4*>(hs + (el >> 1) * 16 + 8 + 4 * (el & 1)));
         } else if (XH && wave == 7) {
             if (t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(hdst + (long)xt * B * 8);
@@ -459,9 +509,9 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         rs_cbar();
         RS_STAMP(9);
         // one wave instruction: lane r stores the workgroup's flag into replica r
-        if (tid < RS_REP) __hip_atomic_store(p.sync + (ATT ? RS_FLAG_ATT + bid : RS_FLAG_DEC + (bid - 96)) + tid * 128, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < RS_REP) __hip_atomic_store(p.sync + (ATT ? RS_FLAG_ATT + bid : RS_FLAG_DEC + (bid - dec0)) + tid * 128, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (ATT && tid < RS_REP + RS_REP1)   // ... and lanes 32 .. 39 the slab flags the attention rows watch (a line each)
-            __hip_atomic_store(p.sync + RS_FLAG_Q + ((tid - RS_REP) * 96 + bid) * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.sync + RS_FLAG_Q + ((tid - RS_REP) * dec0 + bid) * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         RS_WGSTAMP(3);
     }
     // final cell states (the launch-per-step loop keeps them in memory; callers that continue a sequence read them there)
@@ -472,17 +522,20 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
 __global__ __launch_bounds__(RS_THREADS) void decoder_resident_kernel(DecResidentParams p) {
     extern __shared__ __attribute__((aligned(16))) char rs_smem[];
     const int bid = (int)blockIdx.x;
-    const int off_ctrl = bid < 64 ? RsCfg<0>::OFF_CTRL : (bid < 96 ? RsCfg<1>::OFF_CTRL : RsCfg<2>::OFF_CTRL);
+    // kind of this workgroup: 224-workgroup deal 0 / 1 / 2, 192-workgroup deal 3 / 2      (uniform per workgroup)
+    const int kind = p.layout == 2 ? (bid < 64 ? 3 : 2) : (bid < 64 ? 0 : (bid < 96 ? 1 : 2));
+    const int off_ctrl = kind == 0 ? RsCfg<0>::OFF_CTRL : (kind == 1 ? RsCfg<1>::OFF_CTRL : (kind == 2 ? RsCfg<2>::OFF_CTRL : RsCfg<3>::OFF_CTRL));
     if (threadIdx.x < 64) reinterpret_cast<int*>(rs_smem + off_ctrl)[threadIdx.x] = 0;
     __syncthreads();
-    if (bid < 64) rs_body<0>(p, rs_smem, bid);        // uniform per workgroup
-    else if (bid < 96) rs_body<1>(p, rs_smem, bid);
-    else rs_body<2>(p, rs_smem, bid);
+    if (kind == 0) rs_body<0>(p, rs_smem, bid);
+    else if (kind == 1) rs_body<1>(p, rs_smem, bid);
+    else if (kind == 2) rs_body<2>(p, rs_smem, bid);
+    else rs_body<3>(p, rs_smem, bid);
 }
 
 #ifdef GVX_STAMPS
 hipError_t read_stamps_resident(unsigned long long* host480) {
-    return hipMemcpyFromSymbol(host480, HIP_SYMBOL(rs_stamps), sizeof(unsigned long long) * 480);
+    return hipMemcpyFromSymbol(host480, HIP_SYMBOL(rs_stamps), sizeof(unsigned long long) * 480);   // (kinds 0 - 2; kind 3's rows follow)
 }
 hipError_t read_wg_stamps_resident(unsigned long long* host896) {
     return hipMemcpyFromSymbol(host896, HIP_SYMBOL(rs_wg_stamps), sizeof(unsigned long long) * 896);
@@ -501,13 +554,14 @@ hipError_t decoder_resident_init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
 }
 
-bool decoder_resident_supported(int B, int L) { return attention_persistent_layout(B, L) == 1; }
+bool decoder_resident_supported(int B, int L) { const int lay = attention_persistent_layout(B, L); return lay == 1 || lay == 2; }
 
 hipError_t launch_decoder_resident(const DecResidentParams& p, hipStream_t s) {
     if (p.B < 1 || p.B > 32 || p.T < 1 || !p.att_frag || !p.dec_frag || !p.att_bias || !p.dec_bias || !p.wq_t || !p.pre_gate || !p.h_a ||
         !p.hc || !p.q_slab || !p.c_a || !p.c_d || !p.sync)
         return hipErrorInvalidValue;
-    decoder_resident_kernel<<<dim3(224), dim3(RS_THREADS), RS_LDS_BYTES, s>>>(p);
+    if (p.layout != 1 && p.layout != 2) return hipErrorInvalidValue;
+    decoder_resident_kernel<<<dim3(p.layout == 2 ? 192 : 224), dim3(RS_THREADS), RS_LDS_BYTES, s>>>(p);
     return hipGetLastError();
 }
 

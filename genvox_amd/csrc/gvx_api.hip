@@ -1176,7 +1176,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
                                                                // workgroups); 3: 33 .. 64 rows (64 CUs, 384 workgroups, two per CU)
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
     // ... and the LSTM launches as ONE resident kernel too (dec_resident.hip): inference mode, one batch tile, L <= 128
-    const bool resident = pa && pa_layout == 1 && m->tf_resident && !train && decoder_resident_supported(B, L);
+    const bool resident = pa && (pa_layout == 1 || pa_layout == 2) && m->tf_resident && !train && decoder_resident_supported(B, L);
     if (pa && !prenet_done) {   // (the fused forward has taken a side stream for this call already: the encoder ran on it)
         rc = ensure_side_stream(m);
         if (rc != GVX_OK) return rc;
@@ -1349,7 +1349,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         rp.sync = sync;
         rp.att_frag_bytes = (unsigned)(frag_floats(4 * d.att_rnn_dim, P + E + d.att_rnn_dim) * sizeof(float));
         rp.dec_frag_bytes = (unsigned)(frag_floats(4 * D, d.att_rnn_dim + E + D) * sizeof(float));
-        rp.B = B; rp.T = T; rp.spin_limit = m->spin_limit;
+        rp.B = B; rp.T = T; rp.spin_limit = m->spin_limit; rp.layout = pa_layout;
         { static const int dbg = [] { const char* e = std::getenv("GVX_RS_DEBUG"); return e ? std::atoi(e) : 0; }(); rp.debug = dbg; }
         if (kt) HIP_TRY(hipEventRecord(m->kev[0], s));
         HIP_TRY(launch_decoder_resident(rp, s));
@@ -1522,7 +1522,7 @@ int gvx_teacher_forced_resident(const gvx_model* m, int B, int L) {
 int gvx_teacher_forced_loop_kind(const gvx_model* m, int B, int L) {
     if (!m || B < 1 || L < 1) return 0;
     if (!persistent_path(m, B, L)) return 0;
-    return m->tf_resident && attention_persistent_layout(B, L) == 1 && decoder_resident_supported(B, L) ? 2 : 1;
+    return m->tf_resident && decoder_resident_supported(B, L) ? 2 : 1;
 }
 
 int gvx_model_set_persistent_attention(gvx_model* m, int enable) {

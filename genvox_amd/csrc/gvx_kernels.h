@@ -239,7 +239,7 @@ struct AttnPersistParams {
 // profiles/r04_stamps_resident_stationary_v1.txt).  A producer stores its flag into every replica with ONE wave instruction (lane r
 // -> replica r); a reader polls the replica of its index modulo RS_REP: 7 readers per line.
 constexpr int RS_REP = 32;
-constexpr int RS_FLAG_ATT = 8192;                        // [RS_REP][128] attention-LSTM workgroup i (< 96) has published h_a and its query slab of steps < value
+constexpr int RS_FLAG_ATT = 8192;                        // [RS_REP][128] attention-LSTM workgroup i (< 96 / 64) has published h_a and its query slab of steps < value
 constexpr int RS_FLAG_DEC = RS_FLAG_ATT + RS_REP * 128;  // [RS_REP][128] decoder-LSTM workgroup i has published h_d of steps < value
 // The two hand-offs ON the step's chain - contexts to the attention-LSTM workgroups, query slabs to the attention rows - use flags
 // on lines of their own (one writer per line: 32 stores into one line took up to 1 us to be acknowledged), in RS_REP1 replicas:
@@ -260,7 +260,9 @@ struct DecResidentParams {
     unsigned att_frag_bytes, dec_frag_bytes;   // bounds of the loader's buffer descriptors
     int B, T;
     unsigned spin_limit;            // polls without progress before the poller gives up (0 = HANDOFF_SPIN_LIMIT)
-    int debug;                      // timing experiments only (GVX_RS_DEBUG; wrong results): 1 consumers ignore the gates, 2 ignore `landed`, 4 no DMA
+    int debug;                      // timing experiments only (GVX_RS_DEBUG: sleeps between polls)
+    int layout;                     // 1: 224 workgroups beside one attention workgroup per row (L <= 128); 2: 192 workgroups - 64 pairs of
+                                    // attention-LSTM tiles + 128 decoder-LSTM tiles - beside two per row (128 < L <= 256)
 };
 bool decoder_resident_supported(int B, int L);
 hipError_t decoder_resident_init();

@@ -315,7 +315,9 @@ def _ragged_batch(mc, ac, tc, B, L, T, seed):
     return batch
 
 
-@pytest.mark.parametrize("B,L,T", [(7, 100, 33), (32, 128, 24), (1, 1, 1), (32, 5, 2), (17, 127, 9), (3, 64, 70)])
+@pytest.mark.parametrize("B,L,T", [(7, 100, 33), (32, 128, 24), (1, 1, 1), (32, 5, 2), (17, 127, 9), (3, 64, 70),
+                                   # 128 < L <= 256: 192 workgroups (pairs of attention-LSTM tiles) beside two attention workgroups per row
+                                   (3, 129, 6), (32, 190, 12), (5, 143, 9), (1, 256, 4), (32, 256, 3), (9, 200, 40)])
 def test_resident_decoder_equals_launch_per_step(B, L, T, monkeypatch):
     """The teacher-forced loop as ONE resident weight-streaming kernel (dec_resident.hip: loader ring in LDS, hand-offs by
     flags; the default for B <= 32, L <= 128) against the same loop as a launch per step (GVX_TF_RESIDENT=0: skinny.hip beside

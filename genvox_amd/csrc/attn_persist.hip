@@ -141,7 +141,6 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     float* qs = smem + PA_OFF_QS;
     float* es = smem + PA_OFF_ES;
     float* vl = smem + PA_OFF_V;
-    float* cp = smem + PA_OFF_CP;
     volatile int* leave = reinterpret_cast<volatile int*>(smem + PA_OFF_FLAG);
 
     const int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, hf = SPLIT ? (int)(blockIdx.x & 1) : 0;
@@ -159,10 +158,11 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     if (tid == 0) __hip_atomic_fetch_add(p.sync + HANDOFF_READY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident
 
     // ---- resident operands
-    // memory: thread (e4 = float4 column, lg = group of 16 positions) holds memory[b][16 lg + i][e4], i < 16
+    // memory: thread (e4 = float4 column, lg = group of 16 positions) holds memory[b][16 lg + i][e4], i < 16.  The 8 position
+    // groups of a column sit in 8 neighbouring lanes: the context's sum over them is three DPP adds, no LDS, no barrier
     float4 mem[16];
     {
-        const int e4 = tid & 127, lg = tid >> 7;
+        const int e4 = tid >> 3, lg = tid & 7;
         const float4* mb = reinterpret_cast<const float4*>(p.memory) + ((long)b * p.L + l_base) * (PA_E / 4);
 #pragma unroll
         for (int i = 0; i < 16; ++i) mem[i] = mb[(long)min(16 * lg + i, L - 1) * (PA_E / 4) + e4];
@@ -257,7 +257,8 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         PA_STAMP(1);
         int tq = tid;
         asm volatile("" : "+v"(tq));
-        const int lane = tq & 63, e4 = tq & 127, lg = tq >> 7, el = tq >> 3, dg = tq & 7;
+        const int lane = tq & 63, e4 = tq >> 3, lg = tq & 7, el = tq >> 3, dg = tq & 7;
+        const bool cl = lg == 0;   // the lane of its column that stores / exchanges the context
         {
             const int d4 = tq & 31, sg = tq >> 5;   // slabs SPG sg .. SPG sg + SPG - 1 (one slab per workgroup / tile of the attention LSTM)
             float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -266,13 +267,16 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             for (int i = 0; i < SPG; ++i) ql[i] = load_sc1(rq, (unsigned)(((SPG * sg + i) * B + b) * PA_A + 4 * d4) * 4u);
 #pragma unroll
             for (int i = 0; i < SPG; ++i) { s4.x += ql[i].x; s4.y += ql[i].y; s4.z += ql[i].z; s4.w += ql[i].w; }
-            reinterpret_cast<float4*>(qp)[sg * 32 + d4] = s4;
+            // the wave's two slab groups (lanes l, l ^ 32) first: 16 partial rows instead of 32 for the second stage
+            if (!SPLIT) { s4.x += __shfl_xor(s4.x, 32, 64); s4.y += __shfl_xor(s4.y, 32, 64);
+            s4.z += __shfl_xor(s4.z, 32, 64); s4.w += __shfl_xor(s4.w, 32, 64);
+            if ((tq & 32) == 0) reinterpret_cast<float4*>(qp)[(sg >> 1) * 32 + d4] = s4; } else reinterpret_cast<float4*>(qp)[sg * 32 + d4] = s4;
         }
         __syncthreads();
         if (tq < PA_A) {
             float acc = qp[tq];
-#pragma unroll 8
-            for (int g = 1; g < 32; ++g) acc += qp[g * PA_A + tq];
+#pragma unroll
+            for (int g = 1; g < (SPLIT ? 32 : 16); ++g) acc += qp[g * PA_A + tq];
             qs[tq] = acc;
         }
         __syncthreads();
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         for (int l = lane; l < L; l += 64) sum += __expf(es[l] - mref);
         sum = wave_sum_dpp(sum);
         float inv = SPLIT ? 1.f : 1.f / sum;   // SPLIT: the context partials stay unnormalised until the halves have met
+        float4 o_ctx;
         {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -314,8 +319,11 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
                 const float w = l < L ? __expf(es[l] - mref) * inv : 0.f;   // exactly 0 past the row's length (exp(-inf))
                 acc.x = fmaf(w, mem[i].x, acc.x); acc.y = fmaf(w, mem[i].y, acc.y);
                 acc.z = fmaf(w, mem[i].z, acc.z); acc.w = fmaf(w, mem[i].w, acc.w);
+                // (the split variant has no registers to spare: without this the scheduler computes all 16 weights first and
+                // spills three of the resident memory vectors to make room - three scratch round trips per step on the chain)
             }
-            reinterpret_cast<float4*>(cp)[lg * 128 + e4] = acc;
+            acc.x = sum8(acc.x); acc.y = sum8(acc.y); acc.z = sum8(acc.z); acc.w = sum8(acc.w);   // over the column's 8 position groups
+            o_ctx = acc;
         }
         if (!SPLIT && wave == 0) {   // alignment row out; previous / cumulative weights for the next location features
             for (int l = lane; l < L; l += 64) {
@@ -325,18 +333,15 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
                 wc[PA_WC_S + pad + l] += w;
             }
         }
-        __syncthreads();
         PA_STAMP(4);
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tq < 128) {
-            o = reinterpret_cast<const float4*>(cp)[tq];
-#pragma unroll
-            for (int g = 1; g < 8; ++g) {
-                const float4 x = reinterpret_cast<const float4*>(cp)[g * 128 + tq];
-                o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w;
-            }
-        }
+        float4 o = o_ctx;
         if (SPLIT) {
+            // (indices re-derived from a fresh opaque copy of the thread id: kept live from the top of the step they cost this
+            // variant - 80 resident VGPRs - its last free registers)
+            int tx = tid;
+            asm volatile("" : "+v"(tx));
+            const int e4x = tx >> 3;
+            const bool clx = (tx & 7) == 0;
             // ---- hand (m, s, c, edge energies) to the partner half and take its; buffers alternate with the step's parity
             // (a half can be at most one publication ahead of what its partner has read)
             float* const xb_own = p.xchg + (((long)b * 2 + hf) * 2 + (t & 1)) * PA_XCH;
@@ -345,10 +350,10 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             const unsigned* const flag_par = p.sync + HANDOFF_PAIR + (b * 2 + (hf ^ 1)) * 32;
             {
                 const __amdgpu_buffer_rsrc_t ro = make_rsrc(xb_own);
-                if (tq < 128) store_sc1(ro, (unsigned)tq * 16u, o);
-                else if (tq == 128) store_sc1(ro, 512u * 4u, make_float4(mx, sum, 0.f, 0.f));
-                else if (tq >= 132 && tq < 136) {   // the 16 energies next to the cut: the last 16 positions of half 0, the first 16 of half 1
-                    const int i4 = tq - 132, e0 = hf == 0 ? PA_L - 16 : 0;
+                if (clx) store_sc1(ro, (unsigned)e4x * 16u, o);
+                else if (tx == 129) store_sc1(ro, 512u * 4u, make_float4(mx, sum, 0.f, 0.f));
+                else if (tx >= 132 && tx < 136) {   // the 16 energies next to the cut: the last 16 positions of half 0, the first 16 of half 1
+                    const int i4 = tx - 132, e0 = hf == 0 ? PA_L - 16 : 0;
                     store_sc1(ro, (516u + 4u * (unsigned)i4) * 4u, *reinterpret_cast<const float4*>(es + e0 + 4 * i4));
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the flag goes up
@@ -362,13 +367,13 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             if (*leave) break;
             const __amdgpu_buffer_rsrc_t rp = make_rsrc(xb_par);
             const float4 hd = load_sc1(rp, 512u * 4u);                          // partner's (m, s)
-            const float4 cpar = tq < 128 ? load_sc1(rp, (unsigned)tq * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 cpar = clx ? load_sc1(rp, (unsigned)e4x * 16u) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float m0 = hf == 0 ? mx : hd.x, m1 = hf == 0 ? hd.x : mx;     // operands in half order: both halves compute the same bits
             const float s0 = hf == 0 ? sum : hd.y, s1 = hf == 0 ? hd.y : sum;
             const float M = fmaxf(m0, m1);                                      // finite: position 0 of half 0 is never masked
             const float f0 = m0 == -INFINITY ? 0.f : __expf(m0 - M), f1 = m1 == -INFINITY ? 0.f : __expf(m1 - M);
             inv = 1.f / (s0 * f0 + s1 * f1);
-            if (tq < 128) {
+            if (clx) {
                 const float4 c0 = hf == 0 ? o : cpar, c1 = hf == 0 ? cpar : o;
                 o.x = (c0.x * f0 + c1.x * f1) * inv; o.y = (c0.y * f0 + c1.y * f1) * inv;
                 o.z = (c0.z * f0 + c1.z * f1) * inv; o.w = (c0.w * f0 + c1.w * f1) * inv;
@@ -391,15 +396,17 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
                 }
             }
         }
-        if (tq < 128 && hf == 0) {
+        if (cl && hf == 0) {
             // blocked context vector [E/8][B][8] of step t, write-through
             const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.ctx_base + (long)t * p.ctx_ts);
-            store_sc1(rc, (unsigned)((tq >> 1) * B * 8 + b * 8 + 4 * (tq & 1)) * 4u, o);
+            store_sc1(rc, (unsigned)((e4 >> 1) * B * 8 + b * 8 + 4 * (e4 & 1)) * 4u, o);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         if (p.ctx_flags) {   // one wave instruction: lane r stores the row's flag into replica r
-            if (tid < RS_REP1 && hf == 0) __hip_atomic_store(p.ctx_flags + (tid * 32 + b) * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int tf = tid;   // (address from an opaque copy of the thread id: hoisted out of the loop it was spilled and reloaded here)
+            asm volatile("" : "+v"(tf));
+            if (tf < RS_REP1 && hf == 0) __hip_atomic_store(p.ctx_flags + (tf * 32 + b) * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (tid == 0 && hf == 0) __hip_atomic_fetch_add(cnt_ctx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PA_STAMP(5);
 #ifdef GVX_STAMPS

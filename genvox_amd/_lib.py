@@ -108,6 +108,7 @@ SIGNATURES = {
     "gvx_teacher_forced_rows_per_call": (_i, [_vp, _i]),
     "gvx_teacher_forced_resident": (_i, [_vp, _i, _i]),
     "gvx_teacher_forced_loop_kind": (_i, [_vp, _i, _i]),
+    "gvx_autoregressive_loop_kind": (_i, [_vp, _i, _i]),
     "gvx_kernel_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i)]),
 }
 

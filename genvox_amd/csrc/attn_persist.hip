@@ -55,10 +55,13 @@ constexpr int PA_OFF_ES = PA_OFF_QS + PA_A;                    // [128] energies
 constexpr int PA_OFF_V = PA_OFF_ES + PA_L;                     // [128] v
 constexpr int PA_OFF_CP = PA_OFF_V + PA_A;                     // [8][512] context partial sums
 constexpr int PA_OFF_FLAG = PA_OFF_CP + 8 * PA_E;              // [4] "leave the loop" word of the step's wait
-constexpr int PA_LDS_FLOATS = PA_OFF_FLAG + 4;
+constexpr int PA_OFF_H1 = PA_OFF_FLAG + 4;                     // [256] autoregressive role: Prenet layer 1 of the row
+constexpr int PA_LDS_FLOATS = PA_OFF_H1 + 256;
+constexpr int PA_P = 256;      // Prenet width (autoregressive role)
+constexpr int PA_KPT = 5;      // layer-1 k values per thread: n_mels <= 16 PA_KPT
 static_assert(PA_LDS_FLOATS * 4 <= 160 * 1024, "persistent attention LDS");
 static_assert((PA_OFF_FB % 4) == 0 && (PA_OFF_CW % 4) == 0 && (PA_OFF_WD % 4) == 0 && (PA_OFF_QP % 4) == 0 && (PA_OFF_QS % 4) == 0 &&
-              (PA_OFF_V % 4) == 0 && (PA_OFF_CP % 4) == 0, "float4 alignment");
+              (PA_OFF_V % 4) == 0 && (PA_OFF_CP % 4) == 0 && (PA_OFF_H1 % 4) == 0, "float4 alignment");
 
 __device__ __forceinline__ float fast_tanh(float x) {   // as attention.hip
     const float e = __expf(2.f * x);
@@ -129,7 +132,11 @@ __device__ __forceinline__ bool flags_wait(const unsigned* flags, int n, unsigne
 #ifdef GVX_STAMPS
 namespace { __device__ unsigned long long pa_row_stamps[64][8]; }   // per resident workgroup: the phase stamps of step 20
 #endif
-template <int SPG, bool SPLIT>
+// AR (beside decoder_ar_resident_kernel, dec_resident.hip): after its context the row also finishes the step - it sums the 128
+// projection slabs of the decoder-LSTM tiles into the frame + gate of the step (Decoder.decode's linear projection and gate
+// layer, models/tts/tacotron2.py:360-362), runs the stop test (:401-406) and Prenet layer 1 on the frame (:176-179) and hands
+// that to the 8 workgroups of layer 2.  Same arithmetic and summation orders as ar_project_fast_kernel (misc.hip).
+template <int SPG, bool SPLIT, bool AR = false>
 __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersistParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* locf = smem + PA_OFF_LOC;
@@ -415,6 +422,98 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         // ---- off the chain: location features of step t + 1
         if (t + 1 < p.T) location_features();
         PA_STAMP(6);
+        if (AR) {
+            int ta = tid;
+            asm volatile("" : "+v"(ta));
+            // (the role's parameters are read from the kernel-argument segment every step: kept in scalar registers for the whole
+            // loop they pushed other scalars into lanes of vector registers, and one of the resident memory vectors into scratch)
+            typedef const __attribute__((address_space(4))) AttnPersistParams* KargPtr;
+            KargPtr kp = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            const bool more = t + 1 < p.T;   // (the last step: nobody consumes a next Prenet input)
+            const int M = kp->n_mels, PSB = kp->PSB;
+            float4* sp4 = reinterpret_cast<float4*>(qp);                  // [32][32]
+            float4* l1p = reinterpret_cast<float4*>(smem + PA_OFF_CP);    // [16][64]
+            float* mel = qs;                                              // [128]
+            float* h1 = smem + PA_OFF_H1;                                 // [256]
+            if (wave == 0 && !flags_wait(kp->p_flags + (b % RS_REP_P) * 128 * 32, 128, (unsigned)t + 1u, tmo, 0x600u + (unsigned)b, kp->spin_limit, stop, (kp->debug & 32) != 0) && (tid & 63) == 0) *leave = 1;
+            __syncthreads();
+            if (*leave) break;
+            // ---- the slabs of the step (the only loads that depend on the wait) and, behind them, this thread's layer-1 weights
+            const int n4c = PSB >> 2;                 // float4 per slab row (<= 24)
+            const int sg = ta / n4c, n4 = ta - sg * n4c;
+            if (sg < 32) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(kp->p_slab);
+                float4 sv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sv[q] = load_sc1(rs, (unsigned)(((4 * sg + q) * B + b) * PSB + 4 * n4) * 4u);
+                float4 acc = sv[0];
+                acc.x += sv[1].x; acc.y += sv[1].y; acc.z += sv[1].z; acc.w += sv[1].w;
+                acc.x += sv[2].x; acc.y += sv[2].y; acc.z += sv[2].z; acc.w += sv[2].w;
+                acc.x += sv[3].x; acc.y += sv[3].y; acc.z += sv[3].z; acc.w += sv[3].w;
+                sp4[sg * 32 + n4] = acc;
+            }
+            __syncthreads();
+            if (ta < 128) {
+                float v = 0.f;
+                if (ta <= M) {
+                    const float* col = reinterpret_cast<const float*>(sp4) + ta;
+                    float acc = col[0];
+#pragma unroll 4
+                    for (int q = 1; q < 32; ++q) acc += col[q * 128];   // (4 at a time: the layer-1 weights are waiting in registers)
+                    v = acc + kp->proj_b[ta];
+                    kp->proj_out[(long)t * B * PSB + (long)(ta >> 3) * B * 8 + b * 8 + (ta & 7)] = v;
+                    if (ta == M && kp->n_frames[b] == 0) {
+                        const float sgm = 1.f / (1.f + expf(-v));
+                        if (sgm > kp->gate_threshold) {
+                            kp->n_frames[b] = t + 1;
+                            atomicAdd(kp->n_done, 1);
+                        }
+                    }
+                }
+                mel[ta] = ta < M ? v : 0.f;   // zeros past the mel bins: clamped weight loads contribute nothing
+            }
+            __syncthreads();
+            const int kq1 = ta >> 6, j4 = ta & 63;    // layer 1: 16 k slices x 64 float4 columns
+            unsigned char k0 = 0;
+            if (more) {
+                // (this thread's layer-1 weights are L2 hits, the same for every row and step; the kernel has no 20 registers to hold
+                // them across the slab sum, so their round trip is paid here)
+                float4 w0v[PA_KPT];
+                const float4* w0 = reinterpret_cast<const float4*>(kp->pre_w0_t) + j4;
+#pragma unroll
+                for (int i = 0; i < PA_KPT; ++i) w0v[i] = w0[min(kq1 * PA_KPT + i, M - 1) * (PA_P / 4)];
+                if (ta < PA_P) k0 = kp->keep0[((long)(t + 1) * B + b) * PA_P + ta];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < PA_KPT; ++i) {
+                    const float x = mel[kq1 * PA_KPT + i];
+                    acc.x = fmaf(w0v[i].x, x, acc.x); acc.y = fmaf(w0v[i].y, x, acc.y);
+                    acc.z = fmaf(w0v[i].z, x, acc.z); acc.w = fmaf(w0v[i].w, x, acc.w);
+                }
+                l1p[kq1 * 64 + j4] = acc;
+            }
+            __syncthreads();
+            if (more && ta < PA_P) {
+                const float* col = reinterpret_cast<const float*>(l1p) + ta;
+                float acc = col[0];
+#pragma unroll
+                for (int q = 1; q < 16; ++q) acc += col[q * 256];
+                acc = fmaxf(acc, 0.f);
+                h1[ta] = k0 ? 2.f * acc : 0.f;
+            }
+            __syncthreads();
+            if (ta < 64) {
+                if (more) {   // blocked vector [P/8][B][8], write-through
+                    const __amdgpu_buffer_rsrc_t ry = make_rsrc(kp->y1);
+                    store_sc1(ry, (unsigned)((ta >> 1) * B * 8 + b * 8 + 4 * (ta & 1)) * 4u, reinterpret_cast<const float4*>(h1)[ta]);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and the stop test's counter has arrived (wave 1's atomic below)
+            }
+            if (wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ta == 0) __hip_atomic_store(kp->y1_flags + b * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -445,6 +544,7 @@ hipError_t attention_persistent_init() {
     hipError_t e;
     if ((e = pa_set_lds(attn_persistent_kernel<3, false>)) != hipSuccess) return e;
     if ((e = pa_set_lds(attn_persistent_kernel<4, false>)) != hipSuccess) return e;
+    if ((e = pa_set_lds(attn_persistent_kernel<3, false, true>)) != hipSuccess) return e;
     return pa_set_lds(attn_persistent_kernel<2, true>);
 }
 
@@ -469,6 +569,11 @@ hipError_t launch_attention_persistent(const AttnPersistParams& p, hipStream_t s
     if (p.L > PA_L) {
         if (p.n_slabs != 64 || !p.xchg) return hipErrorInvalidValue;
         attn_persistent_kernel<2, true><<<dim3(2 * p.B), dim3(PA_THREADS), lds, s>>>(p);
+    } else if (p.p_slab) {   // autoregressive role beside decoder_ar_resident_kernel
+        if (p.n_slabs != PA_SLABS || !p.q_flags || !p.ctx_flags || !p.p_flags || !p.y1_flags || !p.proj_b || !p.proj_out || !p.pre_w0_t || !p.keep0 ||
+            !p.y1 || !p.n_frames || !p.n_done || p.n_mels < 1 || p.n_mels > 16 * PA_KPT || p.PSB < p.n_mels + 1 || p.PSB > 96 || (p.PSB & 3))
+            return hipErrorInvalidValue;
+        attn_persistent_kernel<3, false, true><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
     } else if (p.n_slabs == PA_SLABS) attn_persistent_kernel<3, false><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
     else if (p.n_slabs == PA_SLABS_AR) attn_persistent_kernel<4, false><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
     else return hipErrorInvalidValue;

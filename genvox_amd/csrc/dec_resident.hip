@@ -67,6 +67,23 @@ constexpr int RC_HD = 2;           // steps whose h_d every decoder-LSTM workgro
 constexpr int RC_ABORT = 3;        // != 0: a wait of this workgroup has given up - every wait returns at once, the workgroup drains
 constexpr int RC_LOCK = 4;         // the wave that holds it polls the global flags for the workgroup
 constexpr int RC_IDLE = 5;         // polls since the last one that moved a word (the bound of the waits)
+constexpr int RC_PRE = 6;          // autoregressive loop: steps whose Prenet output every Prenet workgroup has published (value t: input of step t)
+constexpr int RC_Y1 = 7;           // ... whose Prenet layer 1 every attention row has published
+constexpr int RC_EXIT = 8;         // [2] by step parity: "the workgroup leaves after this step" (written before the step's last barrier)
+
+// Everything the two kernels of this file take (the launchers fill it from DecResidentParams / ArResidentParams)
+struct RsArgs {
+    const float* att_frag; const float* att_bias; const float* wq_t; const float* dec_frag; const float* dec_bias;
+    const float* pre_gate;                                          // teacher-forced loop only
+    const float* proj_hd_t; const float* proj_ctx_t; const float* pre_w1; const uint8_t* keep1;   // autoregressive loop only ...
+    float* prenet; const float* y1; float* p_slab; const int32_t* n_done; int PSB;
+    float* h_a; float* hc; float* q_slab; float* c_a; float* c_d;
+    unsigned* sync;
+    unsigned att_frag_bytes;
+    int B, T;
+    unsigned spin_limit;
+    int debug, layout;
+};
 
 #ifdef GVX_STAMPS
 // diagnostic build (tools/stamps_resident.py): wall-clock stamps (10 ns) of decoder step RS_STAMP_T in one workgroup of each kind
@@ -88,6 +105,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 
 struct RsPoll {   // what a poll needs: the flag words, the status word, sizes
     const unsigned* f_att; const unsigned* f_dec; const unsigned* f_ctx; unsigned* tmo;
+    const unsigned* f_pre; const unsigned* f_y1; const unsigned* stop;   // autoregressive loop (nullptr otherwise)
     unsigned limit; int B, T, bid;
     int n_att;   // attention-LSTM workgroups (96 in the 224-workgroup deal, 64 pairs in the 192-workgroup one)
     int sleep;   // s_sleep units between two looks of the polling wave (GVX_RS_DEBUG experiments)
@@ -106,8 +124,12 @@ __device__ __forceinline__ void rs_poll_once(int* ctrl, const RsPoll& q, int lan
         const unsigned d0 = __hip_atomic_load(q.f_dec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned d1 = __hip_atomic_load(q.f_dec + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         v = min(d0, d1);
-    } else {
+    } else if (word == RC_CTX) {
         v = lane < q.B ? __hip_atomic_load(q.f_ctx + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;   // (a flag per 128-byte line)
+    } else if (word == RC_PRE) {
+        v = lane < 8 ? __hip_atomic_load(q.f_pre + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+    } else {
+        v = lane < q.B ? __hip_atomic_load(q.f_y1 + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: nothing below moves above the loads
 #ifdef GVX_STAMPS
@@ -130,6 +152,8 @@ __device__ __forceinline__ void rs_poll_once(int* ctrl, const RsPoll& q, int lan
     idle = __builtin_amdgcn_readfirstlane(idle);
     if (idle == 0 || (idle & 15) != 0) return;
     bool give_up = __hip_atomic_load(q.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // somebody else has timed out (wave-uniform address)
+    // (autoregressive loop: every row has fired its stop token - the loop is over, the waits end like those of a time-out, but without one)
+    if (q.stop && __hip_atomic_load(q.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) give_up = true;
     if ((unsigned)idle > q.limit) {
         if (lane == 0) __hip_atomic_store(q.tmo, 0x500u + (unsigned)(q.bid & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         give_up = true;
@@ -167,6 +191,21 @@ __device__ __forceinline__ void rs_cbar() {
     asm volatile("" ::: "memory");
 }
 
+// one LDS-DMA piece: 64 lanes x 16 bytes from rsrc + voff + soff to LDS lds_addr + 16 lane (M0: written in the same statement,
+// restored afterwards - the compiler owns it; s_nop 0: M0 write -> LDS-DMA read)
+typedef __attribute__((ext_vector_type(4))) unsigned rs_u32x4;
+__device__ __forceinline__ rs_u32x4 rs_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    rs_u32x4 r;
+    r.x = (unsigned)a; r.y = (unsigned)(a >> 32) & 0xffffu; r.z = bytes; r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void rs_glds(rs_u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 #define RS_MFMA32(W, X)                                                   \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((W).x, (X).x, acc, 0, 0, 0); \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((W).y, (X).y, acc, 0, 0, 0); \
@@ -186,8 +225,8 @@ __device__ __forceinline__ void rs_cbar() {
 
 }  // namespace
 
-template <int KIND>
-__device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, const int bid) {
+template <int KIND, bool AR>
+__device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int bid) {
     using Cfg = RsCfg<KIND>;
     constexpr bool XH = Cfg::XH, ATT = Cfg::ATT;
     constexpr int NN = Cfg::NN, NC = Cfg::NC, NRN = Cfg::NRN, NLN = Cfg::NLN;
@@ -217,6 +256,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
     unsigned* const tmo_w = p.sync + HANDOFF_TIMEOUT;
     const int rep = bid % RS_REP;   // the flag replica this workgroup reads
     const RsPoll poll{p.sync + RS_FLAG_ATT + rep * 128, p.sync + RS_FLAG_DEC + rep * 128, p.sync + RS_FLAG_CTX + (bid % RS_REP1) * 32 * 32, tmo_w,
+                      AR ? p.sync + RS_FLAG_PRE + (bid % RS_REP_PRE) * 8 * 32 : nullptr, AR ? p.sync + RS_FLAG_Y1 : nullptr, AR ? p.sync + HANDOFF_STOP : nullptr,
                       (p.spin_limit ? p.spin_limit : HANDOFF_SPIN_LIMIT) * 16u, B, T, bid, dec0,
                       (!ATT && (p.debug & 16)) ? 32 : ((p.debug & 8) ? 8 : 0)};
     const int bl = lane & 31, h = lane >> 5;
@@ -258,6 +298,26 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         if (XH && x_mine) lh[i * 32 + hidx] = wx[(long)(kn0 + NRN + i) * 64];
     }
 
+    // ---- autoregressive loop: the Prenet columns (k-groups [0, 32) of the attention-LSTM matrix, 4 per wave) cannot be applied
+    // before the loop.  Single tiles keep them in 16 more registers; a tile + half workgroup has neither registers nor LDS left
+    // (48 KB) and stages them every step by LDS-DMA into the partial-sum regions `red` / `red2`, which are free during the
+    // step's products: 6 KB per wave = 4 tile fragments + 4 half fragments, L2 hits, no register passes through
+    constexpr int NP = (AR && KIND == 1) ? 4 : 1;
+    float4 wp[NP], w1f[NP];
+    const bool l2_wg = AR && KIND == 1 && bid - 64 < 8;   // the 8 workgroups that also run Prenet layer 2 (32 output units each)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        wp[i] = (AR && KIND == 1) ? wt[(long)(4 * wave + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // layer-2 fragment: lane (n, h) holds W1[32 i2 + n][8 kg + 4 h .. + 3], kg = 4 wave + i
+        w1f[i] = l2_wg ? *reinterpret_cast<const float4*>(p.pre_w1 + (long)(32 * (bid - 64) + bl) * RS_P + 8 * (4 * wave + i) + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const rs_u32x4 rw_att = rs_rsrc(p.att_frag, p.att_frag_bytes);
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned stage_t = lds_base + (unsigned)Cfg::OFF_RED + (unsigned)wave * 4096u;    // [4][64] float4
+    const unsigned stage_h = lds_base + (unsigned)Cfg::OFF_RED2 + (unsigned)wave * 2048u;   // [4][32] float4
+    // half tile: lanes 0-31 fetch the 32 lanes of the fragment that hold rows 16 xhalf .. + 15 of a k-group, lanes 32-63 those of the next
+    const unsigned v_half = (((unsigned)bl < 16u ? 16u * (unsigned)xhalf + (unsigned)bl : 32u + 16u * (unsigned)xhalf + ((unsigned)bl - 16u)) * 16u) + (unsigned)h * 1024u;
+
     // per-lane constants of the epilogue: cell state (registers for the whole loop), bias, query-slab weights
     const bool cell_wave = wave < 4 * RT;
     const bool cell2_wave = XH && (wave == 4 || wave == 5);
@@ -275,7 +335,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         if (b2 < B) c_state = c_mem[(long)b2 * H + j2];
         bias4 = *reinterpret_cast<const float4*>(bias + xt * 32 + 4 * jloc2);
     }
-    const bool slab_wave = ATT && wave < RS_ATT / 32;
+    const bool slab_wave = ATT ? wave < RS_ATT / 32 : (AR && wave < 3);   // (autoregressive loop: the decoder-LSTM tiles emit projection slabs, PSB <= 96 dims)
 
 #ifdef GVX_STAMPS
     const bool stamp_wg = bid == 0 || bid == 64 || bid == dec0;
@@ -286,7 +346,14 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         // ---- the step's addend (attention LSTM: the Prenet columns, applied to all steps before the loop): its round trip hides
         // under the products
         float4 add4 = bias4;
-        if (ATT) {
+        if (AR && XH) {   // this step's Prenet-column fragments on their way into LDS (every reader of `red` / `red2` has passed the barrier that ended the last step)
+            const unsigned kg = (unsigned)(4 * wave);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs_glds(rw_att, (unsigned)lane * 16u, ((unsigned)tile * NKGW + kg + (unsigned)i) * 1024u, stage_t + (unsigned)i * 1024u);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rs_glds(rw_att, v_half, ((unsigned)xt * NKGW + kg + 2u * (unsigned)i) * 1024u, stage_h + (unsigned)i * 1024u);
+        }
+        if (ATT && !AR) {
             if (cell_wave && bl < B) {
                 const float4 ad = *reinterpret_cast<const float4*>(p.pre_gate + ((long)t * B + bl) * 4 * RS_A + ctile * 32 + 8 * g + 4 * h);
                 add4.x += ad.x; add4.y += ad.y; add4.z += ad.z; add4.w += ad.w;
@@ -348,6 +415,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
             // (decoder LSTM: "every attention-LSTM workgroup has published step t + 1" implies ctx(t) - they consumed it - and keeps
             // its 128 workgroups off the context flags' line, which the step's chain waits on; the last step has no successor)
             if (ATT) rs_gate(ctrl, RC_CTX, t, poll, lane);
+            else if (AR) rs_gate(ctrl, RC_CTX, t + 1, poll, lane);   // (autoregressive loop: this cell is on the chain - no shortcut)
             else if (t + 2 <= T) rs_gate(ctrl, RC_HA, t + 2, poll, lane);
             else rs_gate(ctrl, RC_CTX, t + 1, poll, lane);
             RS_STAMP(3);
@@ -374,6 +442,77 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
                 for (int u = 0; u < XG; ++u) xc[u] = xn[u];
             }
         }
+        if (AR && KIND == 1) {
+            // ---- Prenet layer 2 of this step's input (8 workgroups, 32 output units each, K = 256 split over the 8 waves): y1 comes from
+            // the attention rows (layer 1 on the frame of step t - 1), the result goes to all 96 attention-LSTM workgroups
+            if (l2_wg && t >= 1) {
+                rs_gate(ctrl, RC_Y1, t, poll, lane);
+                // every row has run the stop test of step t - 1: when all have fired, the loop is over (models/tts/tacotron2.py:401-406) -
+                // nothing is published any more, every wait of every workgroup ends at its next look at the stop word
+                if (bid == 64 && tid == 0 && __hip_atomic_load(p.n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= B) {
+                    __hip_atomic_store(p.sync + HANDOFF_STOP, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ctrl + RC_ABORT, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y1 + (long)(4 * wave) * B * 8);
+                float4 xy[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xy[u] = load_sc1(ry, x_lane + (unsigned)u * blkb);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { RS_MFMA32B(w1f[u < NP ? u : 0], xy[u]) }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { red[(wave * 16 + q) * 64 + lane] = acc2[q]; acc2[q] = 0.f; }
+                rs_cbar();
+                if (wave < 4) {   // lane (b, hh) of wave g: units 32 i2 + 8 g + 4 hh .. + 3 of row b
+                    float4 o;
+                    float* op = &o.x;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        float tt = 0.f;
+#pragma unroll
+                        for (int w = 0; w < RS_WAVES; ++w) tt += red[(w * 16 + 4 * wave + qq) * 64 + lane];
+                        op[qq] = tt;
+                    }
+                    if (bl < B) {
+                        const int u0 = 32 * (bid - 64) + 8 * wave + 4 * h;
+                        const unsigned km = *reinterpret_cast<const unsigned*>(p.keep1 + ((long)t * B + bl) * RS_P + u0);
+                        // dropout p = 0.5 at inference time too (models/tts/tacotron2.py:178): relu, then keep * 2
+                        o.x = (km & 0xffu) ? 2.f * fmaxf(o.x, 0.f) : 0.f;
+                        o.y = (km & 0xff00u) ? 2.f * fmaxf(o.y, 0.f) : 0.f;
+                        o.z = (km & 0xff0000u) ? 2.f * fmaxf(o.z, 0.f) : 0.f;
+                        o.w = (km & 0xff000000u) ? 2.f * fmaxf(o.w, 0.f) : 0.f;
+                        const __amdgpu_buffer_rsrc_t rp = make_rsrc(p.prenet + (long)(4 * (bid - 64) + wave) * B * 8);
+                        store_sc1(rp, (unsigned)(bl * 8 + 4 * h) * 4u, o);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                rs_cbar();
+                if (tid < RS_REP_PRE && __hip_atomic_load(ctrl + RC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+                    __hip_atomic_store(p.sync + RS_FLAG_PRE + (tid * 8 + (bid - 64)) * 32, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (AR && ATT) {
+            // ---- part 3 (autoregressive loop): the Prenet columns, prenet(t) behind RC_PRE >= t - the one part of this cell on the chain
+            rs_gate(ctrl, RC_PRE, t, poll, lane);
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.prenet + (long)(4 * wave) * B * 8);
+            float4 xp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xp[u] = load_sc1(rx, x_lane + (unsigned)u * blkb);
+            if (XH) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staged fragments have landed (and the x fragments with them)
+                const float4* st = reinterpret_cast<const float4*>(red + wave * 16 * 64);
+                const float4* sh = reinterpret_cast<const float4*>(red2 + wave * 8 * 64);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 wl = st[u * 64 + lane];
+                    const float4 hl = sh[u * 32 + hidx];
+                    RS_MFMA32(wl, xp[u])
+                    RS_MFMA16(hl, xp[u])
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { RS_MFMA32(wp[u < NP ? u : 0], xp[u]) }
+            }
+        }
         RS_STAMP(4);
 
         // ---- cross-wave K reduction through LDS (same order as skinny.hip).  The epilogue's per-lane indices are recomputed from an
@@ -383,7 +522,19 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         const int el = te & 63, ebl = el & 31, eh = el >> 5;
         // query-slab weights of this wave's 32 attention dims: requested now, used after the cells (L2 hits)
         float4 wq_a = make_float4(0.f, 0.f, 0.f, 0.f), wq_b = wq_a, wq_c = wq_a, wq_d = wq_a;
-        if (slab_wave) {
+        float4 xe = wq_a;
+        if (AR && !ATT && slab_wave) {
+            // projection slab of this tile's 8 hidden units, output dims 32 wave .. + 31 (rows past PSB: clamped, never stored), and the
+            // four context columns that ride on it: weights (L2 hits) and ctx(t)[b][4 tile .. + 3]
+            const int dd = min(32 * wave + ebl, p.PSB - 1);
+            const float* wp_l = p.proj_hd_t + ((long)tile * p.PSB + dd) * 8;
+            wq_a = *reinterpret_cast<const float4*>(wp_l);
+            wq_b = *reinterpret_cast<const float4*>(wp_l + 4);
+            wq_c = *reinterpret_cast<const float4*>(p.proj_ctx_t + ((long)tile * p.PSB + dd) * 4);
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.hc + (long)(t + 1) * B * (RS_D + RS_E) + (long)RS_D * B + (long)(tile >> 1) * B * 8);
+            xe = load_sc1(rc, (unsigned)((ebl < B ? ebl : 0) * 8 + 4 * (tile & 1)) * 4u);
+        }
+        if (ATT && slab_wave) {
             const float* wq_l = p.wq_t + ((long)tile * RS_ATT + 32 * wave + ebl) * 8;
             wq_a = *reinterpret_cast<const float4*>(wq_l);
             wq_b = *reinterpret_cast<const float4*>(wq_l + 4);
@@ -475,6 +626,10 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
                 qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow2[0], eh ? wq_c.y : wq_c.x, qa, 0, 0, 0);
                 qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow2[2], eh ? wq_c.w : wq_c.z, qa, 0, 0, 0);
             }
+            if (AR && !ATT) {   // + sum_j Wp_ctx[d][4 tile + j] ctx(t)[b][4 tile + j]
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(eh ? xe.y : xe.x, eh ? wq_c.y : wq_c.x, qa, 0, 0, 0);
+                qa = __builtin_amdgcn_mfma_f32_32x32x2f32(eh ? xe.w : xe.z, eh ? wq_c.w : wq_c.z, qa, 0, 0, 0);
+            }
             // lane (d, hh) holds D[b = 8 gg + 4 hh + rr][d] in register 4 gg + rr: through the wave's own 4 KiB of `red` (free since the
             // barrier above) into rows of 32 floats, stored as 16-byte pieces - 8 whole 128-byte lines per instruction
             float* tq = red + wave * 16 * 64;
@@ -482,12 +637,13 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
             for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) tq[(8 * gg + 4 * eh + rr) * 32 + ebl] = qa[4 * gg + rr];
-            const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q_slab + (long)bid * B * RS_ATT + 32 * wave);
+            const int sdim = ATT ? RS_ATT : p.PSB;   // floats per slab row
+            const __amdgpu_buffer_rsrc_t rq = make_rsrc(ATT ? p.q_slab + (long)bid * B * RS_ATT + 32 * wave : p.p_slab + (long)tile * B * sdim + 32 * wave);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int row = 8 * ps + (el >> 3), c4 = el & 7;
                 const float4 v = *reinterpret_cast<const float4*>(tq + row * 32 + 4 * c4);
-                if (row < B) store_sc1(rq, (unsigned)(row * RS_ATT + 4 * c4) * 4u, v);
+                if (row < B && (ATT || 32 * wave + 4 * c4 < sdim)) store_sc1(rq, (unsigned)(row * sdim + 4 * c4) * 4u, v);
             }
         } else if (wave == 6) {
             if (ATT && t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);   // the slot's last reader, decoder LSTM (t - RS_HA_SLOTS), has finished
@@ -506,12 +662,22 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
         RS_STAMP(7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the flag goes up
         RS_STAMP(8);
+        // (autoregressive loop: a workgroup whose waits have been ended - every row has stopped, or a time-out - publishes nothing more
+        // and leaves; the decision is one thread's, taken before the barrier, so that all waves leave after the same step)
+        if (AR && tid == 0) ctrl[RC_EXIT + (t & 1)] = __hip_atomic_load(ctrl + RC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         rs_cbar();
         RS_STAMP(9);
-        // one wave instruction: lane r stores the workgroup's flag into replica r
-        if (tid < RS_REP) __hip_atomic_store(p.sync + (ATT ? RS_FLAG_ATT + bid : RS_FLAG_DEC + (bid - dec0)) + tid * 128, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else if (ATT && tid < RS_REP + RS_REP1)   // ... and lanes 32 .. 39 the slab flags the attention rows watch (a line each)
-            __hip_atomic_store(p.sync + RS_FLAG_Q + ((tid - RS_REP) * dec0 + bid) * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool leave = AR && __builtin_amdgcn_readfirstlane(ctrl[RC_EXIT + (t & 1)]) != 0;
+        if (leave) break;
+        // one wave instruction: lane r stores the workgroup's flag into replica r (addresses from an opaque copy of the thread id:
+        // hoisted out of the loop they were spilled and reloaded here, on the chain)
+        int tf = tid;
+        asm volatile("" : "+v"(tf));
+        if (tf < RS_REP) __hip_atomic_store(p.sync + (ATT ? RS_FLAG_ATT + bid : RS_FLAG_DEC + (bid - dec0)) + tf * 128, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (ATT && tf < RS_REP + RS_REP1)   // ... and lanes 32 .. 39 the slab flags the attention rows watch (a line each)
+            __hip_atomic_store(p.sync + RS_FLAG_Q + ((tf - RS_REP) * dec0 + bid) * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (AR && !ATT && tf < RS_REP + RS_REP_P)   // (autoregressive loop: the attention rows watch the projection slabs' flags)
+            __hip_atomic_store(p.sync + RS_FLAG_P + ((tf - RS_REP) * 128 + (bid - dec0)) * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         RS_WGSTAMP(3);
     }
     // final cell states (the launch-per-step loop keeps them in memory; callers that continue a sequence read them there)
@@ -519,7 +685,7 @@ __device__ __forceinline__ void rs_body(const DecResidentParams& p, char* smem, 
     if (cell2_wave && b2 < B) c_mem[(long)b2 * H + j2] = c_state;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void decoder_resident_kernel(DecResidentParams p) {
+__global__ __launch_bounds__(RS_THREADS) void decoder_resident_kernel(RsArgs p) {
     extern __shared__ __attribute__((aligned(16))) char rs_smem[];
     const int bid = (int)blockIdx.x;
     // kind of this workgroup: 224-workgroup deal 0 / 1 / 2, 192-workgroup deal 3 / 2      (uniform per workgroup)
@@ -527,10 +693,31 @@ __global__ __launch_bounds__(RS_THREADS) void decoder_resident_kernel(DecResiden
     const int off_ctrl = kind == 0 ? RsCfg<0>::OFF_CTRL : (kind == 1 ? RsCfg<1>::OFF_CTRL : (kind == 2 ? RsCfg<2>::OFF_CTRL : RsCfg<3>::OFF_CTRL));
     if (threadIdx.x < 64) reinterpret_cast<int*>(rs_smem + off_ctrl)[threadIdx.x] = 0;
     __syncthreads();
-    if (kind == 0) rs_body<0>(p, rs_smem, bid);
-    else if (kind == 1) rs_body<1>(p, rs_smem, bid);
-    else if (kind == 2) rs_body<2>(p, rs_smem, bid);
-    else rs_body<3>(p, rs_smem, bid);
+    if (kind == 0) rs_body<0, false>(p, rs_smem, bid);
+    else if (kind == 1) rs_body<1, false>(p, rs_smem, bid);
+    else if (kind == 2) rs_body<2, false>(p, rs_smem, bid);
+    else rs_body<3, false>(p, rs_smem, bid);
+}
+
+// Autoregressive decode (models/tts/tacotron2.py:390-413 Decoder.inference): the same engine in the 224-workgroup deal, ONE launch
+// for the whole decode.  The frame of step t feeds step t + 1, so both cells are on the step's chain:
+//   attention LSTM (t): h_a(t-1) and ctx(t-1) columns early, the Prenet columns when prenet(t) arrives     -> h_a(t), query slabs
+//   attention rows (t) (attn_persist.hip): energies, softmax, context                                        -> ctx(t)
+//   decoder LSTM (t): h_d(t-1), h_a(t) columns early, the context columns when ctx(t) arrives                -> h_d(t), projection slabs
+//   attention rows again: slab sum = frame + gate of step t, stop test, Prenet layer 1 on the frame          -> y1(t+1)
+//   8 of the attention-LSTM workgroups: Prenet layer 2                                                       -> prenet(t+1)
+// When every row's stop token has fired, the first Prenet workgroup raises the stop word instead of publishing: every waiter
+// finds it at its next look and leaves, the host reads the number of steps from the word.
+__global__ __launch_bounds__(RS_THREADS) void decoder_ar_resident_kernel(RsArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+    const int bid = (int)blockIdx.x;
+    const int kind = bid < 64 ? 0 : (bid < 96 ? 1 : 2);
+    const int off_ctrl = kind == 0 ? RsCfg<0>::OFF_CTRL : (kind == 1 ? RsCfg<1>::OFF_CTRL : RsCfg<2>::OFF_CTRL);
+    if (threadIdx.x < 64) reinterpret_cast<int*>(rs_smem + off_ctrl)[threadIdx.x] = 0;
+    __syncthreads();
+    if (kind == 0) rs_body<0, true>(p, rs_smem, bid);
+    else if (kind == 1) rs_body<1, true>(p, rs_smem, bid);
+    else rs_body<2, true>(p, rs_smem, bid);
 }
 
 #ifdef GVX_STAMPS
@@ -551,7 +738,9 @@ hipError_t read_poll_log_resident(unsigned long long* host192, int* n3) {
 #endif
 
 hipError_t decoder_resident_init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_ar_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
 }
 
 bool decoder_resident_supported(int B, int L) { const int lay = attention_persistent_layout(B, L); return lay == 1 || lay == 2; }
@@ -561,7 +750,26 @@ hipError_t launch_decoder_resident(const DecResidentParams& p, hipStream_t s) {
         !p.hc || !p.q_slab || !p.c_a || !p.c_d || !p.sync)
         return hipErrorInvalidValue;
     if (p.layout != 1 && p.layout != 2) return hipErrorInvalidValue;
-    decoder_resident_kernel<<<dim3(p.layout == 2 ? 192 : 224), dim3(RS_THREADS), RS_LDS_BYTES, s>>>(p);
+    RsArgs a{};
+    a.att_frag = p.att_frag; a.att_bias = p.att_bias; a.wq_t = p.wq_t; a.dec_frag = p.dec_frag; a.dec_bias = p.dec_bias;
+    a.pre_gate = p.pre_gate; a.h_a = p.h_a; a.hc = p.hc; a.q_slab = p.q_slab; a.c_a = p.c_a; a.c_d = p.c_d; a.sync = p.sync;
+    a.att_frag_bytes = p.att_frag_bytes; a.B = p.B; a.T = p.T; a.spin_limit = p.spin_limit; a.debug = p.debug; a.layout = p.layout;
+    decoder_resident_kernel<<<dim3(p.layout == 2 ? 192 : 224), dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_decoder_ar_resident(const ArResidentParams& p, hipStream_t s) {
+    if (p.B < 1 || p.B > 32 || p.T < 1 || !p.att_frag || !p.dec_frag || !p.att_bias || !p.dec_bias || !p.wq_t || !p.proj_hd_t || !p.proj_ctx_t ||
+        !p.pre_w1 || !p.keep1 || !p.prenet || !p.y1 || !p.h_a || !p.hc || !p.q_slab || !p.p_slab || !p.c_a || !p.c_d || !p.n_done || !p.sync)
+        return hipErrorInvalidValue;
+    if (p.PSB < 8 || p.PSB > 96 || (p.PSB & 3) || p.att_frag_bytes == 0) return hipErrorInvalidValue;   // three slab waves of 32 dims
+    RsArgs a{};
+    a.att_frag = p.att_frag; a.att_bias = p.att_bias; a.wq_t = p.wq_t; a.dec_frag = p.dec_frag; a.dec_bias = p.dec_bias;
+    a.proj_hd_t = p.proj_hd_t; a.proj_ctx_t = p.proj_ctx_t; a.pre_w1 = p.pre_w1; a.keep1 = p.keep1; a.prenet = p.prenet; a.y1 = p.y1;
+    a.p_slab = p.p_slab; a.n_done = p.n_done; a.PSB = p.PSB;
+    a.h_a = p.h_a; a.hc = p.hc; a.q_slab = p.q_slab; a.c_a = p.c_a; a.c_d = p.c_d; a.sync = p.sync;
+    a.att_frag_bytes = p.att_frag_bytes; a.B = p.B; a.T = p.T; a.spin_limit = p.spin_limit; a.debug = p.debug; a.layout = 1;
+    decoder_ar_resident_kernel<<<dim3(224), dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
     return hipGetLastError();
 }
 

@@ -150,6 +150,7 @@ struct gvx_model {
     // teacher-forced loop as ONE resident weight-streaming kernel beside the resident attention kernel (dec_resident.hip):
     // B <= 32, L <= 128, inference mode; GVX_TF_RESIDENT=0 keeps the launch per step
     bool tf_resident = true;
+    bool ar_resident_loop = true;   // autoregressive decode as two resident kernels (GVX_AR_RESIDENT_LOOP=0: launches per step)
     int pa_depth = 4;                  // GVX_PA_DEPTH=6: prefetch depth of the launch beside the resident kernel (tests, A/B runs)
     unsigned spin_limit = 0;           // GVX_HANDOFF_SPIN_LIMIT: polls before an in-launch wait gives up (0 = the built-in limit)
     bool debug_skip_resident = false;  // GVX_DEBUG_SKIP_RESIDENT=1: never launch the resident attention kernel, so that every
@@ -454,6 +455,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     if (const char* e = std::getenv("GVX_ENC_PERSISTENT")) m->enc_persistent = e[0] != '0';
     if (const char* e = std::getenv("GVX_TF_ROWS64")) m->tf_rows64 = e[0] == '1';
     if (const char* e = std::getenv("GVX_TF_RESIDENT")) m->tf_resident = e[0] != '0';
+    if (const char* e = std::getenv("GVX_AR_RESIDENT_LOOP")) m->ar_resident_loop = e[0] != '0';
     if (const char* e = std::getenv("GVX_PA_DEPTH")) m->pa_depth = std::atoi(e) == 6 ? 6 : 4;
     if (const char* e = std::getenv("GVX_HANDOFF_SPIN_LIMIT")) m->spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("GVX_DEBUG_SKIP_RESIDENT")) m->debug_skip_resident = e[0] == '1';
@@ -1066,6 +1068,15 @@ int turn_end(hipStream_t s) {     // caller holds g_turn_mutex
     return GVX_OK;
 }
 
+// the autoregressive decode as two resident kernels (beside attention_persistent_supported for the shape): default layer sizes, a
+// handle that has the chip to itself
+bool ar_resident_loop_ok(const gvx_model* m, int B, int L) {
+    const gvx_dims& d = m->d;
+    return B <= 32 && d.embed_dim / 4 == d.dec_rnn_dim / 8 && m->attn_persistent && m->tf_resident && m->ar_resident_loop &&
+           decoder_resident_supported(B, L) && attention_persistent_layout(B, L) == 1 && d.prenet_dim == 256 && d.n_mels <= 80 &&
+           m->PSB() <= 96 && d.att_dim == 128;
+}
+
 int ensure_side_stream(gvx_model* m) {
     if (!m->pa_fork) {
         HIP_TRY(hipEventCreateWithFlags(&m->pa_fork, hipEventDisableTiming));
@@ -1525,6 +1536,16 @@ int gvx_teacher_forced_loop_kind(const gvx_model* m, int B, int L) {
     return m->tf_resident && decoder_resident_supported(B, L) ? 2 : 1;
 }
 
+int gvx_autoregressive_loop_kind(const gvx_model* m, int B, int L) {
+    if (!m || B < 1 || L < 1) return 0;
+    const gvx_dims& d = m->d;
+    const bool pa_ok = m->attn_one_launch && attention_persistent_layout(B, L) == 1 &&
+                       attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
+    if (!pa_ok) return 0;
+    if (ar_resident_loop_ok(m, B, L)) return 2;
+    return m->ar_resident ? 1 : 0;
+}
+
 int gvx_model_set_persistent_attention(gvx_model* m, int enable) {
     if (!m) return fail(GVX_ERR_INVALID_ARG, "null argument");
     m->attn_persistent = enable != 0;
@@ -1826,9 +1847,14 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     // the whole decode, the context of a step arrives inside launch C (deferred segment) and the attention launch leaves the
     // step's chain.  The projection's context columns then ride on the decoder-LSTM tiles' projection slabs (`fold`), so that
     // launch C is exactly 256 tiles.
-    const bool pa = m->ar_resident && m->attn_one_launch && attention_persistent_layout(B, L) == 1 &&
-                    attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
+    const bool pa_ok = m->attn_one_launch && attention_persistent_layout(B, L) == 1 &&
+                       attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
     const bool fold = B <= 32 && E / 4 == D / 8;
+    // ... and when the layer sizes are the default ones, the LSTM cells, the projection and the Prenet live in a second resident
+    // kernel as well (dec_resident.hip, decoder_ar_resident_kernel): the whole decode is two launches.  Not on handles that share
+    // the chip with other calls (gvx_model_set_persistent_attention(model, 0): the two kernels need all 256 CUs)
+    const bool ar_res = pa_ok && ar_resident_loop_ok(m, B, L);
+    const bool pa = pa_ok && (m->ar_resident || ar_res);
     // h_a(t) exists when launch A ends, the context only after the attention step: the h_a columns of both cells (two thirds of
     // what launch C used to stream) are summed by tiles that share the attention step's launch - the step's latency chain
     // hides under 33 MB of weight stream - and launch C is left with the context columns
@@ -1978,7 +2004,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
         }
         return GVX_OK;
     };
-    if (fold) {   // p_ctx = the projection's bias, once: the linear job on the all-zero context of slot 0
+    if (fold && !ar_res) {   // p_ctx = the projection's bias, once: the linear job on the all-zero context of slot 0
         SkinnyJob J;
         std::memset(&J, 0, sizeof J);
         J.Wp = m->dev_blob + m->blob.proj_ctx_frag; J.bias = m->dev_blob + m->blob.proj_b;
@@ -1987,7 +2013,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
         J.y = db.p_ctx;
         HIP_TRY(launch_skinny(&J, 1, SK_AR, s));
     }
-    if (pa) {   // the resident kernel: launched eagerly on the handle's side stream, behind everything queued on `s` so far
+    if (pa && !ar_res) {   // the resident kernel: launched eagerly on the handle's side stream, behind everything queued on `s` so far
         HIP_TRY(hipEventRecord(m->pa_fork, s));
         HIP_TRY(hipStreamWaitEvent(m->pa_stream, m->pa_fork, 0));
         AttnPersistParams pp{};
@@ -2003,8 +2029,56 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     }
     const int CHUNK = 16;  // steps per graph = steps between host checks of the all-rows-finished counter
     int t = 0;
+    if (ar_res) {
+        // ---- the whole decode as TWO resident kernels (dec_resident.hip decoder_ar_resident_kernel + attn_persist.hip, AR role): no
+        // launch per step, no host check - the kernels find the end of the loop themselves (every row's stop token has fired: the
+        // stop word holds the number of steps that ran) or run into max_steps
+        std::unique_lock<std::mutex> turn(g_turn_mutex);   // resident loops take turns on the device
+        rc = turn_begin(s);
+        if (rc != GVX_OK) return rc;
+        HIP_TRY(hipEventRecord(m->pa_fork, s));
+        HIP_TRY(hipStreamWaitEvent(m->pa_stream, m->pa_fork, 0));
+        static const int dbg = [] { const char* e = std::getenv("GVX_RS_DEBUG"); return e ? std::atoi(e) : 0; }();
+        AttnPersistParams pp{};
+        pp.q_slab = db.q_slab; pp.n_slabs = attention_persistent_slabs(1);
+        pp.v = m->dev_blob + m->blob.v; pp.pm = db.pm; pp.memory = memory_ws; pp.lengths = len_ws;
+        pp.loc_conv_t = m->dev_blob + m->blob.loc_conv; pp.loc_dense_t = m->dev_blob + m->blob.loc_dense;
+        pp.w_out = db.align_tm; pp.w_out_bs = (long)L; pp.w_out_ts = (long)B * L;
+        pp.ctx_base = db.hc + (size_t)B * (D + E) + (size_t)D * B; pp.ctx_ts = (long)B * (D + E);   // slot t + 1
+        pp.sync = sync; pp.B = B; pp.L = L; pp.T = T; pp.kl = d.att_loc_kernel;
+        pp.spin_limit = m->spin_limit; pp.q_first = 1;
+        pp.q_flags = sync + RS_FLAG_Q; pp.n_q_flags = pp.n_slabs; pp.ctx_flags = sync + RS_FLAG_CTX; pp.debug = dbg;
+        pp.p_slab = db.p_slab; pp.PSB = PSB; pp.n_mels = M; pp.proj_b = m->dev_blob + m->blob.proj_b; pp.proj_out = db.proj;
+        pp.pre_w0_t = m->dev_blob + m->blob.pre_w0_t; pp.keep0 = masks_ws; pp.y1 = db.pre1;
+        pp.n_frames = n_frames_ws; pp.n_done = n_done; pp.gate_threshold = gate_threshold;
+        pp.p_flags = sync + RS_FLAG_P; pp.y1_flags = sync + RS_FLAG_Y1;
+        if (!m->debug_skip_resident) HIP_TRY(launch_attention_persistent(pp, m->pa_stream));
+        HIP_TRY(hipEventRecord(m->pa_join, m->pa_stream));
+        ArResidentParams rp{};
+        rp.att_frag = m->dev_blob + m->blob.att_frag; rp.att_bias = m->dev_blob + m->blob.att_bias; rp.wq_t = m->dev_blob + m->blob.wq_t;
+        rp.dec_frag = m->dev_blob + m->blob.dec_frag; rp.dec_bias = m->dev_blob + m->blob.dec_bias;
+        rp.proj_hd_t = m->dev_blob + m->blob.proj_hd_t; rp.proj_ctx_t = m->dev_blob + m->blob.proj_ctx_t;
+        rp.pre_w1 = m->dev_blob + m->blob.pre_w1; rp.keep1 = masks_ws + (size_t)T * B * P;
+        rp.prenet = db.prenet; rp.y1 = db.pre1;
+        rp.h_a = db.h_a; rp.hc = db.hc; rp.q_slab = db.q_slab; rp.p_slab = db.p_slab; rp.c_a = db.c_a; rp.c_d = db.c_d;
+        rp.n_done = n_done; rp.sync = sync;
+        rp.att_frag_bytes = (unsigned)(frag_floats(4 * A, P + E + A) * sizeof(float));
+        rp.B = B; rp.T = T; rp.PSB = PSB; rp.spin_limit = m->spin_limit; rp.debug = dbg;
+        HIP_TRY(launch_decoder_ar_resident(rp, s));
+        HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));
+        rc = turn_end(s);
+        if (rc != GVX_OK) return rc;
+        turn.unlock();
+        if (!m->ar_done_host) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->ar_done_host), 2 * sizeof(int32_t), hipHostMallocDefault));
+            for (auto& e : m->ar_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        HIP_TRY(hipMemcpyAsync(m->ar_done_host, sync + HANDOFF_STOP, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        t = m->ar_done_host[0] > 0 && m->ar_done_host[0] < T ? m->ar_done_host[0] : T;
+    }
     gvx_model::GraphSet* gset = nullptr;
-    if (m->use_graph) {
+    if (m->use_graph && !ar_res) {
         gvx_model::LoopKey key{ws, memory_ws, m->dev_blob, B, L, T, lengths != nullptr};
         key.threshold = gate_threshold;
         key.variant = pa ? 1 : (split_h ? 2 : 0);
@@ -2027,10 +2101,12 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
         return GVX_OK;
     };
     int t_enq = 0, slot = 0;   // steps enqueued so far; slot of the chunk the host looks at next
-    rc = enqueue_chunk(0, 0);
-    if (rc != GVX_OK) return rc;
-    t_enq = CHUNK < T ? CHUNK : T;
-    while (true) {
+    if (!ar_res) {
+        rc = enqueue_chunk(0, 0);
+        if (rc != GVX_OK) return rc;
+        t_enq = CHUNK < T ? CHUNK : T;
+    }
+    while (!ar_res) {
         const int t_chunk_end = t_enq;   // end of the chunk whose counter is read next
         const bool more = t_enq < T;
         if (more) {
@@ -2043,7 +2119,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
         if (m->ar_done_host[slot] >= B || !more) break;
         slot ^= 1;
     }
-    if (pa) {   // the loop may have ended early: tell the resident kernel (it leaves at its next look), then wait for it
+    if (pa && !ar_res) {   // the loop may have ended early: tell the resident kernel (it leaves at its next look), then wait for it
         HIP_TRY(launch_handoff_set(sync + HANDOFF_STOP, s));
         HIP_TRY(hipStreamWaitEvent(s, m->pa_join, 0));
     }

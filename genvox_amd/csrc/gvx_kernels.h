@@ -208,7 +208,7 @@ bool attention_supported(int L, int a, int F, int kl, int E);
 constexpr int HANDOFF_CNT_Q = 0, HANDOFF_CNT_CTX = 1024, HANDOFF_READY = 2048, HANDOFF_TIMEOUT = 3072;
 constexpr int HANDOFF_STOP = 3072 + 512;   // the host's "the loop has ended early" word (autoregressive decode): the resident kernel leaves
 constexpr int HANDOFF_PAIR = 4096;   // split resident kernel: flag word of half hf of row b at HANDOFF_PAIR + (2 b + hf) * 32
-constexpr int HANDOFF_WORDS = 51200;   // (from 8192 on: flag replicas of the resident decoder loop, RS_FLAG_* below)
+constexpr int HANDOFF_WORDS = 69632;   // (from 8192 on: flag replicas of the resident decoder loops, RS_FLAG_* below)
 constexpr unsigned HANDOFF_SPIN_LIMIT = 200000u;   // polls with ~2 us of s_sleep between them (a few hundred ms), then the wait gives up
 struct AttnPersistParams {
     const float* q_slab; int n_slabs;       // [n_slabs][B][a], rewritten (sc1) by the attention-LSTM tiles every step
@@ -228,6 +228,18 @@ struct AttnPersistParams {
     const unsigned* q_flags; int n_q_flags;   // producer i's flag for the rows of replica r at q_flags[(r * n_q_flags + i) * 32], r < RS_REP1
     unsigned* ctx_flags;                      // replica r of row b's flag at ctx_flags[(r * 32 + b) * 32], r < RS_REP1
     int debug;   // timing experiments (GVX_RS_DEBUG & 32: no sleep between looks at the flags)
+    // autoregressive role (beside decoder_ar_resident_kernel; p_slab == nullptr otherwise): after publishing its context, row b
+    // waits for the 128 projection slabs of the step (p_flags), sums them into the step's frame + gate (proj_out), runs the stop
+    // test and Prenet layer 1 on the frame and hands y1 to the Prenet workgroups (y1_flags)
+    const float* p_slab; int PSB, n_mels;     // [128][B][PSB]
+    const float* proj_b;                      // [n_mels + 1]
+    float* proj_out;                          // [T][PSB/8][B][8] blocked projection vector of every step
+    const float* pre_w0_t;                    // [n_mels][P] Prenet layer 1 transposed
+    const uint8_t* keep0;                     // [T][B][P] keep mask of layer 1's dropout for the input of step t
+    float* y1;                                // blocked [P/8][B][8]
+    int32_t* n_frames; int32_t* n_done; float gate_threshold;
+    const unsigned* p_flags;                  // decoder-LSTM workgroup i's flag for the rows of replica r at p_flags[(r * 128 + i) * 32], r < RS_REP_P
+    unsigned* y1_flags;                       // row b's flag at y1_flags[b * 32]
 };
 // ---------------------------------------------------------------------------------------------
 // Teacher-forced decoder loop as ONE resident weight-streaming kernel beside the resident attention kernel (dec_resident.hip):
@@ -246,7 +258,14 @@ constexpr int RS_FLAG_DEC = RS_FLAG_ATT + RS_REP * 128;  // [RS_REP][128] decode
 constexpr int RS_REP1 = 8;
 constexpr int RS_FLAG_CTX = RS_FLAG_DEC + RS_REP * 128;             // [RS_REP1][32 rows][32 words]: attention row b has published its context of steps < value
 constexpr int RS_FLAG_Q = RS_FLAG_CTX + RS_REP1 * 32 * 32;          // [RS_REP1][96][32 words]: attention-LSTM workgroup i has published its query slab of steps < value
-static_assert(RS_FLAG_Q + RS_REP1 * 96 * 32 <= HANDOFF_WORDS, "flag replicas inside the hand-off block");
+// Autoregressive resident loop (dec_resident.hip, decoder_ar_resident_kernel): three more hand-offs on the step's chain, all with one
+// writer per line:
+constexpr int RS_FLAG_Y1 = RS_FLAG_Q + RS_REP1 * 96 * 32;           // [32 rows][32 words]: attention row b has published Prenet layer 1 of steps <= value (8 readers)
+constexpr int RS_REP_PRE = 8;
+constexpr int RS_FLAG_PRE = RS_FLAG_Y1 + 32 * 32;                   // [RS_REP_PRE][8][32 words]: Prenet workgroup i has published its slice of layer 2 of steps <= value
+constexpr int RS_REP_P = 4;
+constexpr int RS_FLAG_P = RS_FLAG_PRE + RS_REP_PRE * 8 * 32;        // [RS_REP_P][128][32 words]: decoder-LSTM workgroup i has published h_d and its projection slab of steps < value
+static_assert(RS_FLAG_P + RS_REP_P * 128 * 32 <= HANDOFF_WORDS, "flag replicas inside the hand-off block");
 constexpr int RS_HA_SLOTS = 4;            // ring of h_a vectors: h_a(t) in slot (t + 1) % RS_HA_SLOTS, slot 0 = the zero state
 struct DecResidentParams {
     const float* att_frag; const float* att_bias; const float* wq_t;   // packed [128][224][64][4], [4A] packed row order, [A/8][a][8]
@@ -264,7 +283,29 @@ struct DecResidentParams {
     int layout;                     // 1: 224 workgroups beside one attention workgroup per row (L <= 128); 2: 192 workgroups - 64 pairs of
                                     // attention-LSTM tiles + 128 decoder-LSTM tiles - beside two per row (128 < L <= 256)
 };
+// Autoregressive decode as ONE launch of the same weight-stationary engine (224-workgroup deal) beside the resident attention
+// kernel, which also reduces the projection slabs, tests the stop condition and runs Prenet layer 1 (attn_persist.hip, AR role).
+struct ArResidentParams {
+    const float* att_frag; const float* att_bias; const float* wq_t;   // as DecResidentParams (the Prenet columns, k-groups [0, P/8), are used here)
+    const float* dec_frag; const float* dec_bias;
+    const float* proj_hd_t;         // [D/8][PSB][8] projection weights of the tiles' hidden units (slab operand)
+    const float* proj_ctx_t;        // [E/4][PSB][4] projection weights of the context columns, four per decoder-LSTM tile
+    const float* pre_w1;            // [P][P] Prenet layer 2, row-major [out][in]
+    const uint8_t* keep1;           // [T][B][P] keep mask of layer 2's dropout for the input of step t
+    float* prenet;                  // blocked [P/8][B][8]: Prenet output = input of the step about to run (zero for step 0)
+    const float* y1;                // blocked [P/8][B][8]: Prenet layer 1 of the next step (written by the attention rows)
+    float* h_a; float* hc; float* q_slab;   // as DecResidentParams
+    float* p_slab;                  // [128][B][PSB]
+    float* c_a; float* c_d;
+    const int32_t* n_done;          // rows whose stop token has fired
+    unsigned* sync;
+    unsigned att_frag_bytes;
+    int B, T, PSB;
+    unsigned spin_limit;
+    int debug;
+};
 bool decoder_resident_supported(int B, int L);
+hipError_t launch_decoder_ar_resident(const ArResidentParams& p, hipStream_t s);
 hipError_t decoder_resident_init();
 hipError_t launch_decoder_resident(const DecResidentParams& p, hipStream_t s);
 

@@ -359,6 +359,12 @@ class Tacotron2(nn.Module):
         self._ensure_packed()
         return int(_lib.load().gvx_teacher_forced_loop_kind(self._handle, B, L))
 
+    def ar_loop_kind(self, B: int, L: int) -> int:
+        """How an autoregressive call of this shape runs its decode (gvx_autoregressive_loop_kind): 2 = two resident kernels for the
+        whole decode, 1 / 0 = launches per step (beside the resident attention kernel / not)."""
+        self._ensure_packed()
+        return int(_lib.load().gvx_autoregressive_loop_kind(self._handle, B, L))
+
     def kernel_times_ms(self):
         a, b, n = C.c_float(), C.c_float(), C.c_int()
         _lib.check(_lib.load().gvx_kernel_times_ms(self._handle, C.byref(a), C.byref(b), C.byref(n)))

@@ -148,6 +148,13 @@ int gvx_teacher_forced_resident(const gvx_model* model, int B, int L);
  * 1 = one weight-streaming launch per step beside the resident attention kernel, 0 = a launch pair per step. */
 int gvx_teacher_forced_loop_kind(const gvx_model* model, int B, int L);
 
+/* How an autoregressive call with B rows of L tokens runs its decode (models/tts/tacotron2.py:390-413 Decoder.inference):
+ * 2 = TWO resident kernels for the whole decode (dec_resident.hip decoder_ar_resident_kernel beside attn_persist.hip's rows, which
+ *     also sum the frame, test the stop token and run Prenet layer 1; default layer sizes, B <= 32, L <= 128, the handle does not
+ *     share the chip): no launch per step, the kernels end the loop themselves,
+ * 1 = launches per step beside the resident attention kernel (opt-in, GVX_AR_RESIDENT=1), 0 = launches per step. */
+int gvx_autoregressive_loop_kind(const gvx_model* model, int B, int L);
+
 /* ---- Encoder: embedding + conv/BN/relu stack + BiLSTM with packed-sequence semantics.
  * Replaces nn.Embedding + Encoder.forward / Encoder.inference (models/tts/tacotron2.py:459,
  * :231-246, :248-256).  tokens: int64 [B, L]; lengths: int32 [B] or NULL (= all L);

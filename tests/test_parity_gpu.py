@@ -589,6 +589,73 @@ def test_autoregressive_resident_attention_equals_per_step(monkeypatch):
         assert max_abs_diff(got, want[k]) <= TOL, k
 
 
+@pytest.mark.parametrize("lens", [[50, 41, 33, 20, 9], [64 - b for b in range(32)], [77], [128, 1, 90]])
+def test_autoregressive_resident_loop_equals_launch_per_step(lens, monkeypatch):
+    """The default autoregressive decode for <= 32 rows of <= 128 tokens: TWO resident kernels for the whole loop
+    (decoder_ar_resident_kernel - both LSTM cells, projection slabs, Prenet layer 2 out of weights that stay in registers and LDS -
+    beside the resident attention kernel, which also sums the frame, tests the stop token and runs Prenet layer 1); the kernels end
+    the loop themselves when every row has fired.  Against the launch-per-step schedule (GVX_AR_RESIDENT_LOOP=0): ragged token
+    lengths, rows that stop at different steps, one row / 32 rows / a row of one token, and a run into max_decoder_steps; same frame
+    counts, numbers equal to fp32 rounding (the summation orders differ), no time-out, repeatable bit for bit; row 0 against a
+    batch-1 oracle run (models/tts/tacotron2.py:390-413)."""
+    mc, ac, tc = Tacotron2Config(), AudioConfig(filter_length=1024, log_func="np.log"), TextConfig(n_tokens=40)
+    steps = 40
+    mc.max_decoder_steps = steps
+    sd = gw.generate_state_dict(mc, ac, tc, seed=0)
+    B, L = len(lens), max(lens)
+    tok = (gw.hashed_uniform(41, "arloop", B * L) * tc.n_tokens).astype(np.int64).reshape(B, L)
+    for b, n in enumerate(lens):
+        tok[b, n:] = 0
+    masks = torch.from_numpy(gw.prenet_keep_masks(steps * B, mc.prenet_dim, seed=9)).reshape(2, steps, B, mc.prenet_dim)
+    inputs = {"tokens": torch.from_numpy(tok), "token_lengths": torch.tensor(lens), "prenet_keep_masks": masks}
+
+    def run(threshold):
+        mc.gate_threshold = threshold
+        m = Tacotron2(mc, ac, tc)
+        m.load_state_dict(sd)
+        m = m.to("cuda:0")
+        assert m.ar_loop_kind(B, L) == want_kind
+        a = m.inference(inputs)
+        b = m.inference(inputs)
+        for k in KEYS:
+            assert torch.equal(a[k], b[k]), k
+        m.check_status()
+        return a
+
+    want_kind = 2
+    probe = run(1.0)   # no row ever fires: the loop runs into max_decoder_steps
+    assert probe["mel_outputs"].shape[2] == steps
+    g = torch.sigmoid(probe["gate_outputs"][:, :8]).cpu()
+    thr = float(g.flatten().sort().values[g.numel() // 2])
+    res = run(thr)
+    # ... and one that every row crosses at some step: the kernels end the loop themselves, before max_decoder_steps
+    gall = torch.sigmoid(probe["gate_outputs"][:, :steps - 8]).cpu()
+    thr_all = float(gall.max(dim=1).values.min()) * 0.999
+    early = run(thr_all)
+    assert early["mel_outputs"].shape[2] <= steps - 8
+    monkeypatch.setenv("GVX_AR_RESIDENT_LOOP", "0")
+    want_kind = 0
+    per_probe = run(1.0)
+    per = run(thr)
+    per_early = run(thr_all)
+    for a, b in ((probe, per_probe), (res, per), (early, per_early)):
+        if B > 1:
+            assert a["mel_lengths"].cpu().tolist() == b["mel_lengths"].cpu().tolist()
+        assert a["mel_outputs"].shape == b["mel_outputs"].shape
+        for k in KEYS:
+            assert torch.isfinite(a[k]).all(), k
+            assert max_abs_diff(a[k], b[k]) <= 5e-5, k
+    if B > 1:
+        assert int(res["mel_lengths"].min()) < steps   # at least one row stopped on its gate
+    want = tacotron2_ref.tacotron2_inference(sd, torch.from_numpy(tok[:1]), masks[:, :, 0], thr, steps, token_length=lens[0])
+    nf = want["mel_outputs"].shape[2]
+    if B > 1:
+        assert int(res["mel_lengths"][0]) == nf
+    for k in ("mel_outputs", "gate_outputs", "alignments"):
+        got = res[k][:1, ..., :nf] if k != "alignments" else res[k][:1, :nf]
+        assert max_abs_diff(got, want[k]) <= TOL, k
+
+
 def test_autoregressive_h_columns_beside_attention_equals_launch_per_step(monkeypatch):
     """Default autoregressive step (one handle, <= 32 rows): the h_a(t) columns of both LSTM cells are summed by 256 tiles that
     share the attention step's launch (ar_attn_tiles_kernel), launch C streams the context columns and adds those sums

@@ -347,9 +347,14 @@ def main():
 
     def ar_entry(dt, bb, n_streams):
         S = mc.max_decoder_steps
+        kind = model.ar_loop_kind(min(bb, 32), L)
+        execution = {2: "two resident kernels per 32-row chunk for the whole decode (weight-stationary LSTM / projection / Prenet kernel beside the "
+                        "attention rows; the kernels end the loop themselves)" + (", chunks one after the other" if bb > 32 else ""),
+                     1: "launches per step beside the resident attention kernel, host stop polling",
+                     0: "launches per step, host stop polling" + (", 32-row chunks on two streams" if bb > 32 else "")}[kind]
         return {"us_per_step": round(dt / S * 1e6, 2), "ms_per_utterance_batch": round(dt * 1e3, 2),
                 "rtf_per_stream": round(dt / (S * audio_s_per_frame), 6), "rtf_aggregate": round(dt / (S * audio_s_per_frame * n_streams), 7),
-                "mel_frames_per_s": round(n_streams * S / dt, 1), "includes": "encoder + 1000 decoder steps + Postnet, host stop polling"}
+                "mel_frames_per_s": round(n_streams * S / dt, 1), "includes": "encoder + 1000 decoder steps + Postnet", "execution": execution}
 
     # ---- N > 1: the second line SURVEY.md section 8d asks of the sharded configuration - autoregressive decode, 64 rows per
     # rank, all ranks at once (barrier on both sides, slowest rank defines the time)

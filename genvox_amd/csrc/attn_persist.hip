@@ -55,7 +55,7 @@ constexpr int PA_OFF_ES = PA_OFF_QS + PA_A;                    // [128] energies
 constexpr int PA_OFF_V = PA_OFF_ES + PA_L;                     // [128] v
 constexpr int PA_OFF_CP = PA_OFF_V + PA_A;                     // [8][512] context partial sums
 constexpr int PA_OFF_FLAG = PA_OFF_CP + 8 * PA_E;              // [4] "leave the loop" word of the step's wait
-constexpr int PA_OFF_H1 = PA_OFF_FLAG + 4;                     // [256] autoregressive role: Prenet layer 1 of the row
+constexpr int PA_OFF_H1 = PA_OFF_FLAG + 4;                     // autoregressive role: [128] projection bias, [1] "this row's stop token has fired"
 constexpr int PA_LDS_FLOATS = PA_OFF_H1 + 256;
 constexpr int PA_P = 256;      // Prenet width (autoregressive role)
 constexpr int PA_KPT = 5;      // layer-1 k values per thread: n_mels <= 16 PA_KPT
@@ -130,7 +130,7 @@ __device__ __forceinline__ bool flags_wait(const unsigned* flags, int n, unsigne
 // exp(e - M) / S.  Half 0 publishes the context.  The softmax equals the reference's (models/tts/tacotron2.py:126) up to
 // rounding (1e-7 relative).
 #ifdef GVX_STAMPS
-namespace { __device__ unsigned long long pa_row_stamps[64][8]; }   // per resident workgroup: the phase stamps of step 20
+namespace { __device__ unsigned long long pa_row_stamps[64][8]; __device__ unsigned long long pa_row_stamps_ar[64][4]; }   // per resident workgroup: the phase stamps of step 20
 #endif
 // AR (beside decoder_ar_resident_kernel, dec_resident.hip): after its context the row also finishes the step - it sums the 128
 // projection slabs of the decoder-LSTM tiles into the frame + gate of the step (Decoder.decode's linear projection and gate
@@ -188,6 +188,10 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     }
     for (int i = tid; i < 32 * PA_A / 4; i += PA_THREADS) reinterpret_cast<float4*>(wdl)[i] = reinterpret_cast<const float4*>(p.loc_dense_t)[i];
     if (tid < PA_A) vl[tid] = p.v[tid];
+    if (AR) {   // projection bias and the row's stop state: read on the chain every step
+        if (tid < 128) smem[PA_OFF_H1 + tid] = tid <= p.n_mels ? p.proj_b[tid] : 0.f;
+        if (tid == 128) reinterpret_cast<int*>(smem + PA_OFF_H1)[128] = p.n_frames[b] != 0;
+    }
     for (int i = tid; i < 2 * PA_WC_S; i += PA_THREADS) wc[i] = 0.f;
     __syncthreads();
 
@@ -245,8 +249,10 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q_slab);
 #ifdef GVX_STAMPS
 #define PA_STAMP(i) do { if (t == 20) { GVX_STAMP(0, i); if (tid == 0 && (i) < 8) pa_row_stamps[blockIdx.x & 63][i] = wall_clock64(); } } while (0)
+#define PA_ARSTAMP(i) do { if (t == 20 && tid == 0) pa_row_stamps_ar[blockIdx.x & 63][i] = wall_clock64(); } while (0)
 #else
 #define PA_STAMP(i) do { } while (0)
+#define PA_ARSTAMP(i) do { } while (0)
 #endif
     for (int t = 0; t < p.T; ++t) {
         PA_STAMP(0);
@@ -255,19 +261,28 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         // adds too).  Then sum the partial slabs (fixed order)
         // A wait that returns without its word (the host has ended the loop early - autoregressive decode, every row has
         // stopped - or some wait has timed out) ends the kernel: nothing it could still compute would be used
-        if (p.q_flags) {
-            // beside the resident decoder kernel: one flag per producing workgroup (value = steps published), watched by one wave
-            if (wave == 0 && !flags_wait(p.q_flags + (b % RS_REP1) * p.n_q_flags * 32, p.n_q_flags, (unsigned)t + 1u, tmo, 0x100u + (unsigned)b, p.spin_limit, stop, (p.debug & 32) != 0) && (tid & 63) == 0) *leave = 1;
-        } else if (tid == 0 && !handoff_wait<true>(cnt_q, (unsigned)t + p.q_first, tmo, 0x100u + (unsigned)b, p.spin_limit, stop)) *leave = 1;
-        __syncthreads();
-        if (*leave) break;
-        PA_STAMP(1);
+        if (!p.q_flags) {
+            if (tid == 0 && !handoff_wait<true>(cnt_q, (unsigned)t + p.q_first, tmo, 0x100u + (unsigned)b, p.spin_limit, stop)) *leave = 1;
+            __syncthreads();
+            if (*leave) break;
+            PA_STAMP(1);
+        }
         int tq = tid;
         asm volatile("" : "+v"(tq));
         const int lane = tq & 63, e4 = tq >> 3, lg = tq & 7, el = tq >> 3, dg = tq & 7;
         const bool cl = lg == 0;   // the lane of its column that stores / exchanges the context
         {
             const int d4 = tq & 31, sg = tq >> 5;   // slabs SPG sg .. SPG sg + SPG - 1 (one slab per workgroup / tile of the attention LSTM)
+            // beside the resident decoder kernel: one flag per producing workgroup (value = steps published).  Every wave waits for the
+            // producers of ITS slabs only (2 SPG of them) and fetches those at once: a row's slabs are 48 KB, 2 us of a CU's load path,
+            // and the producers finish over 1.5 us - most of the bytes are in before the last flag goes up
+            // (the wait's parameters from the kernel-argument segment, like the autoregressive role's below)
+            typedef const __attribute__((address_space(4))) AttnPersistParams* KargPtr;
+            KargPtr kq = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kq));
+            if (p.q_flags && !flags_wait(kq->q_flags + ((b % RS_REP1) * kq->n_q_flags + 2 * SPG * wave) * 32, 2 * SPG, (unsigned)t + 1u, tmo, 0x100u + (unsigned)b,
+                                         kq->spin_limit, stop, (kq->debug & 32) != 0) && (tid & 63) == 0) *leave = 1;
+            if (p.q_flags) PA_STAMP(1);   // (wave 0's slabs seen)
             float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 ql[SPG];
 #pragma unroll
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             if ((tq & 32) == 0) reinterpret_cast<float4*>(qp)[(sg >> 1) * 32 + d4] = s4; } else reinterpret_cast<float4*>(qp)[sg * 32 + d4] = s4;
         }
         __syncthreads();
+        if (*leave) break;   // (a wait that was given up: time-out, or the loop has ended)
         if (tq < PA_A) {
             float acc = qp[tq];
 #pragma unroll
@@ -419,8 +435,9 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
 #ifdef GVX_STAMPS
         if (t == 20 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pa_row_stamps[blockIdx.x & 63][7] = wall_clock64(); }   // flag store acknowledged
 #endif
-        // ---- off the chain: location features of step t + 1
-        if (t + 1 < p.T) location_features();
+        // ---- off the chain: location features of step t + 1 (autoregressive role: after the row's second part of the step, which IS on
+        // the chain - the features have until the next query arrives, two hand-offs and a cell later)
+        if (!AR && t + 1 < p.T) location_features();
         PA_STAMP(6);
         if (AR) {
             int ta = tid;
@@ -435,55 +452,79 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             float4* sp4 = reinterpret_cast<float4*>(qp);                  // [32][32]
             float4* l1p = reinterpret_cast<float4*>(smem + PA_OFF_CP);    // [16][64]
             float* mel = qs;                                              // [128]
-            float* h1 = smem + PA_OFF_H1;                                 // [256]
-            if (wave == 0 && !flags_wait(kp->p_flags + (b % RS_REP_P) * 128 * 32, 128, (unsigned)t + 1u, tmo, 0x600u + (unsigned)b, kp->spin_limit, stop, (kp->debug & 32) != 0) && (tid & 63) == 0) *leave = 1;
+            const float* pbl = smem + PA_OFF_H1;                          // [128] projection bias
+            int* fired = reinterpret_cast<int*>(smem + PA_OFF_H1) + 128;
+            // next step's keep byte of layer 1 (one register across the wait; its round trip would sit on the chain)
+            unsigned char k0 = 0;
+            if (more && ta < PA_P) k0 = kp->keep0[((long)(t + 1) * B + b) * PA_P + ta];
+            // ---- the slabs of the step: wave w takes those of decoder-LSTM workgroups 8 w .. 8 w + 7 as soon as THEIR flags are up (45 KB per
+            // row: the same reasoning as for the query slabs), lanes (g, n4): slabs 8 w + 4 g .. + 3, float4 column n4
+            if (!flags_wait(kp->p_flags + ((b % RS_REP_P) * 128 + 8 * wave) * 32, 8, (unsigned)t + 1u, tmo, 0x600u + (unsigned)b, kp->spin_limit, stop, (kp->debug & 32) != 0) && (tid & 63) == 0) *leave = 1;
+            PA_ARSTAMP(0);   // projection slabs of wave 0 seen
+            const int n4c = PSB >> 2;                 // float4 per slab row (<= 24)
+            {
+                const int la = ta & 63, g = la >= n4c ? 1 : 0, n4 = la - g * n4c;
+                if (la < 2 * n4c) {
+                    const __amdgpu_buffer_rsrc_t rs = make_rsrc(kp->p_slab);
+                    float4 sv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[q] = load_sc1(rs, (unsigned)(((8 * wave + 4 * g + q) * B + b) * PSB + 4 * n4) * 4u);
+                    float4 acc = sv[0];
+                    acc.x += sv[1].x; acc.y += sv[1].y; acc.z += sv[1].z; acc.w += sv[1].w;
+                    acc.x += sv[2].x; acc.y += sv[2].y; acc.z += sv[2].z; acc.w += sv[2].w;
+                    acc.x += sv[3].x; acc.y += sv[3].y; acc.z += sv[3].z; acc.w += sv[3].w;
+                    sp4[(2 * wave + g) * 32 + n4] = acc;
+                }
+            }
             __syncthreads();
             if (*leave) break;
-            // ---- the slabs of the step (the only loads that depend on the wait) and, behind them, this thread's layer-1 weights
-            const int n4c = PSB >> 2;                 // float4 per slab row (<= 24)
-            const int sg = ta / n4c, n4 = ta - sg * n4c;
-            if (sg < 32) {
-                const __amdgpu_buffer_rsrc_t rs = make_rsrc(kp->p_slab);
-                float4 sv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sv[q] = load_sc1(rs, (unsigned)(((4 * sg + q) * B + b) * PSB + 4 * n4) * 4u);
-                float4 acc = sv[0];
-                acc.x += sv[1].x; acc.y += sv[1].y; acc.z += sv[1].z; acc.w += sv[1].w;
-                acc.x += sv[2].x; acc.y += sv[2].y; acc.z += sv[2].z; acc.w += sv[2].w;
-                acc.x += sv[3].x; acc.y += sv[3].y; acc.z += sv[3].z; acc.w += sv[3].w;
-                sp4[sg * 32 + n4] = acc;
-            }
-            __syncthreads();
-            if (ta < 128) {
-                float v = 0.f;
-                if (ta <= M) {
-                    const float* col = reinterpret_cast<const float*>(sp4) + ta;
-                    float acc = col[0];
-#pragma unroll 4
-                    for (int q = 1; q < 32; ++q) acc += col[q * 128];   // (4 at a time: the layer-1 weights are waiting in registers)
-                    v = acc + kp->proj_b[ta];
-                    kp->proj_out[(long)t * B * PSB + (long)(ta >> 3) * B * 8 + b * 8 + (ta & 7)] = v;
-                    if (ta == M && kp->n_frames[b] == 0) {
-                        const float sgm = 1.f / (1.f + expf(-v));
-                        if (sgm > kp->gate_threshold) {
-                            kp->n_frames[b] = t + 1;
-                            atomicAdd(kp->n_done, 1);
-                        }
-                    }
-                }
-                mel[ta] = ta < M ? v : 0.f;   // zeros past the mel bins: clamped weight loads contribute nothing
-            }
-            __syncthreads();
+            // this thread's layer-1 weights (L2 hits, the same for every row and step): requested here, their round trip overlaps the
+            // column sums (the kernel has no 20 registers to hold them across the wait)
             const int kq1 = ta >> 6, j4 = ta & 63;    // layer 1: 16 k slices x 64 float4 columns
-            unsigned char k0 = 0;
-            if (more) {
-                // (this thread's layer-1 weights are L2 hits, the same for every row and step; the kernel has no 20 registers to hold
-                // them across the slab sum, so their round trip is paid here)
-                float4 w0v[PA_KPT];
+            float4 w0v[PA_KPT];
+            {
                 const float4* w0 = reinterpret_cast<const float4*>(kp->pre_w0_t) + j4;
 #pragma unroll
                 for (int i = 0; i < PA_KPT; ++i) w0v[i] = w0[min(kq1 * PA_KPT + i, M - 1) * (PA_P / 4)];
-                if (ta < PA_P) k0 = kp->keep0[((long)(t + 1) * B + b) * PA_P + ta];
+            }
+            {   // column c4 (4 projection outputs) summed over the 32 slab groups by the 32 lanes of a half wave: no serial chain of LDS reads
+                const int c4 = ta >> 5, sgl = ta & 31;
+                if (c4 < n4c) {   // (uniform per half wave)
+                    float4 v4 = sp4[sgl * 32 + c4];
+#pragma unroll
+                    for (int o = 16; o >= 1; o >>= 1) {
+                        v4.x += __shfl_xor(v4.x, o, 64); v4.y += __shfl_xor(v4.y, o, 64);
+                        v4.z += __shfl_xor(v4.z, o, 64); v4.w += __shfl_xor(v4.w, o, 64);
+                    }
+                    if (sgl == 0) {
+                        float* vp = &v4.x;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int n = 4 * c4 + i;
+                            vp[i] = n <= M ? vp[i] + pbl[n] : 0.f;
+                        }
+                        if (c4 == (M >> 2) && *fired == 0) {   // stop token (models/tts/tacotron2.py:401-406)
+                            const int gi = M & 3;
+                            const float gate = gi == 0 ? v4.x : (gi == 1 ? v4.y : (gi == 2 ? v4.z : v4.w));
+                            const float sgm = 1.f / (1.f + expf(-gate));
+                            if (sgm > kp->gate_threshold) {
+                                *fired = 1;
+                                kp->n_frames[b] = t + 1;
+                                atomicAdd(kp->n_done, 1);
+                            }
+                        }
+                        // blocked vector [PSB/8][B][8] of the step
+                        *reinterpret_cast<float4*>(kp->proj_out + (long)t * B * PSB + (long)(c4 >> 1) * B * 8 + b * 8 + 4 * (c4 & 1)) = v4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) mel[4 * c4 + i] = 4 * c4 + i < M ? vp[i] : 0.f;   // zeros past the mel bins: clamped weight loads contribute nothing
+                    }
+                } else if (ta < 32 * n4c + 128 - 4 * n4c) {
+                    mel[4 * n4c + (ta - 32 * n4c)] = 0.f;   // (columns past PSB of the 128-float frame buffer)
+                }
+            }
+            __syncthreads();
+            PA_ARSTAMP(1);   // frame summed
+            if (more) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int i = 0; i < PA_KPT; ++i) {
@@ -494,25 +535,31 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
                 l1p[kq1 * 64 + j4] = acc;
             }
             __syncthreads();
-            if (more && ta < PA_P) {
-                const float* col = reinterpret_cast<const float*>(l1p) + ta;
-                float acc = col[0];
+            if (ta < PA_P) {   // (waves 0 - 3)
+                float r = 0.f;
+                if (more) {
+                    const float* col = reinterpret_cast<const float*>(l1p) + ta;
+                    float acc = col[0];
 #pragma unroll
-                for (int q = 1; q < 16; ++q) acc += col[q * 256];
-                acc = fmaxf(acc, 0.f);
-                h1[ta] = k0 ? 2.f * acc : 0.f;
-            }
-            __syncthreads();
-            if (ta < 64) {
-                if (more) {   // blocked vector [P/8][B][8], write-through
-                    const __amdgpu_buffer_rsrc_t ry = make_rsrc(kp->y1);
-                    store_sc1(ry, (unsigned)((ta >> 1) * B * 8 + b * 8 + 4 * (ta & 1)) * 4u, reinterpret_cast<const float4*>(h1)[ta]);
+                    for (int q = 1; q < 16; ++q) acc += col[q * 256];
+                    acc = fmaxf(acc, 0.f);
+                    r = k0 ? 2.f * acc : 0.f;   // dropout p = 0.5 also at inference time (models/tts/tacotron2.py:178)
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and the stop test's counter has arrived (wave 1's atomic below)
+                // four neighbours' values -> one 16-byte write-through piece of the blocked vector [P/8][B][8]
+                const int l0 = (ta & 63) & ~3;
+                const float4 o = make_float4(__shfl(r, l0, 64), __shfl(r, l0 + 1, 64), __shfl(r, l0 + 2, 64), __shfl(r, l0 + 3, 64));
+                if (more && (ta & 3) == 0) {
+                    const __amdgpu_buffer_rsrc_t ry = make_rsrc(kp->y1);
+                    store_sc1(ry, (unsigned)((ta >> 3) * B * 8 + b * 8 + (ta & 7)) * 4u, o);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (the wave that ran the stop test: its counter update has arrived)
+            if (wave == (M >> 2) / 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            PA_ARSTAMP(2);   // layer 1 stored
             if (ta == 0) __hip_atomic_store(kp->y1_flags + b * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (more) location_features();
         }
     }
 }
@@ -555,6 +602,9 @@ hipError_t launch_handoff_set(unsigned* word, hipStream_t s) {
 }
 
 #ifdef GVX_STAMPS
+hipError_t read_row_stamps_persist_ar(unsigned long long* host256) {
+    return hipMemcpyFromSymbol(host256, HIP_SYMBOL(pa_row_stamps_ar), sizeof(unsigned long long) * 256);
+}
 hipError_t read_row_stamps_persist(unsigned long long* host512) {
     return hipMemcpyFromSymbol(host512, HIP_SYMBOL(pa_row_stamps), sizeof(unsigned long long) * 512);
 }

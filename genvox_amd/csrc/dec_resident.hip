@@ -70,6 +70,7 @@ constexpr int RC_IDLE = 5;         // polls since the last one that moved a word
 constexpr int RC_PRE = 6;          // autoregressive loop: steps whose Prenet output every Prenet workgroup has published (value t: input of step t)
 constexpr int RC_Y1 = 7;           // ... whose Prenet layer 1 every attention row has published
 constexpr int RC_EXIT = 8;         // [2] by step parity: "the workgroup leaves after this step" (written before the step's last barrier)
+constexpr int RC_WANT = 10;        // classes (bit = control word) that waves without the lock are waiting for
 
 // Everything the two kernels of this file take (the launchers fill it from DecResidentParams / ArResidentParams)
 struct RsArgs {
@@ -91,13 +92,16 @@ struct RsArgs {
 constexpr int RS_STAMP_T = 20;
 __device__ unsigned long long rs_stamps[4][10][16];
 __device__ unsigned long long rs_wg_stamps[224][4];
+__device__ unsigned long long rs_wg_stamps_ar[224][4];   // autoregressive loop: y1 seen, Prenet flag stored, Prenet seen, Prenet columns done
 __device__ unsigned long long rs_poll_log[3][64];   // [class][k]: return time of the k-th poll of block 64 during step RS_STAMP_T
 __device__ int rs_poll_n[3];
 #define RS_STAMP(ev) do { if (stamp_wg && t == RS_STAMP_T && lane == 0) rs_stamps[KIND][wave][ev] = wall_clock64(); } while (0)
 #define RS_WGSTAMP(i) do { if (t == RS_STAMP_T && tid == 0) rs_wg_stamps[bid][i] = wall_clock64(); } while (0)
+#define RS_ARSTAMP(i) do { if (t == RS_STAMP_T && tid == 0) rs_wg_stamps_ar[bid][i] = wall_clock64(); } while (0)
 #else
 #define RS_STAMP(ev) do { } while (0)
 #define RS_WGSTAMP(i) do { } while (0)
+#define RS_ARSTAMP(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -111,42 +115,48 @@ struct RsPoll {   // what a poll needs: the flag words, the status word, sizes
     int sleep;   // s_sleep units between two looks of the polling wave (GVX_RS_DEBUG experiments)
 };
 
-// One look at the flags of ONE producer class (the class whose word the caller waits for: fewer loads on the hot lines) by the wave
-// that holds the lock; "steps everybody has published" by ballots (a count only moves up).  Every 16th fruitless look also reads the
-// call's status word.  Gives up - status word, abort word - after `limit` looks in a row that moved nothing, or when anybody else has.
-__device__ __forceinline__ void rs_poll_once(int* ctrl, const RsPoll& q, int lane, int word) {
-    unsigned v;
-    if (word == RC_HA) {
-        const unsigned a0 = __hip_atomic_load(q.f_att + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned a1 = lane + 64 < q.n_att ? __hip_atomic_load(q.f_att + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-        v = min(a0, a1);
-    } else if (word == RC_HD) {
-        const unsigned d0 = __hip_atomic_load(q.f_dec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned d1 = __hip_atomic_load(q.f_dec + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = min(d0, d1);
-    } else if (word == RC_CTX) {
-        v = lane < q.B ? __hip_atomic_load(q.f_ctx + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;   // (a flag per 128-byte line)
-    } else if (word == RC_PRE) {
-        v = lane < 8 ? __hip_atomic_load(q.f_pre + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-    } else {
-        v = lane < q.B ? __hip_atomic_load(q.f_y1 + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: nothing below moves above the loads
-#ifdef GVX_STAMPS
-    if (q.bid == 64 && lane == 0 && __hip_atomic_load(ctrl + RC_HA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == RS_STAMP_T + (word == RC_HA ? 0 : 1)) {
-        const int cls = word == RC_HA ? 0 : (word == RC_CTX ? 1 : 2);
-        const int k = rs_poll_n[cls];
-        if (k < 64) { rs_poll_log[cls][k] = (wall_clock64() << 8) | (v & 0xff); rs_poll_n[cls] = k + 1; }
-    }
-#endif
-    const unsigned Tu = (unsigned)q.T;
+// One look at the flags of the producer classes in `mask` (bit = control word: the class the caller waits for and those other waves
+// of the workgroup have asked for - all in ONE round trip) by the wave that holds the lock; "steps everybody has published" per
+// class by ballots (a count only moves up).  Every 16th fruitless look also reads the call's status word.  Gives up - status word,
+// abort word - after `limit` looks in a row that moved nothing, or when anybody else has.
+__device__ __forceinline__ bool rs_count(int* ctrl, int word, unsigned v, unsigned Tu, int lane) {
     const unsigned s0 = (unsigned)__hip_atomic_load(ctrl + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     unsigned n = s0;
     while (n < Tu && __all(v > n)) ++n;
+    if (lane == 0 && n != s0) __hip_atomic_store(ctrl + word, (int)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return n != s0;
+}
+__device__ __forceinline__ void rs_poll_once(int* ctrl, const RsPoll& q, int lane, int mask) {
+    constexpr unsigned none = 0xffffffffu;
+    unsigned va = none, vd = none, vc = none, vp = none, vy = none;
+    if (mask & (1 << RC_HA)) {
+        const unsigned a0 = __hip_atomic_load(q.f_att + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned a1 = lane + 64 < q.n_att ? __hip_atomic_load(q.f_att + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
+        va = min(a0, a1);
+    }
+    if (mask & (1 << RC_HD)) {
+        const unsigned d0 = __hip_atomic_load(q.f_dec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned d1 = __hip_atomic_load(q.f_dec + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vd = min(d0, d1);
+    }
+    if (mask & (1 << RC_CTX)) vc = lane < q.B ? __hip_atomic_load(q.f_ctx + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;   // (a flag per 128-byte line)
+    if (q.f_pre) {   // (autoregressive loop)
+        if (mask & (1 << RC_PRE)) vp = lane < 8 ? __hip_atomic_load(q.f_pre + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
+        if (mask & (1 << RC_Y1)) vy = lane < q.B ? __hip_atomic_load(q.f_y1 + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: nothing below moves above the loads
+    const unsigned Tu = (unsigned)q.T;
+    bool moved = false;
+    if (mask & (1 << RC_HA)) moved |= rs_count(ctrl, RC_HA, va, Tu, lane);
+    if (mask & (1 << RC_HD)) moved |= rs_count(ctrl, RC_HD, vd, Tu, lane);
+    if (mask & (1 << RC_CTX)) moved |= rs_count(ctrl, RC_CTX, vc, Tu, lane);
+    if (q.f_pre) {
+        if (mask & (1 << RC_PRE)) moved |= rs_count(ctrl, RC_PRE, vp, Tu, lane);
+        if (mask & (1 << RC_Y1)) moved |= rs_count(ctrl, RC_Y1, vy, Tu, lane);
+    }
     int idle = 0;
     if (lane == 0) {
-        if (n != s0) __hip_atomic_store(ctrl + word, (int)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        idle = n != s0 ? 0 : __hip_atomic_load(ctrl + RC_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+        idle = moved ? 0 : __hip_atomic_load(ctrl + RC_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
         __hip_atomic_store(ctrl + RC_IDLE, idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     idle = __builtin_amdgcn_readfirstlane(idle);
@@ -162,7 +172,9 @@ __device__ __forceinline__ void rs_poll_once(int* ctrl, const RsPoll& q, int lan
 }
 
 // Gate of a wave's x loads: wait until the LDS word reads >= need.  A wave that has to wait polls for the whole workgroup if nobody
-// else is doing so already.  Returns at once when the abort word is up.
+// else is doing so already; otherwise it leaves the class it waits for in the workgroup's want mask, which the polling wave
+// serves with its own (waves of a decoder-LSTM workgroup wait for two classes at once: without the mask the wave that polled for
+// the contexts kept the lock and the h_a flags went unread for microseconds).  Returns at once when the abort word is up.
 __device__ __forceinline__ void rs_gate(int* ctrl, int word, int need, const RsPoll& q, int lane) {
     while (__hip_atomic_load(ctrl + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
         if (__hip_atomic_load(ctrl + RC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
@@ -170,9 +182,12 @@ __device__ __forceinline__ void rs_gate(int* ctrl, int word, int need, const RsP
         if (lane == 0) {
             int expect = 0;
             got = __hip_atomic_compare_exchange_strong(ctrl + RC_LOCK, &expect, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+            if (got) got = __hip_atomic_exchange(ctrl + RC_WANT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | (1 << word);
+            else __hip_atomic_fetch_or(ctrl + RC_WANT, 1 << word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (__builtin_amdgcn_readfirstlane(got)) {
-            rs_poll_once(ctrl, q, lane, word);
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (got) {
+            rs_poll_once(ctrl, q, lane, got);
             if (lane == 0) __hip_atomic_store(ctrl + RC_LOCK, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (q.sleep == 8) __builtin_amdgcn_s_sleep(8);
             else if (q.sleep == 32) __builtin_amdgcn_s_sleep(32);
@@ -379,32 +394,37 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
             RS_STAMP(1);
             RS_WGSTAMP(1);
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(xsrc);
-            constexpr int XG = (XH || RT == 2) ? 2 : 4;   // k-groups per x batch: the next batch loads while this one multiplies
-            float4 xc[XG], xn[XG];
+            constexpr int XG = (XH || RT == 2) ? 2 : 4;   // k-groups per x batch: later batches load while this one multiplies
+            // batches in flight ahead of the one being multiplied.  One is enough where the cell is off the chain; the decoder LSTM of
+            // the autoregressive loop has 3.4 us of products on h_a(t) between its arrival and the context's, and a batch's round
+            // trip (0.7 us) is longer than its products (0.43 us): with one batch ahead the part took 6 us and ended after the context
+            constexpr int XD = (AR && KIND == 2) ? 3 : 2;
+            float4 xb[XD][XG];
 #pragma unroll
-            for (int u = 0; u < XG; ++u) xc[u] = load_sc1(rx, x_lane + (unsigned)u * blkb);
+            for (int d = 0; d < XD - 1; ++d)
+#pragma unroll
+                for (int u = 0; u < XG; ++u) xb[d][u] = load_sc1(rx, x_lane + (unsigned)(XG * d + u) * blkb);
 #pragma unroll
             for (int gi = 0; gi < NN / XG; ++gi) {
-                if (gi + 1 < NN / XG) {
+                if (gi + XD - 1 < NN / XG) {
 #pragma unroll
-                    for (int u = 0; u < XG; ++u) xn[u] = load_sc1(rx, x_lane + (unsigned)(XG * (gi + 1) + u) * blkb);
+                    for (int u = 0; u < XG; ++u) xb[(gi + XD - 1) % XD][u] = load_sc1(rx, x_lane + (unsigned)(XG * (gi + XD - 1) + u) * blkb);
                 }
 #pragma unroll
                 for (int u = 0; u < XG; ++u) {
                     const int i = XG * gi + u;   // compile-time after unrolling: registers / LDS by index
+                    const float4 xv = xb[gi % XD][u];
                     if (i < NRN) {
-                        RS_MFMA32(wn[i], xc[u])
-                        if (XH) { RS_MFMA16(hn[i < NRH ? i : 0], xc[u]) }
-                        if (RT == 2) { RS_MFMA32B(wn2[i < NR2 ? i : 0], xc[u]) }
+                        RS_MFMA32(wn[i], xv)
+                        if (XH) { RS_MFMA16(hn[i < NRH ? i : 0], xv) }
+                        if (RT == 2) { RS_MFMA32B(wn2[i < NR2 ? i : 0], xv) }
                     } else {
                         const float4 wl = lw[(i - NRN) * RT * 64 + lane];
-                        RS_MFMA32(wl, xc[u])
-                        if (XH) { const float4 hl = lh[(i - NRN) * 32 + hidx]; RS_MFMA16(hl, xc[u]) }
-                        if (RT == 2) { const float4 wl2 = lw[((i - NRN) * RT + 1) * 64 + lane]; RS_MFMA32B(wl2, xc[u]) }
+                        RS_MFMA32(wl, xv)
+                        if (XH) { const float4 hl = lh[(i - NRN) * 32 + hidx]; RS_MFMA16(hl, xv) }
+                        if (RT == 2) { const float4 wl2 = lw[((i - NRN) * RT + 1) * 64 + lane]; RS_MFMA32B(wl2, xv) }
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < XG; ++u) xc[u] = xn[u];
             }
         }
         RS_STAMP(2);
@@ -446,17 +466,21 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
             // ---- Prenet layer 2 of this step's input (8 workgroups, 32 output units each, K = 256 split over the 8 waves): y1 comes from
             // the attention rows (layer 1 on the frame of step t - 1), the result goes to all 96 attention-LSTM workgroups
             if (l2_wg && t >= 1) {
+                // (this lane's keep bytes of layer 2's dropout: requested before the wait, their round trip is off the chain)
+                unsigned km = 0;
+                if (wave < 4 && bl < B) km = *reinterpret_cast<const unsigned*>(p.keep1 + ((long)t * B + bl) * RS_P + 32 * (bid - 64) + 8 * wave + 4 * h);
                 rs_gate(ctrl, RC_Y1, t, poll, lane);
+                RS_ARSTAMP(0);
+                const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y1 + (long)(4 * wave) * B * 8);
+                float4 xy[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xy[u] = load_sc1(ry, x_lane + (unsigned)u * blkb);
                 // every row has run the stop test of step t - 1: when all have fired, the loop is over (models/tts/tacotron2.py:401-406) -
                 // nothing is published any more, every wait of every workgroup ends at its next look at the stop word
                 if (bid == 64 && tid == 0 && __hip_atomic_load(p.n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= B) {
                     __hip_atomic_store(p.sync + HANDOFF_STOP, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ctrl + RC_ABORT, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y1 + (long)(4 * wave) * B * 8);
-                float4 xy[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) xy[u] = load_sc1(ry, x_lane + (unsigned)u * blkb);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { RS_MFMA32B(w1f[u < NP ? u : 0], xy[u]) }
 #pragma unroll
@@ -473,8 +497,6 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                         op[qq] = tt;
                     }
                     if (bl < B) {
-                        const int u0 = 32 * (bid - 64) + 8 * wave + 4 * h;
-                        const unsigned km = *reinterpret_cast<const unsigned*>(p.keep1 + ((long)t * B + bl) * RS_P + u0);
                         // dropout p = 0.5 at inference time too (models/tts/tacotron2.py:178): relu, then keep * 2
                         o.x = (km & 0xffu) ? 2.f * fmaxf(o.x, 0.f) : 0.f;
                         o.y = (km & 0xff00u) ? 2.f * fmaxf(o.y, 0.f) : 0.f;
@@ -488,11 +510,13 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                 rs_cbar();
                 if (tid < RS_REP_PRE && __hip_atomic_load(ctrl + RC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
                     __hip_atomic_store(p.sync + RS_FLAG_PRE + (tid * 8 + (bid - 64)) * 32, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                RS_ARSTAMP(1);
             }
         }
         if (AR && ATT) {
             // ---- part 3 (autoregressive loop): the Prenet columns, prenet(t) behind RC_PRE >= t - the one part of this cell on the chain
             rs_gate(ctrl, RC_PRE, t, poll, lane);
+            RS_ARSTAMP(2);
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.prenet + (long)(4 * wave) * B * 8);
             float4 xp[4];
 #pragma unroll
@@ -514,6 +538,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
             }
         }
         RS_STAMP(4);
+        if (AR) RS_ARSTAMP(3);
 
         // ---- cross-wave K reduction through LDS (same order as skinny.hip).  The epilogue's per-lane indices are recomputed from an
         // opaque copy of the thread id: hoisted out of the step loop they would sit in registers the resident weights need
@@ -646,7 +671,8 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                 if (row < B && (ATT || 32 * wave + 4 * c4 < sdim)) store_sc1(rq, (unsigned)(row * sdim + 4 * c4) * 4u, v);
             }
         } else if (wave == 6) {
-            if (ATT && t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);   // the slot's last reader, decoder LSTM (t - RS_HA_SLOTS), has finished
+            // the slot's last reader, decoder LSTM (t - RS_HA_SLOTS), has finished (autoregressive loop: implied - prenet(t) exists because that cell's step t - 1 has)
+            if (ATT && !AR && t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(hdst + (long)tile * B * 8);
             // (lane l: row l / 2, units 4 (l % 2) .. + 3 of the first tile; hs rows hold 8 RT units)
             if (4 * el < 8 * B) store_sc1(rh, (unsigned)el * 16u, *reinterpret_cast<const float4*>(hs + (el >> 1) * 8 * RT + 4 * (el & 1)));
@@ -655,7 +681,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(hdst + (long)(tile + 1) * B * 8);
             if (4 * el < 8 * B) store_sc1(rh, (unsigned)el * 16u, *reinterpret_cast<const float4*>(hs + (el >> 1) * 16 + 8 + 4 * (el & 1)));
         } else if (XH && wave == 7) {
-            if (t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);
+            if (!AR && t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(hdst + (long)xt * B * 8);
             if (el < B) store_sc1(rh, (unsigned)(el * 8 + 4 * xhalf) * 4u, *reinterpret_cast<const float4*>(hs2 + 4 * el));
         }
@@ -723,6 +749,9 @@ __global__ __launch_bounds__(RS_THREADS) void decoder_ar_resident_kernel(RsArgs 
 #ifdef GVX_STAMPS
 hipError_t read_stamps_resident(unsigned long long* host480) {
     return hipMemcpyFromSymbol(host480, HIP_SYMBOL(rs_stamps), sizeof(unsigned long long) * 480);   // (kinds 0 - 2; kind 3's rows follow)
+}
+hipError_t read_wg_stamps_resident_ar(unsigned long long* host896) {
+    return hipMemcpyFromSymbol(host896, HIP_SYMBOL(rs_wg_stamps_ar), sizeof(unsigned long long) * 896);
 }
 hipError_t read_wg_stamps_resident(unsigned long long* host896) {
     return hipMemcpyFromSymbol(host896, HIP_SYMBOL(rs_wg_stamps), sizeof(unsigned long long) * 896);

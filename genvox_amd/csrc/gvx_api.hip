@@ -33,6 +33,8 @@ hipError_t read_stamps_persist(unsigned long long* host96);
 hipError_t read_wg_spans(unsigned long long* host1024);
 hipError_t read_stamps_resident(unsigned long long* host480);
 hipError_t read_wg_stamps_resident(unsigned long long* host896);
+hipError_t read_wg_stamps_resident_ar(unsigned long long* host896);
+hipError_t read_row_stamps_persist_ar(unsigned long long* host256);
 hipError_t read_poll_log_resident(unsigned long long* host192, int* n3);
 hipError_t read_row_stamps_persist(unsigned long long* host512);
 #endif
@@ -2165,6 +2167,12 @@ int gvx_debug_read_wg_stamps_resident(unsigned long long* host896, unsigned long
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(gvx::read_wg_stamps_resident(host896));
     HIP_TRY(gvx::read_row_stamps_persist(rows512));
+    return GVX_OK;
+}
+int gvx_debug_read_stamps_ar(unsigned long long* host896, unsigned long long* rows256) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(gvx::read_wg_stamps_resident_ar(host896));
+    HIP_TRY(gvx::read_row_stamps_persist_ar(rows256));
     return GVX_OK;
 }
 int gvx_debug_read_poll_log_resident(unsigned long long* host192, int* n3) {

@@ -578,9 +578,10 @@ class Tacotron2(nn.Module):
         ``mel_lengths`` holds every row's frame count and frames past it carry the padding values of the reference's
         mask_padding (mel / mel_postnet / alignment 0, gate 1e3) - row b up to its length is what a batch-1 run gives.
 
-        Batches above STREAM_ROWS rows are decoded as chunks on two streams at once (each chunk a C-ABI call of its own,
-        driven by its own host thread because the call polls the stop flags): like the teacher-forced path, a second
-        independent batch fills the latency gaps of the first."""
+        Batches above STREAM_ROWS rows are decoded as chunks of at most that many rows: one after the other when a chunk decodes as
+        two resident kernels that fill the chip (``ar_loop_kind`` 2: default layer sizes, rows of <= 128 tokens), otherwise on two
+        streams at once (each chunk a C-ABI call of its own, driven by its own host thread because the call polls the stop flags):
+        a second independent batch then fills the latency gaps of the first."""
         dev = self._require_gpu()
         self._ensure_packed()
         tokens = inputs["tokens"].to(device=dev, dtype=torch.int64).contiguous()
@@ -619,13 +620,19 @@ class Tacotron2(nn.Module):
 
         n_chunks = -(-B // STREAM_ROWS)
         seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(n_chunks)]  # CPU generator: manual_seed repeats runs
+        bounds = [(B * i) // n_chunks for i in range(n_chunks + 1)]
+        chunks = list(zip(bounds, bounds[1:]))
         if n_chunks == 1:
             run(0, B, self._handle, self._workspace_of(lib.gvx_workspace_bytes_autoregressive(self._handle, B, L, S)), seeds[0])
+        elif all(lib.gvx_autoregressive_loop_kind(self._handle, hi - lo, L) == 2 for lo, hi in chunks):
+            # every chunk decodes as two resident kernels that fill the chip: one after the other on this stream (two such loops
+            # cannot share the device; 2 x 25 us per step pair against 61 us for two concurrent lanes of launch-per-step loops)
+            ws = self._workspace_of(lib.gvx_workspace_bytes_autoregressive(self._handle, max(hi - lo for lo, hi in chunks), L, S))
+            for ci, (lo, hi) in enumerate(chunks):
+                run(lo, hi, self._handle, ws, seeds[ci])
         else:
             import threading
 
-            bounds = [(B * i) // n_chunks for i in range(n_chunks + 1)]
-            chunks = list(zip(bounds, bounds[1:]))
             need = lib.gvx_workspace_bytes_autoregressive(self._handle, max(hi - lo for lo, hi in chunks), L, S)
             streams, wss = self._lanes(dev, need)
             self._ensure_lane_handles()

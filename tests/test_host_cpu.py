@@ -77,13 +77,25 @@ def test_resident_loop_policy_queries():
     assert lib.gvx_teacher_forced_resident(h, 32, 300) == 0 and lib.gvx_teacher_forced_resident(h, 64, 128) == 0
     assert lib.gvx_teacher_forced_resident(h, 0, 128) == 0 and lib.gvx_teacher_forced_resident(None, 32, 128) == 0
     assert lib.gvx_teacher_forced_rows_per_call(h, 128) == 32
+    # the decoder loops' kinds: 2 = one resident kernel for all steps (teacher-forced: also rows of 129-256 tokens; autoregressive:
+    # two resident kernels for the whole decode, rows of <= 128 tokens), otherwise launches per step
+    assert lib.gvx_teacher_forced_loop_kind(h, 32, 128) == 2 and lib.gvx_teacher_forced_loop_kind(h, 3, 200) == 2
+    assert lib.gvx_autoregressive_loop_kind(h, 1, 128) == 2 and lib.gvx_autoregressive_loop_kind(h, 32, 77) == 2
+    assert lib.gvx_autoregressive_loop_kind(h, 32, 129) == 0 and lib.gvx_autoregressive_loop_kind(h, 33, 64) == 0
+    assert lib.gvx_autoregressive_loop_kind(h, 0, 64) == 0 and lib.gvx_autoregressive_loop_kind(None, 1, 64) == 0
     assert lib.gvx_model_set_persistent_attention(h, 0) == 0
     assert lib.gvx_teacher_forced_resident(h, 32, 128) == 0
+    assert lib.gvx_autoregressive_loop_kind(h, 1, 128) == 0   # a handle that shares the chip: launches per step
+    assert lib.gvx_model_set_persistent_attention(h, 1) == 0
+    assert lib.gvx_autoregressive_loop_kind(h, 1, 128) == 2
+    assert lib.gvx_model_set_resident_kernels(h, 0) == 0      # (what a model does after a hand-off time-out)
+    assert lib.gvx_autoregressive_loop_kind(h, 1, 128) == 0 and lib.gvx_teacher_forced_loop_kind(h, 32, 128) == 0
     lib.gvx_model_destroy(h)
     from tests.golden.cases import TF_CASES, case_configs
     d = dims_from_configs(*case_configs(TF_CASES["tf_small"]))
     assert lib.gvx_model_create(C.byref(d), C.byref(h)) == 0
     assert lib.gvx_teacher_forced_resident(h, 4, 16) == 0   # reduced layer sizes: launch per attention step
+    assert lib.gvx_autoregressive_loop_kind(h, 1, 16) == 0
     lib.gvx_model_destroy(h)
 
 

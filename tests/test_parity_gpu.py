@@ -416,6 +416,21 @@ def test_forward_strict_recovers_from_a_timeout(monkeypatch):
     for b in range(2):
         want = tacotron2_ref.tacotron2_inference(sd, tok[b:b + 1], masks[:, :, b], 1.0, 8)
         assert max_abs_diff(out["mel_outputs"][b:b + 1], want["mel_outputs"]) <= TOL
+    # ... and for the autoregressive decode as two resident kernels: its attention kernel is never launched, the tile kernel's
+    # waits give up, the call's outputs are poisoned, inference() switches to the launch-per-step loop and runs again
+    monkeypatch.delenv("GVX_DEBUG_ENC_SKIP_BLOCK")
+    monkeypatch.setenv("GVX_DEBUG_SKIP_RESIDENT", "1")
+    m3, _, _ = _default_model()
+    m3.model_config.max_decoder_steps = 8
+    m3.model_config.gate_threshold = 1.0
+    assert m3.ar_loop_kind(2, 17) == 2
+    with pytest.warns(UserWarning, match="hand-off"):
+        out = m3.inference({"tokens": tok, "prenet_keep_masks": masks})
+    assert m3._resident_off and m3.ar_loop_kind(2, 17) == 0
+    assert all(torch.isfinite(v).all() for v in out.values())
+    for b in range(2):
+        want = tacotron2_ref.tacotron2_inference(sd, tok[b:b + 1], masks[:, :, b], 1.0, 8)
+        assert max_abs_diff(out["mel_outputs"][b:b + 1], want["mel_outputs"]) <= TOL
 
 
 def test_two_models_run_concurrently_from_two_threads():

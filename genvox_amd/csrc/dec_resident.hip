@@ -283,22 +283,31 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
     //   attention LSTM: k-groups KG0 + 64 + 16 w + i (h_a columns, i < 16), then KG0 + 8 w + i (context columns, i < 8)
     //   decoder LSTM:   k-groups 32 w + i (waves 0-3: h_a columns) / 32 w + 64 + i (waves 4-7: h_d columns), i < 32, then 128 + 8 w + i
     const float4* wsrc = reinterpret_cast<const float4*>(ATT ? p.att_frag : p.dec_frag);
+    constexpr bool ARD = AR && KIND == 2;   // decoder LSTM of the autoregressive loop: its own K deal (below)
+    // the Prenet columns of the attention LSTM (k-groups [0, 32) of its matrix) multiplied in the kernel: the autoregressive loop only
+    // (prenet(t) is made by the loop).  The teacher-forced loop adds the products of one GEMM over all steps (pre_gate): measured with
+    // the part in the kernel, the tile + half workgroups - whose matrix pipes are 66 % busy and bound the step - lost 0.7-0.9 us
+    // per step wherever the part was placed, more than the 0.8 ms GEMM (which overlaps the encoder) costs (round 4, EXPERIMENTS.md)
+    constexpr bool PP = AR && ATT;
+    constexpr int NSUB = ARD ? 2 : 1;
     const int kn0 = ATT ? RS_KG0_ATT + 64 + 16 * wave : (wave < 4 ? 32 * wave : 32 * wave + 64);
+    // k-group of the wave's i-th "early" fragment inside the packed matrix (ARD: 16 h_d k-groups 192 + 16 w + i, then 16 h_a k-groups 16 w + i)
+    auto kni = [&](int i) -> int { return ARD ? (i < 16 ? 192 + 16 * wave + i : 16 * wave + (i - 16)) : kn0 + i; };
     const int kc0 = ATT ? RS_KG0_ATT + 8 * wave : 128 + 8 * wave;
     const float4* wt = wsrc + (long)tile * NKGW * 64 + lane;
     const float4* wx = wsrc + (long)xt * NKGW * 64 + mlane;
     float4 wn[NRN], wc[NC], hn[NRH], hc[NCH], wn2[NR2], wc2[NC2];
     const float4* wt2 = wt + (long)NKGW * 64;   // the pair's second tile
 #pragma unroll
-    for (int i = 0; i < NRN; ++i) wn[i] = wt[(long)(kn0 + i) * 64];
+    for (int i = 0; i < NRN; ++i) wn[i] = wt[(long)kni(i) * 64];
 #pragma unroll
     for (int i = 0; i < NC; ++i) wc[i] = wt[(long)(kc0 + i) * 64];
 #pragma unroll
-    for (int i = 0; i < NR2; ++i) wn2[i] = RT == 2 ? wt2[(long)(kn0 + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NR2; ++i) wn2[i] = RT == 2 ? wt2[(long)kni(i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NC2; ++i) wc2[i] = RT == 2 ? wt2[(long)(kc0 + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < NRH; ++i) hn[i] = XH ? wx[(long)(kn0 + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NRH; ++i) hn[i] = XH ? wx[(long)kni(i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) hc[i] = XH ? wx[(long)(kc0 + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
     // the rest in LDS, private to the wave: [NLN][64 lanes] tile fragments, then [NLN][32] half fragments (written by the lanes
@@ -308,21 +317,21 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
     const int hidx = (mlane & 15) + 16 * (mlane >> 5);
 #pragma unroll
     for (int i = 0; i < NLN; ++i) {
-        lw[i * RT * 64 + lane] = wt[(long)(kn0 + NRN + i) * 64];
-        if (RT == 2) lw[(i * RT + 1) * 64 + lane] = wt2[(long)(kn0 + NRN + i) * 64];
-        if (XH && x_mine) lh[i * 32 + hidx] = wx[(long)(kn0 + NRN + i) * 64];
+        lw[i * RT * 64 + lane] = wt[(long)kni(NRN + i) * 64];
+        if (RT == 2) lw[(i * RT + 1) * 64 + lane] = wt2[(long)kni(NRN + i) * 64];
+        if (XH && x_mine) lh[i * 32 + hidx] = wx[(long)kni(NRN + i) * 64];
     }
 
     // ---- autoregressive loop: the Prenet columns (k-groups [0, 32) of the attention-LSTM matrix, 4 per wave) cannot be applied
     // before the loop.  Single tiles keep them in 16 more registers; a tile + half workgroup has neither registers nor LDS left
     // (48 KB) and stages them every step by LDS-DMA into the partial-sum regions `red` / `red2`, which are free during the
     // step's products: 6 KB per wave = 4 tile fragments + 4 half fragments, L2 hits, no register passes through
-    constexpr int NP = (AR && KIND == 1) ? 4 : 1;
+    constexpr int NP = (PP && KIND == 1) ? 4 : 1;
     float4 wp[NP], w1f[NP];
     const bool l2_wg = AR && KIND == 1 && bid - 64 < 8;   // the 8 workgroups that also run Prenet layer 2 (32 output units each)
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        wp[i] = (AR && KIND == 1) ? wt[(long)(4 * wave + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        wp[i] = (PP && KIND == 1) ? wt[(long)(4 * wave + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
         // layer-2 fragment: lane (n, h) holds W1[32 i2 + n][8 kg + 4 h .. + 3], kg = 4 wave + i
         w1f[i] = l2_wg ? *reinterpret_cast<const float4*>(p.pre_w1 + (long)(32 * (bid - 64) + bl) * RS_P + 8 * (4 * wave + i) + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -361,14 +370,14 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         // ---- the step's addend (attention LSTM: the Prenet columns, applied to all steps before the loop): its round trip hides
         // under the products
         float4 add4 = bias4;
-        if (AR && XH) {   // this step's Prenet-column fragments on their way into LDS (every reader of `red` / `red2` has passed the barrier that ended the last step)
+        if (PP && XH) {   // this step's Prenet-column fragments on their way into LDS (every reader of `red` / `red2` has passed the barrier that ended the last step)
             const unsigned kg = (unsigned)(4 * wave);
 #pragma unroll
             for (int i = 0; i < 4; ++i) rs_glds(rw_att, (unsigned)lane * 16u, ((unsigned)tile * NKGW + kg + (unsigned)i) * 1024u, stage_t + (unsigned)i * 1024u);
 #pragma unroll
             for (int i = 0; i < 2; ++i) rs_glds(rw_att, v_half, ((unsigned)xt * NKGW + kg + 2u * (unsigned)i) * 1024u, stage_h + (unsigned)i * 1024u);
         }
-        if (ATT && !AR) {
+        if (ATT && !PP) {
             if (cell_wave && bl < B) {
                 const float4 ad = *reinterpret_cast<const float4*>(p.pre_gate + ((long)t * B + bl) * 4 * RS_A + ctile * 32 + 8 * g + 4 * h);
                 add4.x += ad.x; add4.y += ad.y; add4.z += ad.z; add4.w += ad.w;
@@ -380,39 +389,69 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         f32x16 acc, acc2;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc2[q] = 0.f; }
+        // ---- the Prenet columns (autoregressive loop): prenet(t) behind RC_PRE >= t, the one part of this cell on the chain - called
+        // after the others
+        auto prenet_part = [&]() {
+            rs_gate(ctrl, RC_PRE, t, poll, lane);
+            RS_ARSTAMP(2);
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.prenet + (long)(4 * wave) * B * 8);
+            float4 xp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xp[u] = load_sc1(rx, x_lane + (unsigned)u * blkb);
+            if (XH) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staged fragments have landed (and the x fragments with them)
+                const float4* st = reinterpret_cast<const float4*>(red + wave * 16 * 64);
+                const float4* sh = reinterpret_cast<const float4*>(red2 + wave * 8 * 64);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 wl = st[u * 64 + lane];
+                    const float4 hl = sh[u * 32 + hidx];
+                    RS_MFMA32(wl, xp[u])
+                    RS_MFMA16(hl, xp[u])
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { RS_MFMA32(wp[u < NP ? u : 0], xp[u]) }
+            }
+        };
 
         // ---- part 1: the columns whose x is known early
         //   attention LSTM (t):  h_a(t-1) [ring slot t % RS]  behind RC_HA >= t
         //   decoder LSTM (t):    waves 0-3 h_a(t) [slot (t+1) % RS] behind RC_HA >= t + 1, waves 4-7 h_d(t-1) [hc slot t] behind RC_HD >= t
-        {
+        //   decoder LSTM (t) of the autoregressive loop (on the chain): EVERY wave first its sixteenth of the h_d(t-1) columns, then
+        //   of the h_a(t) columns - when h_a(t) arrives all four SIMDs multiply it (1.7 us instead of 3.4 on two), done before the context
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
             const float* xsrc;
             int word, need;
             if (ATT) { xsrc = p.h_a + (long)(t % RS_HA_SLOTS) * RS_A * B + (long)(16 * wave) * B * 8; word = RC_HA; need = t; }
+            else if (ARD && sub == 0) { xsrc = p.hc + (long)t * B * (RS_D + RS_E) + (long)(16 * wave) * B * 8; word = RC_HD; need = t; }
+            else if (ARD) { xsrc = p.h_a + (long)((t + 1) % RS_HA_SLOTS) * RS_A * B + (long)(16 * wave) * B * 8; word = RC_HA; need = t + 1; }
             else if (wave < 4) { xsrc = p.h_a + (long)((t + 1) % RS_HA_SLOTS) * RS_A * B + (long)(32 * wave) * B * 8; word = RC_HA; need = t + 1; }
             else { xsrc = p.hc + (long)t * B * (RS_D + RS_E) + (long)(32 * (wave - 4)) * B * 8; word = RC_HD; need = t; }
             rs_gate(ctrl, word, need, poll, lane);
-            RS_STAMP(1);
-            RS_WGSTAMP(1);
+            if (sub == NSUB - 1) { RS_STAMP(1); RS_WGSTAMP(1); }
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(xsrc);
             constexpr int XG = (XH || RT == 2) ? 2 : 4;   // k-groups per x batch: later batches load while this one multiplies
             // batches in flight ahead of the one being multiplied.  One is enough where the cell is off the chain; the decoder LSTM of
-            // the autoregressive loop has 3.4 us of products on h_a(t) between its arrival and the context's, and a batch's round
-            // trip (0.7 us) is longer than its products (0.43 us): with one batch ahead the part took 6 us and ended after the context
-            constexpr int XD = (AR && KIND == 2) ? 3 : 2;
+            // the autoregressive loop multiplies h_a(t) between its arrival and the context's, and a batch's round trip is longer than
+            // its products (0.43 us)
+            constexpr int XD = ARD ? 3 : 2;
+            constexpr int NNS = NN / NSUB;   // k-groups of this sub-part
             float4 xb[XD][XG];
 #pragma unroll
             for (int d = 0; d < XD - 1; ++d)
 #pragma unroll
                 for (int u = 0; u < XG; ++u) xb[d][u] = load_sc1(rx, x_lane + (unsigned)(XG * d + u) * blkb);
 #pragma unroll
-            for (int gi = 0; gi < NN / XG; ++gi) {
-                if (gi + XD - 1 < NN / XG) {
+            for (int gi = 0; gi < NNS / XG; ++gi) {
+                if (gi + XD - 1 < NNS / XG) {
 #pragma unroll
                     for (int u = 0; u < XG; ++u) xb[(gi + XD - 1) % XD][u] = load_sc1(rx, x_lane + (unsigned)(XG * (gi + XD - 1) + u) * blkb);
                 }
 #pragma unroll
                 for (int u = 0; u < XG; ++u) {
-                    const int i = XG * gi + u;   // compile-time after unrolling: registers / LDS by index
+                    const int i = sub * NNS + XG * gi + u;   // compile-time after unrolling: registers / LDS by index
                     const float4 xv = xb[gi % XD][u];
                     if (i < NRN) {
                         RS_MFMA32(wn[i], xv)
@@ -513,30 +552,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                 RS_ARSTAMP(1);
             }
         }
-        if (AR && ATT) {
-            // ---- part 3 (autoregressive loop): the Prenet columns, prenet(t) behind RC_PRE >= t - the one part of this cell on the chain
-            rs_gate(ctrl, RC_PRE, t, poll, lane);
-            RS_ARSTAMP(2);
-            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.prenet + (long)(4 * wave) * B * 8);
-            float4 xp[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) xp[u] = load_sc1(rx, x_lane + (unsigned)u * blkb);
-            if (XH) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staged fragments have landed (and the x fragments with them)
-                const float4* st = reinterpret_cast<const float4*>(red + wave * 16 * 64);
-                const float4* sh = reinterpret_cast<const float4*>(red2 + wave * 8 * 64);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 wl = st[u * 64 + lane];
-                    const float4 hl = sh[u * 32 + hidx];
-                    RS_MFMA32(wl, xp[u])
-                    RS_MFMA16(hl, xp[u])
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { RS_MFMA32(wp[u < NP ? u : 0], xp[u]) }
-            }
-        }
+        if (AR && PP) prenet_part();
         RS_STAMP(4);
         if (AR) RS_ARSTAMP(3);
 

@@ -16,12 +16,14 @@ touched the GPU - and relays the child's output (rank 0's JSON line) and exit co
 broadcasts the packed blob over RCCL; every rank then runs its own independent batch.
 
 Rank 0 prints ONE JSON line.
-  roofline      dominant kernel (decoder LSTM step launch): algorithmic bytes per launch / its average duration.
-                The duration is measured live with HIP events on the launch stream around 64 back-to-back launches of a
-                mid-sequence step in an instrumented pass right after the timed region (inside the replayed hipGraph a
-                single kernel cannot be bracketed); `decoder_step_us` next to it is the whole step (3 launches incl. their
-                boundaries) taken from HIP events recorded around the decoder loop INSIDE the timed region.  `traffic` is
-                null here: HBM bytes come from separate rocprofv3 --pmc passes (profiles/README.md), never from a file.
+  roofline      dominant kernel: `decoder_resident_kernel`, ONE launch for all T decoder steps (default layer sizes, B <= 32,
+                L <= 256).  Unit = one decoder step for all B rows; `achieved` = SURVEY.md section 8d's algorithmic bytes per step
+                x T / the launch's duration, measured live with a HIP event pair on the launch stream around the kernel in an
+                instrumented pass right after the timed region (third of three warm passes); `decoder_step_us` next to it is the
+                loop's time per step from HIP events recorded INSIDE the timed region.  The kernel keeps the weights on chip, so
+                `traffic` is null: HBM counters cannot be collected for it (`rocprofv3 --pmc` serialises kernels, the resident
+                decoder and attention kernels wait for each other) - see DESIGN.md section 6.  Shapes without the resident
+                kernel report the weight-streaming step launch instead (64 back-to-back replays of a mid-sequence step).
   cpu_baseline  the oracle (CPU restatement of the reference) on the host cores, bounded sample of the same workload.
                 Every timed forward is `forward(batch, strict=False)`: the mirror's default (strict=True) synchronises after each
                 call to look at the hand-off status; here nothing may synchronise inside the timed region, and the status is

@@ -238,6 +238,22 @@ __device__ __forceinline__ void rs_glds(rs_u32x4 rsrc, unsigned voff, unsigned s
     acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32((W).z, (X).z, acc2, 0, 0, 0); \
     acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32((W).w, (X).w, acc2, 0, 0, 0);
 
+// Batches of one or two rows: the same products on the vector ALUs.  A 32 x 32 MFMA tile costs 64 cycles per 2 k whatever the batch
+// is; with one row every lane already holds x[0][8 kg + 4 h ..] (rows past B read row 0), so a k-group is 4 FMAs per lane into ONE
+// accumulator (lane (n, h): row n of the tile, k half h) - 16 cycles instead of 256.
+// (as inline assembly: left to the compiler, the updates of two accumulators were packed into v_pk_fma_f32, whose operands - PAIRS of
+// resident weight registers that are not neighbours - it then copied into 64 more registers, hoisted out of the step loop: spills)
+#define RS_VFMAC(A, W, X) asm("v_fmac_f32 %0, %1, %2" : "+v"(A) : "v"(W), "v"(X));
+#define RS_VDOT(A, W, X) RS_VFMAC(A, (W).x, (X).x) RS_VFMAC(A, (W).y, (X).y) RS_VFMAC(A, (W).z, (X).z) RS_VFMAC(A, (W).w, (X).w)
+// (two rows: even lanes load row 0's fragment, odd lanes row 1's; a lane gets the other row's from its neighbour - DPP quad_perm
+// [1, 0, 3, 2], no LDS - and keeps one accumulator for its OWN row and one for the OTHER; the two swap roles in odd lanes at the end)
+#define RS_DPPSWAP(v) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true))
+#define RS_XROW1(X) make_float4(RS_DPPSWAP((X).x), RS_DPPSWAP((X).y), RS_DPPSWAP((X).z), RS_DPPSWAP((X).w))
+#define RS_MUL32(W, X) if (V) { RS_VDOT(av[0], W, X) if (two_rows) { const float4 x1_ = RS_XROW1(X); RS_VDOT(av[1], W, x1_) } } else { RS_MFMA32(W, X) }
+#define RS_MUL32B(W, X) if (V) { RS_VDOT(av2[0], W, X) if (two_rows) { const float4 x1_ = RS_XROW1(X); RS_VDOT(av2[1], W, x1_) } } else { RS_MFMA32B(W, X) }
+#define RS_MUL16(W, X) if (V) { RS_VDOT(av2[0], W, X) if (two_rows) { const float4 x1_ = RS_XROW1(X); RS_VDOT(av2[1], W, x1_) } } else { RS_MFMA16(W, X) }
+template <bool B> struct RsBool { static constexpr bool value = B; };
+
 }  // namespace
 
 template <int KIND, bool AR>
@@ -277,7 +293,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
     const int bl = lane & 31, h = lane >> 5;
     const bool x_mine = ((lane >> 4) & 1) == xhalf;
     const int mlane = x_mine ? lane : (lane ^ 16);   // the lane whose half-tile fragment this lane multiplies with
-    const unsigned x_lane = (unsigned)((bl < B ? bl : 0) * 8 + 4 * h) * 4u;   // rows past B read row 0; their results are never stored
+    const bool vmode = B <= 2 && !(p.debug & 64), two_rows = B == 2;   // products on the vector ALUs (RS_MUL32; GVX_RS_DEBUG & 64: never)
+    // rows past B read row 0; their results are never stored (vector-ALU mode: row lane % 2 in every lane)
+    const unsigned x_lane = (unsigned)((vmode ? (two_rows ? (bl & 1) : 0) : (bl < B ? bl : 0)) * 8 + 4 * h) * 4u;
 
     // ---- prologue: this wave's weight fragments, once per call.  Wave w owns, in the order it multiplies them (skinny.hip):
     //   attention LSTM: k-groups KG0 + 64 + 16 w + i (h_a columns, i < 16), then KG0 + 8 w + i (context columns, i < 8)
@@ -386,12 +404,19 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                 add4.x += ad.x; add4.y += ad.y; add4.z += ad.z; add4.w += ad.w;
             }
         }
+        f32x16 acc2x;                    // pairs of tiles: the second tile's sums, kept until the second phase of the epilogue
+        float av2x[2] = {0.f, 0.f};      // ... in vector-ALU mode
+        // ---- the step's products and their way into `red`, once with the products on the matrix units and once on the vector ALUs
+        // (B <= 2): two instantiations of one body, so that each has only ITS accumulators live beside the resident weights
+        auto body = [&](auto vc) __attribute__((always_inline)) {
+        constexpr bool V = decltype(vc)::value;
         f32x16 acc, acc2;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc2[q] = 0.f; }
+        float av[2] = {0.f, 0.f}, av2[2] = {0.f, 0.f};   // vector-ALU mode: row b of the tile / of the half or second tile
         // ---- the Prenet columns (autoregressive loop): prenet(t) behind RC_PRE >= t, the one part of this cell on the chain - called
         // after the others
-        auto prenet_part = [&]() {
+        auto prenet_part = [&]() __attribute__((always_inline)) {
             rs_gate(ctrl, RC_PRE, t, poll, lane);
             RS_ARSTAMP(2);
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.prenet + (long)(4 * wave) * B * 8);
@@ -406,12 +431,12 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                 for (int u = 0; u < 4; ++u) {
                     const float4 wl = st[u * 64 + lane];
                     const float4 hl = sh[u * 32 + hidx];
-                    RS_MFMA32(wl, xp[u])
-                    RS_MFMA16(hl, xp[u])
+                    RS_MUL32(wl, xp[u])
+                    RS_MUL16(hl, xp[u])
                 }
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { RS_MFMA32(wp[u < NP ? u : 0], xp[u]) }
+                for (int u = 0; u < 4; ++u) { RS_MUL32(wp[u < NP ? u : 0], xp[u]) }
             }
         };
 
@@ -420,6 +445,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         //   decoder LSTM (t):    waves 0-3 h_a(t) [slot (t+1) % RS] behind RC_HA >= t + 1, waves 4-7 h_d(t-1) [hc slot t] behind RC_HD >= t
         //   decoder LSTM (t) of the autoregressive loop (on the chain): EVERY wave first its sixteenth of the h_d(t-1) columns, then
         //   of the h_a(t) columns - when h_a(t) arrives all four SIMDs multiply it (1.7 us instead of 3.4 on two), done before the context
+        {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
             const float* xsrc;
@@ -454,17 +480,18 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                     const int i = sub * NNS + XG * gi + u;   // compile-time after unrolling: registers / LDS by index
                     const float4 xv = xb[gi % XD][u];
                     if (i < NRN) {
-                        RS_MFMA32(wn[i], xv)
-                        if (XH) { RS_MFMA16(hn[i < NRH ? i : 0], xv) }
-                        if (RT == 2) { RS_MFMA32B(wn2[i < NR2 ? i : 0], xv) }
+                        RS_MUL32(wn[i], xv)
+                        if (XH) { RS_MUL16(hn[i < NRH ? i : 0], xv) }
+                        if (RT == 2) { RS_MUL32B(wn2[i < NR2 ? i : 0], xv) }
                     } else {
                         const float4 wl = lw[(i - NRN) * RT * 64 + lane];
-                        RS_MFMA32(wl, xv)
-                        if (XH) { const float4 hl = lh[(i - NRN) * 32 + hidx]; RS_MFMA16(hl, xv) }
-                        if (RT == 2) { const float4 wl2 = lw[((i - NRN) * RT + 1) * 64 + lane]; RS_MFMA32B(wl2, xv) }
+                        RS_MUL32(wl, xv)
+                        if (XH) { const float4 hl = lh[(i - NRN) * 32 + hidx]; RS_MUL16(hl, xv) }
+                        if (RT == 2) { const float4 wl2 = lw[((i - NRN) * RT + 1) * 64 + lane]; RS_MUL32B(wl2, xv) }
                     }
                 }
             }
+        }
         }
         RS_STAMP(2);
         // ---- part 2: the context columns (registers): ctx(t-1) [hc slot t] behind RC_CTX >= t (attention LSTM), ctx(t) [hc slot t + 1]
@@ -493,9 +520,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
 #pragma unroll
                 for (int u = 0; u < XG; ++u) {
                     const int i = XG * gi + u;
-                    RS_MFMA32(wc[i], xc[u])
-                    if (XH) { RS_MFMA16(hc[i < NCH ? i : 0], xc[u]) }
-                    if (RT == 2) { RS_MFMA32B(wc2[i < NC2 ? i : 0], xc[u]) }
+                    RS_MUL32(wc[i], xc[u])
+                    if (XH) { RS_MUL16(hc[i < NCH ? i : 0], xc[u]) }
+                    if (RT == 2) { RS_MUL32B(wc2[i < NC2 ? i : 0], xc[u]) }
                 }
 #pragma unroll
                 for (int u = 0; u < XG; ++u) xc[u] = xn[u];
@@ -520,10 +547,24 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                     __hip_atomic_store(p.sync + HANDOFF_STOP, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ctrl + RC_ABORT, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                if (V) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { RS_MFMA32B(w1f[u < NP ? u : 0], xy[u]) }
+                    for (int u = 0; u < 4; ++u) { RS_MUL32B(w1f[u < NP ? u : 0], xy[u]) }
+                    // lane (n, hh) holds its k half of unit n: both halves, then into the MFMA result layout (lane (b, hh'), register
+                    // 4 g + r = unit 8 g + 4 hh' + r) for rows b < B - the other columns of `red` are never stored
+                    if (two_rows && (lane & 1)) { const float s2 = av2[0]; av2[0] = av2[1]; av2[1] = s2; }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { red[(wave * 16 + q) * 64 + lane] = acc2[q]; acc2[q] = 0.f; }
+                    for (int b = 0; b < 2; ++b) {
+                        av2[b] += __shfl_xor(av2[b], 32, 64);
+                        if (h == 0 && b < B) red[(wave * 16 + 4 * (bl >> 3) + (bl & 3)) * 64 + b + 32 * ((bl >> 2) & 1)] = av2[b];
+                        av2[b] = 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { RS_MFMA32B(w1f[u < NP ? u : 0], xy[u]) }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { red[(wave * 16 + q) * 64 + lane] = acc2[q]; acc2[q] = 0.f; }
+                }
                 rs_cbar();
                 if (wave < 4) {   // lane (b, hh) of wave g: units 32 i2 + 8 g + 4 hh .. + 3 of row b
                     float4 o;
@@ -555,9 +596,45 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         if (AR && PP) prenet_part();
         RS_STAMP(4);
         if (AR) RS_ARSTAMP(3);
+        // ---- cross-wave K reduction through LDS (same order as skinny.hip): this wave's sums into its rows of `red`
+        {
+        int tr = tid;
+        asm volatile("" : "+v"(tr));
+        const int el = tr & 63;
+        if (V) {
+            // vector-ALU mode: lane (n, hh) holds its k half of row n of the tile for batch rows 0 (1): both halves, then into the MFMA
+            // result layout the cell waves read (tile: lane (b, hh'), register 4 g + r = row 8 g + 4 hh' + r; half tile: lane
+            // (b % 16, unit), register 4 (b / 16) + gate).  Columns of rows >= B keep old bytes: their cells are never stored
+            const int en = el & 31;
+            if (two_rows && (el & 1)) {   // odd lanes: "own" was row 1
+                const float s0 = av[0], s2 = av2[0];
+                av[0] = av[1]; av[1] = s0; av2[0] = av2[1]; av2[1] = s2;
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                av[b] += __shfl_xor(av[b], 32, 64);
+                if (XH || RT == 2) av2[b] += __shfl_xor(av2[b], 32, 64);
+                if (el < 32 && b < B) red[(wave * 16 + 4 * (en >> 3) + (en & 3)) * 64 + b + 32 * ((en >> 2) & 1)] = av[b];
+                // (half tile: the lanes that hold their own fragment, rows 16 xhalf + (lane & 15) of the neighbour's tile)
+                if (XH && el < 32 && ((el >> 4) & 1) == xhalf && b < B) red2[(wave * 8 + (el & 3)) * 64 + b + 16 * ((el & 15) >> 2)] = av2[b];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + el] = acc[q];
+            if (XH) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) red2[(wave * 8 + q) * 64 + el] = acc2[q] + acc2[8 + q];
+            }
+        }
+        if (RT == 2) {
+            if (V) { av2x[0] = av2[0]; av2x[1] = av2[1]; } else acc2x = acc2;
+        }
+        }
+        };
+        if (vmode) body(RsBool<true>{}); else body(RsBool<false>{});
 
-        // ---- cross-wave K reduction through LDS (same order as skinny.hip).  The epilogue's per-lane indices are recomputed from an
-        // opaque copy of the thread id: hoisted out of the step loop they would sit in registers the resident weights need
+        // ---- the epilogue's per-lane indices are recomputed from an opaque copy of the thread id: hoisted out of the step loop they
+        // would sit in registers the resident weights need
         int te = tid;
         asm volatile("" : "+v"(te));
         const int el = te & 63, ebl = el & 31, eh = el >> 5;
@@ -586,12 +663,6 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                 wq_d = *reinterpret_cast<const float4*>(wq_l2 + 4);
             }
         }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + el] = acc[q];
-        if (XH) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) red2[(wave * 8 + q) * 64 + el] = acc2[q] + acc2[8 + q];
-        }
         rs_cbar();
         RS_STAMP(5);
         if (cell2_wave) {
@@ -619,8 +690,15 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         for (int ph = 0; ph < RT; ++ph) {
             if (ph == 1) {
                 rs_cbar();
+                if (vmode) {
+                    const int en = el & 31;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + el] = acc2[q];
+                    for (int b = 0; b < 2; ++b)
+                        if (el < 32 && b < B) red[(wave * 16 + 4 * (en >> 3) + (en & 3)) * 64 + b + 32 * ((en >> 2) & 1)] = av2x[b];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + el] = acc2x[q];
+                }
                 rs_cbar();
             }
             if (cell_wave && (wave >> 2) == ph) {

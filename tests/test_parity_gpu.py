@@ -315,14 +315,16 @@ def _ragged_batch(mc, ac, tc, B, L, T, seed):
     return batch
 
 
-@pytest.mark.parametrize("B,L,T", [(7, 100, 33), (32, 128, 24), (1, 1, 1), (32, 5, 2), (17, 127, 9), (3, 64, 70),
+@pytest.mark.parametrize("B,L,T", [(7, 100, 33), (32, 128, 24), (1, 1, 1), (32, 5, 2), (17, 127, 9), (3, 64, 70), (1, 100, 40), (2, 128, 30), (2, 200, 12),
                                    # 128 < L <= 256: 192 workgroups (pairs of attention-LSTM tiles) beside two attention workgroups per row
                                    (3, 129, 6), (32, 190, 12), (5, 143, 9), (1, 256, 4), (32, 256, 3), (9, 200, 40)])
 def test_resident_decoder_equals_launch_per_step(B, L, T, monkeypatch):
     """The teacher-forced loop as ONE resident weight-streaming kernel (dec_resident.hip: loader ring in LDS, hand-offs by
     flags; the default for B <= 32, L <= 128) against the same loop as a launch per step (GVX_TF_RESIDENT=0: skinny.hip beside
     the resident attention kernel).  Same tiles, K slices and summation order: the outputs must agree BIT FOR BIT, repeatably,
-    with a clear hand-off status word - and match the oracle (models/tts/tacotron2.py:365-388) within 1e-3."""
+    with a clear hand-off status word - and match the oracle (models/tts/tacotron2.py:365-388) within 1e-3.  (Batches of one or two
+    rows: the resident kernel multiplies on the vector ALUs, one FMA chain per row of a tile instead of the MFMA's order - equal to
+    fp32 rounding, 2e-5.)"""
     res, sd, (mc, ac, tc) = _default_model()
     batch = _ragged_batch(mc, ac, tc, B, L, T, seed=B + L + T)
     out = {k: v.clone() for k, v in res.forward(batch).items()}
@@ -336,7 +338,10 @@ def test_resident_decoder_equals_launch_per_step(B, L, T, monkeypatch):
     for k in KEYS:
         assert torch.isfinite(out[k]).all(), k
         assert torch.equal(out[k], out2[k]), f"{k}: two runs differ by {max_abs_diff(out[k], out2[k])}"
-        assert torch.equal(out[k], ref[k]), f"{k}: resident loop differs from the launch-per-step loop by {max_abs_diff(out[k], ref[k])}"
+        if B > 2:
+            assert torch.equal(out[k], ref[k]), f"{k}: resident loop differs from the launch-per-step loop by {max_abs_diff(out[k], ref[k])}"
+        else:
+            assert max_abs_diff(out[k], ref[k]) <= 2e-5, f"{k}: resident loop differs from the launch-per-step loop by {max_abs_diff(out[k], ref[k])}"
     if B * T <= 300:
         P = mc.prenet_dim
         want = tacotron2_ref.tacotron2_forward(sd, batch, batch["prenet_keep_masks"].reshape(2, -1, P), mask_padding=True)
@@ -604,7 +609,7 @@ def test_autoregressive_resident_attention_equals_per_step(monkeypatch):
         assert max_abs_diff(got, want[k]) <= TOL, k
 
 
-@pytest.mark.parametrize("lens", [[50, 41, 33, 20, 9], [64 - b for b in range(32)], [77], [128, 1, 90]])
+@pytest.mark.parametrize("lens", [[50, 41, 33, 20, 9], [64 - b for b in range(32)], [77], [128, 1, 90], [101, 60]])
 def test_autoregressive_resident_loop_equals_launch_per_step(lens, monkeypatch):
     """The default autoregressive decode for <= 32 rows of <= 128 tokens: TWO resident kernels for the whole loop
     (decoder_ar_resident_kernel - both LSTM cells, projection slabs, Prenet layer 2 out of weights that stay in registers and LDS -
@@ -640,8 +645,8 @@ def test_autoregressive_resident_loop_equals_launch_per_step(lens, monkeypatch):
     want_kind = 2
     probe = run(1.0)   # no row ever fires: the loop runs into max_decoder_steps
     assert probe["mel_outputs"].shape[2] == steps
-    g = torch.sigmoid(probe["gate_outputs"][:, :8]).cpu()
-    thr = float(g.flatten().sort().values[g.numel() // 2])
+    g = torch.sigmoid(probe["gate_outputs"][:, :8]).cpu().flatten().sort().values
+    thr = float(g[g.numel() // 2] + g[g.numel() // 2 - 1]) / 2   # between two gate values: rounding cannot move a stop step
     res = run(thr)
     # ... and one that every row crosses at some step: the kernels end the loop themselves, before max_decoder_steps
     gall = torch.sigmoid(probe["gate_outputs"][:, :steps - 8]).cpu()

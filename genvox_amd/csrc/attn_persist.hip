@@ -93,7 +93,7 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 
 // One WAVE waits until every one of the n (<= 128) flag words (one per 128-byte line) reads >= target: two words per lane per look.  Bounded like
 // handoff_wait<true>; returns false (wave-uniform) when the wait was given up, by a time-out here or anywhere else, or by the
-// host's stop word.
+// host's stop word.  (Two looks in flight half a round trip apart were measured: no gain - 22.07 vs 21.68 us per autoregressive step.)
 __device__ __forceinline__ bool flags_wait(const unsigned* flags, int n, unsigned target, unsigned* tmo, unsigned code, unsigned limit,
                                            const unsigned* stop, bool nosleep) {
     if (limit == 0u) limit = HANDOFF_SPIN_LIMIT;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             KargPtr kq = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kq));
             if (p.q_flags && !flags_wait(kq->q_flags + ((b % RS_REP1) * kq->n_q_flags + 2 * SPG * wave) * 32, 2 * SPG, (unsigned)t + 1u, tmo, 0x100u + (unsigned)b,
-                                         kq->spin_limit, stop, (kq->debug & 32) != 0) && (tid & 63) == 0) *leave = 1;
+                                         kq->spin_limit, stop, (kq->debug & 32) == 0) && (tid & 63) == 0) *leave = 1;
             if (p.q_flags) PA_STAMP(1);   // (wave 0's slabs seen)
             float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 ql[SPG];
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             if (more && ta < PA_P) k0 = kp->keep0[((long)(t + 1) * B + b) * PA_P + ta];
             // ---- the slabs of the step: wave w takes those of decoder-LSTM workgroups 8 w .. 8 w + 7 as soon as THEIR flags are up (45 KB per
             // row: the same reasoning as for the query slabs), lanes (g, n4): slabs 8 w + 4 g .. + 3, float4 column n4
-            if (!flags_wait(kp->p_flags + ((b % RS_REP_P) * 128 + 8 * wave) * 32, 8, (unsigned)t + 1u, tmo, 0x600u + (unsigned)b, kp->spin_limit, stop, (kp->debug & 32) != 0) && (tid & 63) == 0) *leave = 1;
+            if (!flags_wait(kp->p_flags + ((b % RS_REP_P) * 128 + 8 * wave) * 32, 8, (unsigned)t + 1u, tmo, 0x600u + (unsigned)b, kp->spin_limit, stop, (kp->debug & 32) == 0) && (tid & 63) == 0) *leave = 1;
             PA_ARSTAMP(0);   // projection slabs of wave 0 seen
             const int n4c = PSB >> 2;                 // float4 per slab row (<= 24)
             {

@@ -227,7 +227,7 @@ struct AttnPersistParams {
     // t + 1 into ctx_flags[b] (in place of the context counter); nullptr otherwise
     const unsigned* q_flags; int n_q_flags;   // producer i's flag for the rows of replica r at q_flags[(r * n_q_flags + i) * 32], r < RS_REP1
     unsigned* ctx_flags;                      // replica r of row b's flag at ctx_flags[(r * 32 + b) * 32], r < RS_REP1
-    int debug;   // timing experiments (GVX_RS_DEBUG & 32: no sleep between looks at the flags)
+    int debug;   // timing experiments (GVX_RS_DEBUG & 32: s_sleep between looks at the flags)
     // autoregressive role (beside decoder_ar_resident_kernel; p_slab == nullptr otherwise): after publishing its context, row b
     // waits for the 128 projection slabs of the step (p_flags), sums them into the step's frame + gate (proj_out), runs the stop
     // test and Prenet layer 1 on the frame and hands y1 to the Prenet workgroups (y1_flags)

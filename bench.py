@@ -33,7 +33,7 @@ Rank 0 prints ONE JSON line.
                 same Prenet-mask seed bit for bit.
   extra         (N = 1) the other BASELINE configurations, each timed like the headline (warm-up, then K runs bracketed by
                 synchronize) with its own roofline fraction and CPU-oracle figure: c1_b1x568 (configs[0]), tf_b64x800,
-                ar_b64_1000, ar_b1_1000, postnet_b256x800, train_step_b32x200, gl_60it_b256x800.
+                ar_b64_1000, ar_b1_1000, ar_b1_1000_L190 (a long sentence), postnet_b256x800, train_step_b32x200, gl_60it_b256x800.
                 (N > 1) ar_b64_1000_per_rank: every rank decodes 64 rows autoregressively at the same time.
 """
 import argparse
@@ -337,19 +337,19 @@ def main():
 
     audio_s_per_frame = ac.hop_length / ac.sampling_rate
 
-    def ar_leg(bb, reps=3):
+    def ar_leg(bb, reps=3, tokens=None):
         """Autoregressive decode of bb rows x max_decoder_steps (the gate never fires): seconds per batch."""
         mc.gate_threshold = 1.0   # never fires: exactly max_decoder_steps frames (BASELINE configs[2])
-        tok = torch.from_numpy(gw.synthetic_inputs(bb, L, 8, tc.n_tokens, ac.n_mels, seed=3 + rank)["token_padded"]).to(dev)
+        tok = torch.from_numpy(gw.synthetic_inputs(bb, tokens or L, 8, tc.n_tokens, ac.n_mels, seed=3 + rank)["token_padded"]).to(dev)
         with contextlib.redirect_stdout(sys.stderr):   # "Warning! Reached max decoder steps" must not land next to the JSON line
             dt = timed(torch, lambda: model.inference({"tokens": tok}), 2, reps)
         mc.gate_threshold = 0.5
         model.check_status()
         return dt, tok
 
-    def ar_entry(dt, bb, n_streams):
+    def ar_entry(dt, bb, n_streams, tokens=None):
         S = mc.max_decoder_steps
-        kind = model.ar_loop_kind(min(bb, 32), L)
+        kind = model.ar_loop_kind(min(bb, 32), tokens or L)
         execution = {2: "two resident kernels per 32-row chunk for the whole decode (weight-stationary LSTM / projection / Prenet kernel beside the "
                         "attention rows; the kernels end the loop themselves)" + (", chunks one after the other" if bb > 32 else ""),
                      1: "launches per step beside the resident attention kernel, host stop polling",
@@ -373,7 +373,7 @@ def main():
 
     # ---- the other BASELINE configurations (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_extra:
-        want = set(filter(None, args.only_extra.split(","))) or {"c1_b1x568", "tf_b64x800", "ar_b64_1000", "ar_b1_1000", "postnet_b256x800",
+        want = set(filter(None, args.only_extra.split(","))) or {"c1_b1x568", "tf_b64x800", "ar_b64_1000", "ar_b1_1000", "ar_b1_1000_L190", "postnet_b256x800",
                                                                   "train_step_b32x200", "gl_60it_b256x800"}
         with_cpu = not args.no_cpu_baseline
         extra = {"host_cpu": cpu_model, "cpu_threads": n_thr}
@@ -442,6 +442,10 @@ def main():
                                      "cores": n_thr, "kind": "port",
                                      "sample": f"oracle Tacotron2.inference, batch 1 (the reference's only autoregressive mode), {steps_c} steps incl. encoder + Postnet"}
             extra[key] = e
+        if "ar_b1_1000_L190" in want:   # a long sentence (the reference's autoregressive mode is batch 1; LJSpeech rows reach ~190 characters)
+            log("extra: autoregressive batch 1 x 1000 steps, 190 tokens")
+            dt, _ = ar_leg(1, tokens=190)
+            extra["ar_b1_1000_L190"] = ar_entry(dt, 1, 1, tokens=190)
         if "postnet_b256x800" in want:
             log("extra: Postnet batch 256 x 800 (one call)")
             mel = torch.randn(256, ac.n_mels, T, device=dev)

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         // the chain - the features have until the next query arrives, two hand-offs and a cell later)
         if (!AR && t + 1 < p.T) location_features();
         PA_STAMP(6);
-        if (AR) {
+        if (AR && hf == 0) {   // (a row of two halves: half 0, which has published the context, finishes the step)
             int ta = tid;
             asm volatile("" : "+v"(ta));
             // (the role's parameters are read from the kernel-argument segment every step: kept in scalar registers for the whole
@@ -559,8 +559,8 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             __syncthreads();
             PA_ARSTAMP(2);   // layer 1 stored
             if (ta == 0) __hip_atomic_store(kp->y1_flags + b * 32, (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (more) location_features();
         }
+        if (AR && t + 1 < p.T) location_features();
     }
 }
 
@@ -592,6 +592,7 @@ hipError_t attention_persistent_init() {
     if ((e = pa_set_lds(attn_persistent_kernel<3, false>)) != hipSuccess) return e;
     if ((e = pa_set_lds(attn_persistent_kernel<4, false>)) != hipSuccess) return e;
     if ((e = pa_set_lds(attn_persistent_kernel<3, false, true>)) != hipSuccess) return e;
+    if ((e = pa_set_lds(attn_persistent_kernel<3, true, true>)) != hipSuccess) return e;
     return pa_set_lds(attn_persistent_kernel<2, true>);
 }
 
@@ -616,14 +617,18 @@ hipError_t read_stamps_persist(unsigned long long* host96) {
 hipError_t launch_attention_persistent(const AttnPersistParams& p, hipStream_t s) {
     if (!attention_persistent_supported(p.B, p.L, PA_A, 32, p.kl, PA_E, 1024, 1024) || p.T < 1) return hipErrorInvalidValue;
     const size_t lds = PA_LDS_FLOATS * sizeof(float);
-    if (p.L > PA_L) {
-        if (p.n_slabs != 64 || !p.xchg) return hipErrorInvalidValue;
-        attn_persistent_kernel<2, true><<<dim3(2 * p.B), dim3(PA_THREADS), lds, s>>>(p);
-    } else if (p.p_slab) {   // autoregressive role beside decoder_ar_resident_kernel
+    if (p.p_slab) {   // autoregressive role beside decoder_ar_resident_kernel (224-workgroup deal: 96 slabs; rows of 129-256 tokens: two
+                      // workgroups per row, which leaves room for 16 rows beside the 224)
         if (p.n_slabs != PA_SLABS || !p.q_flags || !p.ctx_flags || !p.p_flags || !p.y1_flags || !p.proj_b || !p.proj_out || !p.pre_w0_t || !p.keep0 ||
             !p.y1 || !p.n_frames || !p.n_done || p.n_mels < 1 || p.n_mels > 16 * PA_KPT || p.PSB < p.n_mels + 1 || p.PSB > 96 || (p.PSB & 3))
             return hipErrorInvalidValue;
-        attn_persistent_kernel<3, false, true><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
+        if (p.L > PA_L) {
+            if (!p.xchg || p.B > 16) return hipErrorInvalidValue;
+            attn_persistent_kernel<3, true, true><<<dim3(2 * p.B), dim3(PA_THREADS), lds, s>>>(p);
+        } else attn_persistent_kernel<3, false, true><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
+    } else if (p.L > PA_L) {
+        if (p.n_slabs != 64 || !p.xchg) return hipErrorInvalidValue;
+        attn_persistent_kernel<2, true><<<dim3(2 * p.B), dim3(PA_THREADS), lds, s>>>(p);
     } else if (p.n_slabs == PA_SLABS) attn_persistent_kernel<3, false><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
     else if (p.n_slabs == PA_SLABS_AR) attn_persistent_kernel<4, false><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
     else return hipErrorInvalidValue;

@@ -1074,8 +1074,10 @@ int turn_end(hipStream_t s) {     // caller holds g_turn_mutex
 // handle that has the chip to itself
 bool ar_resident_loop_ok(const gvx_model* m, int B, int L) {
     const gvx_dims& d = m->d;
+    const int lay = attention_persistent_layout(B, L);
+    // (rows of 129-256 tokens take two attention workgroups each: 16 rows of them fit beside the 224 workgroups of the tile kernel)
     return B <= 32 && d.embed_dim / 4 == d.dec_rnn_dim / 8 && m->attn_persistent && m->tf_resident && m->ar_resident_loop &&
-           decoder_resident_supported(B, L) && attention_persistent_layout(B, L) == 1 && d.prenet_dim == 256 && d.n_mels <= 80 &&
+           decoder_resident_supported(B, L) && (lay == 1 || (lay == 2 && B <= 16)) && d.prenet_dim == 256 && d.n_mels <= 80 &&
            m->PSB() <= 96 && d.att_dim == 128;
 }
 
@@ -1543,9 +1545,10 @@ int gvx_autoregressive_loop_kind(const gvx_model* m, int B, int L) {
     const gvx_dims& d = m->d;
     const bool pa_ok = m->attn_one_launch && attention_persistent_layout(B, L) == 1 &&
                        attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
-    if (!pa_ok) return 0;
-    if (ar_resident_loop_ok(m, B, L)) return 2;
-    return m->ar_resident ? 1 : 0;
+    const bool pa_any = m->attn_one_launch &&
+                        attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
+    if (pa_any && ar_resident_loop_ok(m, B, L)) return 2;
+    return pa_ok && m->ar_resident ? 1 : 0;
 }
 
 int gvx_model_set_persistent_attention(gvx_model* m, int enable) {
@@ -1849,14 +1852,15 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
     // the whole decode, the context of a step arrives inside launch C (deferred segment) and the attention launch leaves the
     // step's chain.  The projection's context columns then ride on the decoder-LSTM tiles' projection slabs (`fold`), so that
     // launch C is exactly 256 tiles.
-    const bool pa_ok = m->attn_one_launch && attention_persistent_layout(B, L) == 1 &&
-                       attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
+    const bool pa_any = m->attn_one_launch &&
+                        attention_persistent_supported(B, L, d.att_dim, d.att_loc_filters, d.att_loc_kernel, d.embed_dim, d.att_rnn_dim, d.dec_rnn_dim);
+    const bool pa_ok = pa_any && attention_persistent_layout(B, L) == 1;
     const bool fold = B <= 32 && E / 4 == D / 8;
     // ... and when the layer sizes are the default ones, the LSTM cells, the projection and the Prenet live in a second resident
     // kernel as well (dec_resident.hip, decoder_ar_resident_kernel): the whole decode is two launches.  Not on handles that share
     // the chip with other calls (gvx_model_set_persistent_attention(model, 0): the two kernels need all 256 CUs)
-    const bool ar_res = pa_ok && ar_resident_loop_ok(m, B, L);
-    const bool pa = pa_ok && (m->ar_resident || ar_res);
+    const bool ar_res = pa_any && ar_resident_loop_ok(m, B, L);
+    const bool pa = (pa_ok && m->ar_resident) || ar_res;
     // h_a(t) exists when launch A ends, the context only after the attention step: the h_a columns of both cells (two thirds of
     // what launch C used to stream) are summed by tiles that share the attention step's launch - the step's latency chain
     // hides under 33 MB of weight stream - and launch C is left with the context columns
@@ -2043,6 +2047,7 @@ int gvx_decoder_autoregressive(gvx_model* m, const float* memory, const int32_t*
         static const int dbg = [] { const char* e = std::getenv("GVX_RS_DEBUG"); return e ? std::atoi(e) : 0; }();
         AttnPersistParams pp{};
         pp.q_slab = db.q_slab; pp.n_slabs = attention_persistent_slabs(1);
+        pp.xchg = ws_ptr<float>(ws, wp.xchg);   // (rows of 129-256 tokens: the halves' exchange buffers)
         pp.v = m->dev_blob + m->blob.v; pp.pm = db.pm; pp.memory = memory_ws; pp.lengths = len_ws;
         pp.loc_conv_t = m->dev_blob + m->blob.loc_conv; pp.loc_dense_t = m->dev_blob + m->blob.loc_dense;
         pp.w_out = db.align_tm; pp.w_out_bs = (long)L; pp.w_out_ts = (long)B * L;

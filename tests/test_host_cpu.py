@@ -82,6 +82,9 @@ def test_resident_loop_policy_queries():
     assert lib.gvx_teacher_forced_loop_kind(h, 32, 128) == 2 and lib.gvx_teacher_forced_loop_kind(h, 3, 200) == 2
     assert lib.gvx_autoregressive_loop_kind(h, 1, 128) == 2 and lib.gvx_autoregressive_loop_kind(h, 32, 77) == 2
     assert lib.gvx_autoregressive_loop_kind(h, 32, 129) == 0 and lib.gvx_autoregressive_loop_kind(h, 33, 64) == 0
+    # rows of 129-256 tokens: two attention workgroups per row, up to 16 rows beside the 224 workgroups of the tile kernel
+    assert lib.gvx_autoregressive_loop_kind(h, 16, 190) == 2 and lib.gvx_autoregressive_loop_kind(h, 1, 256) == 2
+    assert lib.gvx_autoregressive_loop_kind(h, 17, 190) == 0 and lib.gvx_autoregressive_loop_kind(h, 1, 257) == 0
     assert lib.gvx_autoregressive_loop_kind(h, 0, 64) == 0 and lib.gvx_autoregressive_loop_kind(None, 1, 64) == 0
     assert lib.gvx_model_set_persistent_attention(h, 0) == 0
     assert lib.gvx_teacher_forced_resident(h, 32, 128) == 0

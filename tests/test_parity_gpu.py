@@ -609,9 +609,11 @@ def test_autoregressive_resident_attention_equals_per_step(monkeypatch):
         assert max_abs_diff(got, want[k]) <= TOL, k
 
 
-@pytest.mark.parametrize("lens", [[50, 41, 33, 20, 9], [64 - b for b in range(32)], [77], [128, 1, 90], [101, 60]])
+@pytest.mark.parametrize("lens", [[50, 41, 33, 20, 9], [64 - b for b in range(32)], [77], [128, 1, 90], [101, 60],
+                                  # rows of 129-256 tokens: two attention workgroups per row (<= 16 rows)
+                                  [190], [256, 140, 131], [129 + 7 * b for b in range(16)]])
 def test_autoregressive_resident_loop_equals_launch_per_step(lens, monkeypatch):
-    """The default autoregressive decode for <= 32 rows of <= 128 tokens: TWO resident kernels for the whole loop
+    """The default autoregressive decode for <= 32 rows of <= 128 tokens (<= 16 rows of <= 256): TWO resident kernels for the whole loop
     (decoder_ar_resident_kernel - both LSTM cells, projection slabs, Prenet layer 2 out of weights that stay in registers and LDS -
     beside the resident attention kernel, which also sums the frame, tests the stop token and runs Prenet layer 1); the kernels end
     the loop themselves when every row has fired.  Against the launch-per-step schedule (GVX_AR_RESIDENT_LOOP=0): ragged token

@@ -593,6 +593,7 @@ hipError_t attention_persistent_init() {
     if ((e = pa_set_lds(attn_persistent_kernel<4, false>)) != hipSuccess) return e;
     if ((e = pa_set_lds(attn_persistent_kernel<3, false, true>)) != hipSuccess) return e;
     if ((e = pa_set_lds(attn_persistent_kernel<3, true, true>)) != hipSuccess) return e;
+    if ((e = pa_set_lds(attn_persistent_kernel<3, true>)) != hipSuccess) return e;
     return pa_set_lds(attn_persistent_kernel<2, true>);
 }
 
@@ -627,8 +628,10 @@ hipError_t launch_attention_persistent(const AttnPersistParams& p, hipStream_t s
             attn_persistent_kernel<3, true, true><<<dim3(2 * p.B), dim3(PA_THREADS), lds, s>>>(p);
         } else attn_persistent_kernel<3, false, true><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
     } else if (p.L > PA_L) {
-        if (p.n_slabs != 64 || !p.xchg) return hipErrorInvalidValue;
-        attn_persistent_kernel<2, true><<<dim3(2 * p.B), dim3(PA_THREADS), lds, s>>>(p);
+        if (!p.xchg) return hipErrorInvalidValue;
+        if (p.n_slabs == 64) attn_persistent_kernel<2, true><<<dim3(2 * p.B), dim3(PA_THREADS), lds, s>>>(p);
+        else if (p.n_slabs == PA_SLABS && p.B <= 16) attn_persistent_kernel<3, true><<<dim3(2 * p.B), dim3(PA_THREADS), lds, s>>>(p);   // (beside the 224-workgroup tile kernel)
+        else return hipErrorInvalidValue;
     } else if (p.n_slabs == PA_SLABS) attn_persistent_kernel<3, false><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
     else if (p.n_slabs == PA_SLABS_AR) attn_persistent_kernel<4, false><<<dim3(p.B), dim3(PA_THREADS), lds, s>>>(p);
     else return hipErrorInvalidValue;

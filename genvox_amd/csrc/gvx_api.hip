@@ -153,6 +153,7 @@ struct gvx_model {
     // B <= 32, L <= 128, inference mode; GVX_TF_RESIDENT=0 keeps the launch per step
     bool tf_resident = true;
     bool ar_resident_loop = true;   // autoregressive decode as two resident kernels (GVX_AR_RESIDENT_LOOP=0: launches per step)
+    bool tf_long_rows_224 = true;   // teacher-forced rows of 129-256 tokens, <= 16 rows: the 224-workgroup deal (GVX_TF_LONG_224=0: 192)
     int pa_depth = 4;                  // GVX_PA_DEPTH=6: prefetch depth of the launch beside the resident kernel (tests, A/B runs)
     unsigned spin_limit = 0;           // GVX_HANDOFF_SPIN_LIMIT: polls before an in-launch wait gives up (0 = the built-in limit)
     bool debug_skip_resident = false;  // GVX_DEBUG_SKIP_RESIDENT=1: never launch the resident attention kernel, so that every
@@ -458,6 +459,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     if (const char* e = std::getenv("GVX_TF_ROWS64")) m->tf_rows64 = e[0] == '1';
     if (const char* e = std::getenv("GVX_TF_RESIDENT")) m->tf_resident = e[0] != '0';
     if (const char* e = std::getenv("GVX_AR_RESIDENT_LOOP")) m->ar_resident_loop = e[0] != '0';
+    if (const char* e = std::getenv("GVX_TF_LONG_224")) m->tf_long_rows_224 = e[0] != '0';
     if (const char* e = std::getenv("GVX_PA_DEPTH")) m->pa_depth = std::atoi(e) == 6 ? 6 : 4;
     if (const char* e = std::getenv("GVX_HANDOFF_SPIN_LIMIT")) m->spin_limit = (unsigned)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("GVX_DEBUG_SKIP_RESIDENT")) m->debug_skip_resident = e[0] == '1';
@@ -1192,6 +1194,11 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
     // ... and the LSTM launches as ONE resident kernel too (dec_resident.hip): inference mode, one batch tile, L <= 128
     const bool resident = pa && (pa_layout == 1 || pa_layout == 2) && m->tf_resident && !train && decoder_resident_supported(B, L);
+    // the resident tile kernel's deal: 224 workgroups beside <= 32 attention workgroups - rows of 129-256 tokens take two each, so
+    // up to 16 such rows keep the 224-workgroup deal (its 48-row workgroups are lighter than the pairs of the 192-workgroup one:
+    // 15.4 vs 17.3 us per step at 16 x L = 190; not at B <= 2, where the products run on the vector ALUs and the 64 slabs of the
+    // 192-workgroup deal win: 13.9 vs 14.2)
+    const int tile_layout = resident && pa_layout == 2 && B > 2 && B <= 16 && m->tf_long_rows_224 ? 1 : pa_layout;
     if (pa && !prenet_done) {   // (the fused forward has taken a side stream for this call already: the encoder ran on it)
         rc = ensure_side_stream(m);
         if (rc != GVX_OK) return rc;
@@ -1220,7 +1227,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         HIP_TRY(hipEventRecord(m->pa_fork, st));
         HIP_TRY(hipStreamWaitEvent(m->pa_stream, m->pa_fork, 0));
         AttnPersistParams pp{};
-        pp.q_slab = db.q_slab; pp.n_slabs = attention_persistent_slabs(pa_layout);
+        pp.q_slab = db.q_slab; pp.n_slabs = attention_persistent_slabs(resident ? tile_layout : pa_layout);
         pp.xchg = ws_ptr<float>(ws, wp.xchg);
         pp.v = m->dev_blob + m->blob.v; pp.pm = db.pm; pp.memory = memory; pp.lengths = len_ws;
         pp.loc_conv_t = m->dev_blob + m->blob.loc_conv; pp.loc_dense_t = m->dev_blob + m->blob.loc_dense;
@@ -1364,7 +1371,7 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         rp.sync = sync;
         rp.att_frag_bytes = (unsigned)(frag_floats(4 * d.att_rnn_dim, P + E + d.att_rnn_dim) * sizeof(float));
         rp.dec_frag_bytes = (unsigned)(frag_floats(4 * D, d.att_rnn_dim + E + D) * sizeof(float));
-        rp.B = B; rp.T = T; rp.spin_limit = m->spin_limit; rp.layout = pa_layout;
+        rp.B = B; rp.T = T; rp.spin_limit = m->spin_limit; rp.layout = tile_layout;
         { static const int dbg = [] { const char* e = std::getenv("GVX_RS_DEBUG"); return e ? std::atoi(e) : 0; }(); rp.debug = dbg; }
         if (kt) HIP_TRY(hipEventRecord(m->kev[0], s));
         HIP_TRY(launch_decoder_resident(rp, s));

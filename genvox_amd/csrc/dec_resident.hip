@@ -387,6 +387,11 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         RS_WGSTAMP(0);
         // ---- the step's addend (attention LSTM: the Prenet columns, applied to all steps before the loop): its round trip hides
         // under the products
+        // (teacher-forced loop) the waves that will store h_a(t) into ring slot (t + 1) % RS make sure NOW that the slot's last reader,
+        // decoder LSTM (t - RS_HA_SLOTS), has finished: here the wait - a look at the decoder-LSTM flags every few steps - hides under
+        // the wait for h_a(t-1); in the epilogue it sat on the step's chain (0.9 us in the steps that needed a look).  The
+        // autoregressive loop needs no check: prenet(t) exists because that cell's step t - 1 has finished
+        if (ATT && !AR && t >= RS_HA_SLOTS && (wave == 6 || ((XH || RT == 2) && wave == 7))) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, lane);
         float4 add4 = bias4;
         if (PP && XH) {   // this step's Prenet-column fragments on their way into LDS (every reader of `red` / `red2` has passed the barrier that ended the last step)
             const unsigned kg = (unsigned)(4 * wave);
@@ -765,17 +770,13 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                 if (row < B && (ATT || 32 * wave + 4 * c4 < sdim)) store_sc1(rq, (unsigned)(row * sdim + 4 * c4) * 4u, v);
             }
         } else if (wave == 6) {
-            // the slot's last reader, decoder LSTM (t - RS_HA_SLOTS), has finished (autoregressive loop: implied - prenet(t) exists because that cell's step t - 1 has)
-            if (ATT && !AR && t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(hdst + (long)tile * B * 8);
             // (lane l: row l / 2, units 4 (l % 2) .. + 3 of the first tile; hs rows hold 8 RT units)
             if (4 * el < 8 * B) store_sc1(rh, (unsigned)el * 16u, *reinterpret_cast<const float4*>(hs + (el >> 1) * 8 * RT + 4 * (el & 1)));
         } else if (RT == 2 && wave == 7) {
-            if (t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(hdst + (long)(tile + 1) * B * 8);
             if (4 * el < 8 * B) store_sc1(rh, (unsigned)el * 16u, *reinterpret_cast<const float4*>(hs + (el >> 1) * 16 + 8 + 4 * (el & 1)));
         } else if (XH && wave == 7) {
-            if (!AR && t >= RS_HA_SLOTS) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, el);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(hdst + (long)xt * B * 8);
             if (el < B) store_sc1(rh, (unsigned)(el * 8 + 4 * xhalf) * 4u, *reinterpret_cast<const float4*>(hs2 + 4 * el));
         }

@@ -266,7 +266,7 @@ constexpr int RS_FLAG_PRE = RS_FLAG_Y1 + 32 * 32;                   // [RS_REP_P
 constexpr int RS_REP_P = 4;
 constexpr int RS_FLAG_P = RS_FLAG_PRE + RS_REP_PRE * 8 * 32;        // [RS_REP_P][128][32 words]: decoder-LSTM workgroup i has published h_d and its projection slab of steps < value
 static_assert(RS_FLAG_P + RS_REP_P * 128 * 32 <= HANDOFF_WORDS, "flag replicas inside the hand-off block");
-constexpr int RS_HA_SLOTS = 4;            // ring of h_a vectors: h_a(t) in slot (t + 1) % RS_HA_SLOTS, slot 0 = the zero state
+constexpr int RS_HA_SLOTS = 8;            // ring of h_a vectors: h_a(t) in slot (t + 1) % RS_HA_SLOTS, slot 0 = the zero state (the decoder-LSTM workgroups of the teacher-forced loop may run up to 7 steps behind)
 struct DecResidentParams {
     const float* att_frag; const float* att_bias; const float* wq_t;   // packed [128][224][64][4], [4A] packed row order, [A/8][a][8]
     const float* dec_frag; const float* dec_bias;                      // packed [128][320][64][4], [4D]

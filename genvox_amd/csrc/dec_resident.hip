@@ -1,5 +1,9 @@
-// Teacher-forced decoder loop as ONE resident, WEIGHT-STATIONARY kernel (models/tts/tacotron2.py:365-388 Decoder.forward,
-// :333-363 Decoder.decode): both LSTM cells of every step, beside the resident attention kernel (attn_persist.hip).
+// The decoder loops as ONE resident, WEIGHT-STATIONARY kernel each, beside the resident attention kernel (attn_persist.hip):
+//   decoder_resident_kernel     teacher-forced (models/tts/tacotron2.py:365-388 Decoder.forward, :333-363 Decoder.decode): both LSTM
+//                               cells of every step; 224-workgroup deal (below) or 192 (pairs of attention-LSTM tiles, rows of 129-256 tokens)
+//   decoder_ar_resident_kernel  autoregressive (:390-413 Decoder.inference): the same engine with the frame feedback - the attention
+//                               LSTM's Prenet columns, the projection as slabs of the decoder-LSTM tiles, Prenet layer 2; comment at the kernel
+// Both run batches of one or two rows on the vector ALUs instead of the matrix units (RS_MUL32; one body, two instantiations).
 //
 // Why: the two cells' recurrent matrices are 65.5 MB of fp32 and every decoder step multiplies all of them with the 32 batch
 // rows' vectors.  Streamed per step (skinny.hip, one launch per step) that is 18.3 us per step: a CU's load path moves ~25 KB/us
@@ -17,13 +21,15 @@
 //   blocks [64, 96):  attention-LSTM tiles 96 .. 127                   (192 KB: 96 VGPRs)
 //   blocks [96, 224): decoder-LSTM tiles                                (320 KB: 100 VGPRs + 120 KB of LDS)
 // The decoder cell is off the step's chain (only the projection after the loop reads h_d): its workgroups free-run behind the
-// attention-LSTM workgroups, gated by the same flags, at most RS_HA_SLOTS - 1 steps behind (the h_a ring; checked by its writers).
+// attention-LSTM workgroups, gated by the same flags, at most RS_HA_SLOTS - 1 steps behind (the h_a ring; its writers check at the
+// top of a step that the slot's last reader has finished).
 //
 // Hand-offs (cdna_hip_programming.md guideline 16, MI355X_MICROARCH.md "Valid forms", first table row): every handed-off byte is
 // stored `sc1` in 16-byte pieces, every storing wave drains (s_waitcnt vmcnt(0)), the waves meet at a barrier, ONE lane stores the
 // workgroup's flag (`sc1`, value = steps published); a reader polls every producer's flag (`sc1` loads, ONE wave per workgroup:
-// whichever wave blocks first takes an LDS lock and polls for all), keeps "steps everybody has published" per producer class in
-// LDS words behind the matched poll, and every load of the bytes is an `sc1` buffer load issued behind such a word.
+// whichever wave blocks first takes an LDS lock and polls - its own class and those other waves have left in the want mask, in one
+// round trip), keeps "steps everybody has published" per producer class in LDS words behind the matched poll, and every load of
+// the bytes is an `sc1` buffer load issued behind such a word.  Flags exist in replicas on lines of their own (gvx_kernels.h).
 // Every wait is bounded: polls without progress beyond the limit raise the call's status word and the workgroup's abort word, every
 // wait then returns at once, the grid drains and the caller's poison launch overwrites the outputs (gvx_api.hip).
 #include "gvx_kernels.h"

@@ -99,8 +99,6 @@ constexpr int RS_STAMP_T = 20;
 __device__ unsigned long long rs_stamps[4][10][16];
 __device__ unsigned long long rs_wg_stamps[224][4];
 __device__ unsigned long long rs_wg_stamps_ar[224][4];   // autoregressive loop: y1 seen, Prenet flag stored, Prenet seen, Prenet columns done
-__device__ unsigned long long rs_poll_log[3][64];   // [class][k]: return time of the k-th poll of block 64 during step RS_STAMP_T
-__device__ int rs_poll_n[3];
 #define RS_STAMP(ev) do { if (stamp_wg && t == RS_STAMP_T && lane == 0) rs_stamps[KIND][wave][ev] = wall_clock64(); } while (0)
 #define RS_WGSTAMP(i) do { if (t == RS_STAMP_T && tid == 0) rs_wg_stamps[bid][i] = wall_clock64(); } while (0)
 #define RS_ARSTAMP(i) do { if (t == RS_STAMP_T && tid == 0) rs_wg_stamps_ar[bid][i] = wall_clock64(); } while (0)
@@ -856,14 +854,6 @@ hipError_t read_wg_stamps_resident_ar(unsigned long long* host896) {
 }
 hipError_t read_wg_stamps_resident(unsigned long long* host896) {
     return hipMemcpyFromSymbol(host896, HIP_SYMBOL(rs_wg_stamps), sizeof(unsigned long long) * 896);
-}
-hipError_t read_poll_log_resident(unsigned long long* host192, int* n3) {
-    hipError_t e = hipMemcpyFromSymbol(host192, HIP_SYMBOL(rs_poll_log), sizeof(unsigned long long) * 192);
-    if (e != hipSuccess) return e;
-    e = hipMemcpyFromSymbol(n3, HIP_SYMBOL(rs_poll_n), sizeof(int) * 3);
-    if (e != hipSuccess) return e;
-    const int z[3] = {0, 0, 0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(rs_poll_n), z, sizeof z);
 }
 #endif
 

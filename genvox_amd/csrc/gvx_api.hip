@@ -35,7 +35,6 @@ hipError_t read_stamps_resident(unsigned long long* host480);
 hipError_t read_wg_stamps_resident(unsigned long long* host896);
 hipError_t read_wg_stamps_resident_ar(unsigned long long* host896);
 hipError_t read_row_stamps_persist_ar(unsigned long long* host256);
-hipError_t read_poll_log_resident(unsigned long long* host192, int* n3);
 hipError_t read_row_stamps_persist(unsigned long long* host512);
 #endif
 hipError_t skinny_init();
@@ -2185,11 +2184,6 @@ int gvx_debug_read_stamps_ar(unsigned long long* host896, unsigned long long* ro
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(gvx::read_wg_stamps_resident_ar(host896));
     HIP_TRY(gvx::read_row_stamps_persist_ar(rows256));
-    return GVX_OK;
-}
-int gvx_debug_read_poll_log_resident(unsigned long long* host192, int* n3) {
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(gvx::read_poll_log_resident(host192, n3));
     return GVX_OK;
 }
 int gvx_debug_read_stamps(unsigned long long* host96) {

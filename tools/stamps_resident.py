@@ -25,8 +25,6 @@ lib = C.CDLL(_lib.LIB_PATH)
 for _ in range(3):
     m.forward(batch)
     torch.cuda.synchronize()
-    _pl = (C.c_ulonglong * 192)(); _pn = (C.c_int * 3)()
-    lib.gvx_debug_read_poll_log_resident(_pl, _pn)   # (resets the log: the last forward's stays)
 buf = (C.c_ulonglong * 480)()
 assert lib.gvx_debug_read_stamps_resident(buf) == 0
 ev = ["step begins", "gate 1 (h)", "part 1 done", "gate 2 (ctx)", "part 2 done", "sums synced", "cells synced", "stores issued", "stores drained", "barrier 3"]
@@ -66,7 +64,3 @@ print(f"  {'':14s}  slabs seen  {span(r[:, 1])}")
 print(f"  {'':14s}  ctx stored  {span(r[:, 5])}")
 print(f"  {'':14s}  flag acked  {span(r[:, 7])}")
 
-print("polls of block 64 (attention LSTM, 32 rows) while it waited in step 20 / 21: return time relative to z, low byte of the lane-0 flag")
-for cls, name in enumerate(("h_a flags (gate 1 of step 21)", "ctx flags (gate 2 of step 20)", "h_d flags")):
-    n = min(_pn[cls], 64)
-    print(f"  {name}: {n} polls: " + " ".join(f"{((_pl[cls * 64 + k] >> 8) - z) * 10}:{_pl[cls * 64 + k] & 0xff}" for k in range(n)))

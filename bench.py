@@ -205,6 +205,13 @@ def main():
         model.load_state_dict(gw.generate_state_dict(mc, ac, tc, seed=0))
     model = model.to(dev)
     broadcast_packed_weights(model, src=0)  # one RCCL broadcast of the packed blob (no collective for a single process)
+    if args.rehearse_one_gpu and world > 1:
+        # several PROCESSES on one GPU: a resident loop needs every CU (two of them would wait for each other's workgroups until
+        # their time-outs; the turn-taking of resident loops is per process), so the rehearsal runs the launch-per-step kernels
+        from genvox_amd import _lib
+        model._ensure_packed()
+        _lib.check(_lib.load().gvx_model_set_resident_kernels(model._handle, 0))
+        log(f"rank {rank}: rehearsal on a shared GPU: resident kernels off (launch-per-step loops)")
 
     inp = gw.synthetic_inputs(B, L, T, tc.n_tokens, ac.n_mels, seed=3 + rank)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}

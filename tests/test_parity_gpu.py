@@ -478,6 +478,77 @@ def test_two_models_run_concurrently_from_two_threads():
         raise errors[0]
 
 
+def test_resident_loops_under_memory_traffic():
+    """The hand-offs of the resident kernels (write-through stores, drained, flags; `sc1` loads behind the matched poll) must hold when
+    the memory system is busy with something else: a second thread keeps the copy engines moving 256 MB buffers host <-> device
+    and device <-> device on streams of its own (no CUs: the loops hold them all) while the teacher-forced loop (32 x 128 x 60)
+    and the autoregressive loop (batch 1 and 5, rows that stop at different steps) run 30 times each: every output equal to
+    the quiet run's, bit for bit, no time-out."""
+    import threading
+
+    m, sd, (mc, ac, tc) = _default_model()
+    batch = _ragged_batch(mc, ac, tc, 32, 128, 60, seed=31)
+    assert m.loop_kind(32, 128) == 2
+    want_tf = {k: v.clone() for k, v in m.forward(batch).items()}
+    steps = 30
+    m.model_config.max_decoder_steps = steps
+    ar_inputs = []
+    for lens in ([77], [90, 41, 33, 20, 9]):
+        B, L = len(lens), max(lens)
+        tok = (gw.hashed_uniform(51, "traffic", B * L) * tc.n_tokens).astype(np.int64).reshape(B, L)
+        for b, n in enumerate(lens):
+            tok[b, n:] = 0
+        masks = torch.from_numpy(gw.prenet_keep_masks(steps * B, mc.prenet_dim, seed=9)).reshape(2, steps, B, mc.prenet_dim)
+        ar_inputs.append({"tokens": torch.from_numpy(tok), "token_lengths": torch.tensor(lens), "prenet_keep_masks": masks})
+        assert m.ar_loop_kind(B, L) == 2
+    m.model_config.gate_threshold = 1.0
+    probe = m.inference(ar_inputs[1])
+    g = torch.sigmoid(probe["gate_outputs"][:, :8]).cpu().flatten().sort().values
+    m.model_config.gate_threshold = float(g[g.numel() // 2] + g[g.numel() // 2 - 1]) / 2
+    want_ar = [{k: v.clone() for k, v in m.inference(x).items()} for x in ar_inputs]
+    m.check_status()
+    stop = threading.Event()
+    errors = []
+
+    def traffic():
+        try:
+            with torch.cuda.device(0):
+                n = 64 * 1024 * 1024
+                host = torch.empty(n, dtype=torch.float32).pin_memory()
+                dev_a = torch.empty(n, dtype=torch.float32, device="cuda:0")
+                dev_b = torch.empty(n, dtype=torch.float32, device="cuda:0")
+                s1, s2 = torch.cuda.Stream(device="cuda:0"), torch.cuda.Stream(device="cuda:0")
+                while not stop.is_set():
+                    with torch.cuda.stream(s1):
+                        dev_a.copy_(host, non_blocking=True)
+                        host.copy_(dev_a, non_blocking=True)
+                    with torch.cuda.stream(s2):
+                        dev_b.copy_(dev_a, non_blocking=True)
+                    s1.synchronize()
+                    s2.synchronize()
+        except BaseException as e:
+            errors.append(e)
+
+    th = threading.Thread(target=traffic)
+    th.start()
+    try:
+        for it in range(30):
+            out = m.forward(batch)
+            for k in KEYS:
+                assert torch.equal(out[k], want_tf[k]), f"teacher-forced call {it}: {k} differs by {max_abs_diff(out[k], want_tf[k])}"
+            for x, want in zip(ar_inputs, want_ar):
+                out = m.inference(x)
+                for k in KEYS:
+                    assert torch.equal(out[k], want[k]), f"autoregressive call {it}: {k} differs by {max_abs_diff(out[k], want[k])}"
+        m.check_status()
+        assert not m._resident_off   # no time-out fallback happened on the way
+    finally:
+        stop.set()
+        th.join()
+    if errors:
+        raise errors[0]
+
+
 def test_encoder_handoff_timeout_is_loud(monkeypatch):
     """The resident encoder recurrence hands its hidden state round through flags in the workspace; a workgroup that never
     publishes (forced: GVX_DEBUG_ENC_SKIP_BLOCK makes one of the 64 leave at once, the waits give up after a few polls) must not

@@ -196,9 +196,9 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     __syncthreads();
 
     // location features of the next step from the previous / cumulative weights in wc, on the MFMA units:
-    //   conv   C[f][l] = sum_kk Wc[f][kk] X[kk][l],  kk = 32 ch + k, X[kk][l] = wc[ch][l + k]   (4 position tiles, K = 64)
-    //   dense  D[d][l] = sum_f  Wd[d][f]  C[f][l]                                               (4 x 4 tiles, K = 32)
-    // v_mfma_f32_32x32x2_f32: A lane (i = lane & 31, kh = lane >> 5) gives A[i][kh], B lane (j, kh) gives B[kh][j], and lane
+    //   conv   C[f][l] = sum_kk Wc[f][kk] X[kk][l],  kk = 32 ch + k, X[kk][l] = wc[ch][l + k]   (2 x 8 tiles of 16 x 16, K = 64)
+    //   dense  D[d][l] = sum_f  Wd[d][f]  C[f][l]                                               (4 x 4 tiles of 32 x 32, K = 32)
+    // v_mfma_f32_32x32x2_f32 (dense): A lane (i = lane & 31, kh = lane >> 5) gives A[i][kh], B lane (j, kh) gives B[kh][j], and lane
     // (j, h) receives D[8 g + 4 h + r][j] in accumulator 4 g + r.  (As VALU loops this phase took 9.5 us per step.)
     auto location_features = [&]() {
         // (per-thread indices are recomputed from an opaque copy of the thread id in every phase of the step loop: hoisted out
@@ -206,21 +206,22 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         int tq = tid;
         asm volatile("" : "+v"(tq));
         const int lj = tq & 31, kh = (tq >> 5) & 1;
-        if (wave < 4) {   // conv: one position tile per wave
-            const int l0 = 32 * wave;
-            f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll 8
-            for (int s = 0; s < 32; ++s) {
-                const int kk = 2 * s + kh, ch = kk >> 5, k = kk & 31;
-                const float av = cw[(ch * 32 + k) * 32 + lj];
-                const float bv = wc[ch * PA_WC_S + l0 + lj + k];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        {   // conv on all 16 waves: wave -> (filter tile of 16 = wave & 1, position tile of 16 = wave >> 1), v_mfma_f32_16x16x4_f32:
+            // A lane (i = lane & 15, kq = lane >> 4) gives A[i][kq], B lane (j, kq) gives B[kq][j], lane (j, g) receives D[4 g + r][j] in
+            // register r.  (As four waves with 32 x 32 tiles the loop was a chain of LDS round trips - the kernel has no registers
+            // to fetch ahead - and took 2.4 us; four waves per SIMD hide each other's.)
+            using f32x4 = __attribute__((ext_vector_type(4))) float;
+            const int li = tq & 15, kq = (tq >> 4) & 3;
+            const int f0 = 16 * (wave & 1), l0 = 16 * (wave >> 1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const int kk = 4 * s + kq, ch = kk >> 5, k = kk & 31;
+                const float av = cw[(ch * 32 + k) * 32 + f0 + li];
+                const float bv = wc[ch * PA_WC_S + l0 + li + k];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(fb + (l0 + lj) * PA_FB_S + 8 * g + 4 * kh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            *reinterpret_cast<float4*>(fb + (l0 + li) * PA_FB_S + f0 + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
         __syncthreads();
         {   // dense: wave -> (d tile = wave & 3, position tile = wave >> 2)

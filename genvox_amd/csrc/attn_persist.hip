@@ -130,7 +130,10 @@ __device__ __forceinline__ bool flags_wait(const unsigned* flags, int n, unsigne
 // exp(e - M) / S.  Half 0 publishes the context.  The softmax equals the reference's (models/tts/tacotron2.py:126) up to
 // rounding (1e-7 relative).
 #ifdef GVX_STAMPS
-namespace { __device__ unsigned long long pa_row_stamps[64][8]; __device__ unsigned long long pa_row_stamps_ar[64][4]; }   // per resident workgroup: the phase stamps of step 20
+namespace { __device__ unsigned long long pa_row_stamps[64][8]; __device__ unsigned long long pa_row_stamps_ar[64][4]; __device__ unsigned long long pa_loc_stamps[4][8]; }
+#define PA_LSTAMP(i) do { if (loc_stamp_on && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) % 5 == 0) pa_loc_stamps[(threadIdx.x >> 6) / 5][i] = wall_clock64(); } while (0)
+#else
+#define PA_LSTAMP(i) do { } while (0)   // per resident workgroup: the phase stamps of step 20
 #endif
 // AR (beside decoder_ar_resident_kernel, dec_resident.hip): after its context the row also finishes the step - it sums the 128
 // projection slabs of the decoder-LSTM tiles into the frame + gate of the step (Decoder.decode's linear projection and gate
@@ -200,6 +203,9 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     //   dense  D[d][l] = sum_f  Wd[d][f]  C[f][l]                                               (4 x 4 tiles of 32 x 32, K = 32)
     // v_mfma_f32_32x32x2_f32 (dense): A lane (i = lane & 31, kh = lane >> 5) gives A[i][kh], B lane (j, kh) gives B[kh][j], and lane
     // (j, h) receives D[8 g + 4 h + r][j] in accumulator 4 g + r.  (As VALU loops this phase took 9.5 us per step.)
+#ifdef GVX_STAMPS
+    bool loc_stamp_on = false;   // (stamps build: waves 0 / 5 / 10 / 15 of row 0 stamp the phases of the location features of step 20)
+#endif
     auto location_features = [&]() {
         // (per-thread indices are recomputed from an opaque copy of the thread id in every phase of the step loop: hoisted out
         // of the loop they would sit in registers the resident operands need)
@@ -214,27 +220,40 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             const int li = tq & 15, kq = (tq >> 4) & 3;
             const int f0 = 16 * (wave & 1), l0 = 16 * (wave >> 1);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-                const int kk = 4 * s + kq, ch = kk >> 5, k = kk & 31;
-                const float av = cw[(ch * 32 + k) * 32 + f0 + li];
-                const float bv = wc[ch * PA_WC_S + l0 + li + k];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            // (operands of four products fetched together: left to itself the compiler waits for each LDS read right before its product)
+#pragma unroll
+            for (int s0 = 0; s0 < 16; s0 += 4) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = 4 * (s0 + u) + kq, ch = kk >> 5, k = kk & 31;
+                    av[u] = cw[(ch * 32 + k) * 32 + f0 + li];
+                    bv[u] = wc[ch * PA_WC_S + l0 + li + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
             }
             *reinterpret_cast<float4*>(fb + (l0 + li) * PA_FB_S + f0 + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
+        PA_LSTAMP(0);
         __syncthreads();
+        PA_LSTAMP(1);
         {   // dense: wave -> (d tile = wave & 3, position tile = wave >> 2)
             const int d0 = 32 * (wave & 3), l = 32 * (wave >> 2) + lj;
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll 8
-            for (int s = 0; s < 16; ++s) {
-                const int f = 2 * s + kh;
-                const float av = wdl[((f >> 2) * PA_A + d0 + lj) * 4 + (f & 3)];
-                const float bv = fb[l * PA_FB_S + f];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+            for (int s0 = 0; s0 < 16; s0 += 4) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = 2 * (s0 + u) + kh;
+                    av[u] = wdl[((f >> 2) * PA_A + d0 + lj) * 4 + (f & 3)];
+                    bv[u] = fb[l * PA_FB_S + f];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -243,7 +262,9 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
                     make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
             }
         }
+        PA_LSTAMP(2);
         __syncthreads();
+        PA_LSTAMP(3);
     };
     location_features();   // step 0: zero weights
 
@@ -438,6 +459,9 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
 #endif
         // ---- off the chain: location features of step t + 1 (autoregressive role: after the row's second part of the step, which IS on
         // the chain - the features have until the next query arrives, two hand-offs and a cell later)
+#ifdef GVX_STAMPS
+        loc_stamp_on = t == 20 && blockIdx.x == 0;
+#endif
         if (!AR && t + 1 < p.T) location_features();
         PA_STAMP(6);
         if (AR && hf == 0) {   // (a row of two halves: half 0, which has published the context, finishes the step)
@@ -605,6 +629,9 @@ hipError_t launch_handoff_set(unsigned* word, hipStream_t s) {
 }
 
 #ifdef GVX_STAMPS
+hipError_t read_loc_stamps_persist(unsigned long long* host32) {
+    return hipMemcpyFromSymbol(host32, HIP_SYMBOL(pa_loc_stamps), sizeof(unsigned long long) * 32);
+}
 hipError_t read_row_stamps_persist_ar(unsigned long long* host256) {
     return hipMemcpyFromSymbol(host256, HIP_SYMBOL(pa_row_stamps_ar), sizeof(unsigned long long) * 256);
 }

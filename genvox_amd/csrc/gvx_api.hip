@@ -35,6 +35,7 @@ hipError_t read_stamps_resident(unsigned long long* host480);
 hipError_t read_wg_stamps_resident(unsigned long long* host896);
 hipError_t read_wg_stamps_resident_ar(unsigned long long* host896);
 hipError_t read_row_stamps_persist_ar(unsigned long long* host256);
+hipError_t read_loc_stamps_persist(unsigned long long* host32);
 hipError_t read_row_stamps_persist(unsigned long long* host512);
 #endif
 hipError_t skinny_init();
@@ -2178,6 +2179,11 @@ int gvx_debug_read_wg_stamps_resident(unsigned long long* host896, unsigned long
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(gvx::read_wg_stamps_resident(host896));
     HIP_TRY(gvx::read_row_stamps_persist(rows512));
+    return GVX_OK;
+}
+int gvx_debug_read_loc_stamps(unsigned long long* host32) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(gvx::read_loc_stamps_persist(host32));
     return GVX_OK;
 }
 int gvx_debug_read_stamps_ar(unsigned long long* host896, unsigned long long* rows256) {

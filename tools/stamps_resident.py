@@ -64,3 +64,10 @@ print(f"  {'':14s}  slabs seen  {span(r[:, 1])}")
 print(f"  {'':14s}  ctx stored  {span(r[:, 5])}")
 print(f"  {'':14s}  flag acked  {span(r[:, 7])}")
 
+
+ls = (C.c_ulonglong * 32)()
+if lib.gvx_debug_read_loc_stamps(ls) == 0:
+    print("location features of step 20, row 0, waves 0 / 5 / 10 / 15: conv done | conv barrier passed | dense done | last barrier passed (ns after wave 0's conv)")
+    base = ls[0]
+    for w in range(4):
+        print(f"   wave {5 * w:2d}: " + "  ".join(f"{(ls[w * 8 + e] - base) * 10:6d}" for e in range(4)))

@@ -36,7 +36,7 @@ constexpr int PA_THREADS = 1024;
 constexpr int PA_A = 128;      // attention dim
 constexpr int PA_E = 512;      // encoder embedding dim
 constexpr int PA_L = 128;      // positions held per row
-constexpr int PA_FB_S = 36;    // LDS row stride of the conv output [l][32 filters] (+4: conflict-free float4 rows)
+constexpr int PA_FB_S = 33;    // LDS row stride of the conv output [l][32 filters] (odd: the dense product's lanes read one filter of 32 positions, no bank conflicts)
 constexpr int PA_KL_MAX = 31;
 constexpr int PA_SLABS = 96;   // workgroups of the attention LSTM in the teacher-forced launch's layout (skinny.hip): one query slab each
 constexpr int PA_SLABS_AR = 128;   // autoregressive launches: one slab per attention-LSTM tile
@@ -47,7 +47,7 @@ constexpr int PA_XCH = PA_E + 64;    // floats of one exchange buffer of the spl
 constexpr int PA_OFF_LOC = 0;                                  // [128][128] location features, float4 groups swizzled by (l & 1)
 constexpr int PA_OFF_FB = PA_OFF_LOC + PA_L * PA_A;            // [128][36]
 constexpr int PA_OFF_CW = PA_OFF_FB + PA_L * PA_FB_S;          // [2][32][32] conv weights, taps zero-padded to 32
-constexpr int PA_OFF_WD = PA_OFF_CW + 2 * 32 * 32;             // [8][128][4] dense weights
+constexpr int PA_OFF_WD = PA_OFF_CW + 2 * 32 * 32;             // [32 filters][128] dense weights (filter-major: lanes read 32 consecutive dims)
 constexpr int PA_OFF_WC = PA_OFF_WD + 32 * PA_A;               // [2][PA_WC_S]
 constexpr int PA_OFF_QP = PA_OFF_WC + 2 * PA_WC_S;             // [32][128] query partial sums
 constexpr int PA_OFF_QS = PA_OFF_QP + 32 * PA_A;               // [128] query
@@ -189,7 +189,10 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         const int ch = i >> 10, k = (i >> 5) & 31, f = i & 31;
         cw[i] = k < kl ? p.loc_conv_t[(ch * kl + k) * 32 + f] : 0.f;
     }
-    for (int i = tid; i < 32 * PA_A / 4; i += PA_THREADS) reinterpret_cast<float4*>(wdl)[i] = reinterpret_cast<const float4*>(p.loc_dense_t)[i];
+    for (int i = tid; i < 32 * PA_A; i += PA_THREADS) {   // global [32/4][a][4] -> [32][a]
+        const int f = i / PA_A, dd = i - f * PA_A;
+        wdl[i] = p.loc_dense_t[((f >> 2) * PA_A + dd) * 4 + (f & 3)];
+    }
     if (tid < PA_A) vl[tid] = p.v[tid];
     if (AR) {   // projection bias and the row's stop state: read on the chain every step
         if (tid < 128) smem[PA_OFF_H1 + tid] = tid <= p.n_mels ? p.proj_b[tid] : 0.f;
@@ -233,7 +236,8 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
             }
-            *reinterpret_cast<float4*>(fb + (l0 + li) * PA_FB_S + f0 + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fb[(l0 + li) * PA_FB_S + f0 + 4 * kq + r] = acc[r];
         }
         PA_LSTAMP(0);
         __syncthreads();
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int f = 2 * (s0 + u) + kh;
-                    av[u] = wdl[((f >> 2) * PA_A + d0 + lj) * 4 + (f & 3)];
+                    av[u] = wdl[f * PA_A + d0 + lj];
                     bv[u] = fb[l * PA_FB_S + f];
                 }
 #pragma unroll

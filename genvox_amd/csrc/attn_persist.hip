@@ -44,7 +44,7 @@ constexpr int PA_WC_S = PA_L + 32;   // stride of the two halo-padded weight row
 constexpr int PA_XCH = PA_E + 64;    // floats of one exchange buffer of the split kernel: c[512], (m, s, -, -), edge energies[16]
 
 // LDS layout (floats)
-constexpr int PA_OFF_LOC = 0;                                  // [128][128] location features, float4 groups swizzled by (l & 1)
+constexpr int PA_OFF_LOC = 0;                                  // [128][128] location features, float4 groups swizzled (pa_loc_swz)
 constexpr int PA_OFF_FB = PA_OFF_LOC + PA_L * PA_A;            // [128][36]
 constexpr int PA_OFF_CW = PA_OFF_FB + PA_L * PA_FB_S;          // [2][32][32] conv weights, taps zero-padded to 32
 constexpr int PA_OFF_WD = PA_OFF_CW + 2 * 32 * 32;             // [32 filters][128] dense weights (filter-major: lanes read 32 consecutive dims)
@@ -56,13 +56,18 @@ constexpr int PA_OFF_V = PA_OFF_ES + PA_L;                     // [128] v
 constexpr int PA_OFF_CP = PA_OFF_V + PA_A;                     // [8][512] context partial sums
 constexpr int PA_OFF_FLAG = PA_OFF_CP + 8 * PA_E;              // [4] "leave the loop" word of the step's wait
 constexpr int PA_OFF_H1 = PA_OFF_FLAG + 4;                     // autoregressive role: [128] projection bias, [1] "this row's stop token has fired"
-constexpr int PA_LDS_FLOATS = PA_OFF_H1 + 256;
+constexpr int PA_OFF_MEML = PA_OFF_H1 + 256;                   // autoregressive role: [1024] float4, the 16th memory vector of every thread (below)
+constexpr int PA_LDS_FLOATS = PA_OFF_MEML + 4 * PA_THREADS;
 constexpr int PA_P = 256;      // Prenet width (autoregressive role)
 constexpr int PA_KPT = 5;      // layer-1 k values per thread: n_mels <= 16 PA_KPT
 static_assert(PA_LDS_FLOATS * 4 <= 160 * 1024, "persistent attention LDS");
 static_assert((PA_OFF_FB % 4) == 0 && (PA_OFF_CW % 4) == 0 && (PA_OFF_WD % 4) == 0 && (PA_OFF_QP % 4) == 0 && (PA_OFF_QS % 4) == 0 &&
-              (PA_OFF_V % 4) == 0 && (PA_OFF_CP % 4) == 0 && (PA_OFF_H1 % 4) == 0, "float4 alignment");
+              (PA_OFF_V % 4) == 0 && (PA_OFF_CP % 4) == 0 && (PA_OFF_H1 % 4) == 0 && (PA_OFF_MEML % 4) == 0, "float4 alignment");
 
+// float4 group g of position l of the location features sits at group g ^ pa_loc_swz(l) of its 128-float row: bit 3 by the position's
+// parity (the energies phase: 8 lanes read a row's groups dg + 8 j, neighbouring positions in the other half of the banks), bit 2
+// by bit 2 of the position (the dense product's writes: a half wave writes 16 dims of two positions 4 apart)
+__device__ __forceinline__ int pa_loc_swz(int l) { return ((l & 1) << 3) | (((l >> 2) & 1) << 2); }
 __device__ __forceinline__ float fast_tanh(float x) {   // as attention.hip
     const float e = __expf(2.f * x);
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
@@ -170,12 +175,19 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
     // ---- resident operands
     // memory: thread (e4 = float4 column, lg = group of 16 positions) holds memory[b][16 lg + i][e4], i < 16.  The 8 position
     // groups of a column sit in 8 neighbouring lanes: the context's sum over them is three DPP adds, no LDS, no barrier
-    float4 mem[16];
+    // (autoregressive variants: the kernel sits at its 128-register limit and the allocator kept spilling one of these vectors - a
+    // scratch round trip per step on the chain; the 16th one lives in LDS there, 16 KB the shrunken tables left free, read once per step)
+    constexpr int NMR = AR ? 15 : 16;
+    float4 mem[NMR];
     {
         const int e4 = tid >> 3, lg = tid & 7;
         const float4* mb = reinterpret_cast<const float4*>(p.memory) + ((long)b * p.L + l_base) * (PA_E / 4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mem[i] = mb[(long)min(16 * lg + i, L - 1) * (PA_E / 4) + e4];
+        for (int i = 0; i < 16; ++i) {
+            const float4 v = mb[(long)min(16 * lg + i, L - 1) * (PA_E / 4) + e4];
+            if (i < NMR) mem[i < NMR ? i : 0] = v;
+            else reinterpret_cast<float4*>(smem + PA_OFF_MEML)[tid] = v;
+        }
     }
     // processed memory: thread (l = position, dg) holds the float4 groups dg + 8 j of pm[b][l]
     float4 pmr[4];
@@ -214,7 +226,6 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         // of the loop they would sit in registers the resident operands need)
         int tq = tid;
         asm volatile("" : "+v"(tq));
-        const int lj = tq & 31, kh = (tq >> 5) & 1;
         {   // conv on all 16 waves: wave -> (filter tile of 16 = wave & 1, position tile of 16 = wave >> 1), v_mfma_f32_16x16x4_f32:
             // A lane (i = lane & 15, kq = lane >> 4) gives A[i][kq], B lane (j, kq) gives B[kq][j], lane (j, g) receives D[4 g + r][j] in
             // register r.  (As four waves with 32 x 32 tiles the loop was a chain of LDS round trips - the kernel has no registers
@@ -223,18 +234,21 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             const int li = tq & 15, kq = (tq >> 4) & 3;
             const int f0 = 16 * (wave & 1), l0 = 16 * (wave >> 1);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            // (operands of four products fetched together: left to itself the compiler waits for each LDS read right before its product)
+            // (operands of four products fetched together: left to itself the compiler waits for each LDS read right before its product;
+            // two in the autoregressive variants, which have no registers for four - a resident memory vector was spilled, a scratch
+            // round trip on the chain - and 10 us of slack for this phase)
+            constexpr int CB = AR ? 2 : 4;
 #pragma unroll
-            for (int s0 = 0; s0 < 16; s0 += 4) {
-                float av[4], bv[4];
+            for (int s0 = 0; s0 < 16; s0 += CB) {
+                float av[CB], bv[CB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < CB; ++u) {
                     const int kk = 4 * (s0 + u) + kq, ch = kk >> 5, k = kk & 31;
                     av[u] = cw[(ch * 32 + k) * 32 + f0 + li];
                     bv[u] = wc[ch * PA_WC_S + l0 + li + k];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+                for (int u = 0; u < CB; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) fb[(l0 + li) * PA_FB_S + f0 + 4 * kq + r] = acc[r];
@@ -242,28 +256,50 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         PA_LSTAMP(0);
         __syncthreads();
         PA_LSTAMP(1);
-        {   // dense: wave -> (d tile = wave & 3, position tile = wave >> 2)
-            const int d0 = 32 * (wave & 3), l = 32 * (wave >> 2) + lj;
-            f32x16 acc;
+        {   // dense: wave -> (32 positions l0 .., 32 dims d0 ..) as FOUR 16 x 16 tiles (v_mfma_f32_16x16x4_f32, 8 k-steps; a k-step's
+            // 4 products share 2 + 2 operands).  POSITIONS are the tile's rows and dims its columns: lane (j, g) receives
+            // D[position 4 g + r][dim j] in register r, so that 16 lanes write 16 consecutive dims of a position - with dims as rows
+            // (and one 32 x 32 tile per wave) the float4 writes of 16 / 32 lanes went to the SAME banks of rows 128 floats apart:
+            // 1.3 us of the phase's 3.6 were bank conflicts of these writes (stamps without them: profiles/r04_stamps_resident_final.txt)
+            using f32x4 = __attribute__((ext_vector_type(4))) float;
+            const int li = tq & 15, kq = (tq >> 4) & 3;
+            const int d0 = 32 * (wave & 3), l0 = 32 * (wave >> 2);
+            auto put = [&](const f32x4& v, int lt, int dt) {
+                const int dim = d0 + 16 * dt + li;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-            for (int s0 = 0; s0 < 16; s0 += 4) {
-                float av[4], bv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int f = 2 * (s0 + u) + kh;
-                    av[u] = wdl[f * PA_A + d0 + lj];
-                    bv[u] = fb[l * PA_FB_S + f];
+                for (int r = 0; r < 4; ++r) {
+                    const int l = l0 + 16 * lt + 4 * kq + r;
+                    locf[l * PA_A + 4 * ((dim >> 2) ^ pa_loc_swz(l)) + (dim & 3)] = v[r];
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int g4 = (d0 + 8 * g + 4 * kh) >> 2;
-                reinterpret_cast<float4*>(locf)[l * (PA_A / 4) + (g4 ^ ((l & 1) << 3))] =
-                    make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            };
+            if (!AR) {
+                f32x4 a00 = {0.f, 0.f, 0.f, 0.f}, a01 = a00, a10 = a00, a11 = a00;   // [position tile][dim tile]
+#pragma unroll 2
+                for (int s = 0; s < 8; ++s) {
+                    const int f = 4 * s + kq;
+                    const float av0 = fb[(l0 + li) * PA_FB_S + f], av1 = fb[(l0 + 16 + li) * PA_FB_S + f];
+                    const float bv0 = wdl[f * PA_A + d0 + li], bv1 = wdl[f * PA_A + d0 + 16 + li];
+                    a00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0, a00, 0, 0, 0);
+                    a01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv1, a01, 0, 0, 0);
+                    a10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv0, a10, 0, 0, 0);
+                    a11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1, a11, 0, 0, 0);
+                }
+                put(a00, 0, 0); put(a01, 0, 1); put(a10, 1, 0); put(a11, 1, 1);
+            } else {
+                // (autoregressive variants, as in the convolution above: two passes of two tiles each)
+#pragma unroll 1
+                for (int dt = 0; dt < 2; ++dt) {
+                    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;   // [position tile]
+#pragma unroll 1
+                    for (int s = 0; s < 8; ++s) {
+                        const int f = 4 * s + kq;
+                        const float av0 = fb[(l0 + li) * PA_FB_S + f], av1 = fb[(l0 + 16 + li) * PA_FB_S + f];
+                        const float bv = wdl[f * PA_A + d0 + 16 * dt + li];
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv, a1, 0, 0, 0);
+                    }
+                    put(a0, 0, dt); put(a1, 1, dt);
+                }
             }
         }
         PA_LSTAMP(2);
@@ -338,7 +374,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
                 const int g4 = dg + 8 * j;
                 const float4 qv = reinterpret_cast<const float4*>(qs)[g4];
                 const float4 vv = reinterpret_cast<const float4*>(vl)[g4];
-                const float4 lv = reinterpret_cast<const float4*>(locf)[el * (PA_A / 4) + (g4 ^ ((el & 1) << 3))];
+                const float4 lv = reinterpret_cast<const float4*>(locf)[el * (PA_A / 4) + (g4 ^ pa_loc_swz(el))];
                 pe = fmaf(vv.x, fast_tanh(qv.x + (lv.x + pmr[j].x)), pe);
                 pe = fmaf(vv.y, fast_tanh(qv.y + (lv.y + pmr[j].y)), pe);
                 pe = fmaf(vv.z, fast_tanh(qv.z + (lv.z + pmr[j].z)), pe);
@@ -366,8 +402,9 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             for (int i = 0; i < 16; ++i) {
                 const int l = 16 * lg + i;
                 const float w = l < L ? __expf(es[l] - mref) * inv : 0.f;   // exactly 0 past the row's length (exp(-inf))
-                acc.x = fmaf(w, mem[i].x, acc.x); acc.y = fmaf(w, mem[i].y, acc.y);
-                acc.z = fmaf(w, mem[i].z, acc.z); acc.w = fmaf(w, mem[i].w, acc.w);
+                const float4 mv = i < NMR ? mem[i < NMR ? i : 0] : reinterpret_cast<const float4*>(smem + PA_OFF_MEML)[tq];
+                acc.x = fmaf(w, mv.x, acc.x); acc.y = fmaf(w, mv.y, acc.y);
+                acc.z = fmaf(w, mv.z, acc.z); acc.w = fmaf(w, mv.w, acc.w);
                 // (the split variant has no registers to spare: without this the scheduler computes all 16 weights first and
                 // spills three of the resident memory vectors to make room - three scratch round trips per step on the chain)
             }

@@ -391,8 +391,16 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         mx = wave_max_dpp(mx);
         // SPLIT: a half whose positions are all masked has mx = -inf; its local terms use reference 0 and come out as zeros
         const float mref = (SPLIT && mx == -INFINITY) ? 0.f : mx;
+        // exp(e - m) of every position, once per wave: summed for the normaliser and left in a row of the wave's own in the query
+        // partial-sum region (free since the query was summed), where the context loop below reads its 16 - as broadcasts, in place of
+        // 16 more v_exp_f32 per thread (a quarter-rate instruction: 0.35 us of the phase)
+        float* wex = qp + wave * PA_L;
         float sum = 0.f;
-        for (int l = lane; l < L; l += 64) sum += __expf(es[l] - mref);
+        for (int l = lane; l < PA_L; l += 64) {
+            const float ex = l < L ? __expf(es[l] - mref) : 0.f;
+            wex[l] = ex;
+            sum += ex;
+        }
         sum = wave_sum_dpp(sum);
         float inv = SPLIT ? 1.f : 1.f / sum;   // SPLIT: the context partials stay unnormalised until the halves have met
         float4 o_ctx;
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int l = 16 * lg + i;
-                const float w = l < L ? __expf(es[l] - mref) * inv : 0.f;   // exactly 0 past the row's length (exp(-inf))
+                const float w = wex[l] * inv;   // exactly 0 past the row's length (exp(-inf)) and past the positions held
                 const float4 mv = i < NMR ? mem[i < NMR ? i : 0] : reinterpret_cast<const float4*>(smem + PA_OFF_MEML)[tq];
                 acc.x = fmaf(w, mv.x, acc.x); acc.y = fmaf(w, mv.y, acc.y);
                 acc.z = fmaf(w, mv.z, acc.z); acc.w = fmaf(w, mv.w, acc.w);

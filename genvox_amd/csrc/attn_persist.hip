@@ -368,18 +368,31 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
         PA_STAMP(2);
         // ---- energies: e[l] = v . tanh(q + (loc[l] + pm[l]))   (8 lanes per position, DPP sum)
         {
-            float pe = 0.f;
+            // Two elements per instruction wherever the ISA has a packed fp32 form (v_pk_add / mul / fma_f32): the phase was bound by
+            // instruction issue - 8 full-rate and 2 quarter-rate (v_exp, v_rcp) instructions per element, 16 elements per thread,
+            // 4 waves per SIMD: 1.64 us.  tanh(z) = 1 - 2 / (exp2(z 2 log2 e) + 1) as in fast_tanh, the same values bit for bit
+            // (2 z and 2 r are exact); the two halves of a pair accumulate separately (the sum's order differs from the per-step kernel's).
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f k2l = {2.885390043f, 2.885390043f};   // 2 log2(e)
+            v2f pe2 = {0.f, 0.f};
+            auto pair = [&](float qa, float qb, float la, float lb, float pa, float pb, float va, float vb) {
+                v2f z = (v2f){qa, qb} + ((v2f){la, lb} + (v2f){pa, pb});
+                z = z * k2l;
+                v2f d = (v2f){__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + (v2f){1.f, 1.f};
+                const v2f r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                const v2f th = __builtin_elementwise_fma((v2f){-2.f, -2.f}, r, (v2f){1.f, 1.f});
+                pe2 = __builtin_elementwise_fma((v2f){va, vb}, th, pe2);
+            };
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int g4 = dg + 8 * j;
                 const float4 qv = reinterpret_cast<const float4*>(qs)[g4];
                 const float4 vv = reinterpret_cast<const float4*>(vl)[g4];
                 const float4 lv = reinterpret_cast<const float4*>(locf)[el * (PA_A / 4) + (g4 ^ pa_loc_swz(el))];
-                pe = fmaf(vv.x, fast_tanh(qv.x + (lv.x + pmr[j].x)), pe);
-                pe = fmaf(vv.y, fast_tanh(qv.y + (lv.y + pmr[j].y)), pe);
-                pe = fmaf(vv.z, fast_tanh(qv.z + (lv.z + pmr[j].z)), pe);
-                pe = fmaf(vv.w, fast_tanh(qv.w + (lv.w + pmr[j].w)), pe);
+                pair(qv.x, qv.y, lv.x, lv.y, pmr[j].x, pmr[j].y, vv.x, vv.y);
+                pair(qv.z, qv.w, lv.z, lv.w, pmr[j].z, pmr[j].w, vv.z, vv.w);
             }
+            float pe = pe2.x + pe2.y;
             pe = sum8(pe);
             if (dg == 0) es[el] = el < len ? pe : -INFINITY;
         }

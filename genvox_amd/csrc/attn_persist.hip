@@ -60,6 +60,8 @@ constexpr int PA_OFF_MEML = PA_OFF_H1 + 256;                   // autoregressive
 constexpr int PA_LDS_FLOATS = PA_OFF_MEML + 4 * PA_THREADS;
 constexpr int PA_P = 256;      // Prenet width (autoregressive role)
 constexpr int PA_KPT = 5;      // layer-1 k values per thread: n_mels <= 16 PA_KPT
+constexpr int PA_SP_S = 25;    // float4 row stride of the slab partial sums [32][PSB / 4 <= 24]: odd - their column reads are conflict free (with 32,
+                               // a half wave's 32 rows of a column sat in the same banks: 2 us of the row's second part)
 static_assert(PA_LDS_FLOATS * 4 <= 160 * 1024, "persistent attention LDS");
 static_assert((PA_OFF_FB % 4) == 0 && (PA_OFF_CW % 4) == 0 && (PA_OFF_WD % 4) == 0 && (PA_OFF_QP % 4) == 0 && (PA_OFF_QS % 4) == 0 &&
               (PA_OFF_V % 4) == 0 && (PA_OFF_CP % 4) == 0 && (PA_OFF_H1 % 4) == 0 && (PA_OFF_MEML % 4) == 0, "float4 alignment");
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             asm volatile("" : "+s"(kp));
             const bool more = t + 1 < p.T;   // (the last step: nobody consumes a next Prenet input)
             const int M = kp->n_mels, PSB = kp->PSB;
-            float4* sp4 = reinterpret_cast<float4*>(qp);                  // [32][32]
+            float4* sp4 = reinterpret_cast<float4*>(qp);                  // [32][PA_SP_S]
             float4* l1p = reinterpret_cast<float4*>(smem + PA_OFF_CP);    // [16][64]
             float* mel = qs;                                              // [128]
             const float* pbl = smem + PA_OFF_H1;                          // [128] projection bias
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
                     acc.x += sv[1].x; acc.y += sv[1].y; acc.z += sv[1].z; acc.w += sv[1].w;
                     acc.x += sv[2].x; acc.y += sv[2].y; acc.z += sv[2].z; acc.w += sv[2].w;
                     acc.x += sv[3].x; acc.y += sv[3].y; acc.z += sv[3].z; acc.w += sv[3].w;
-                    sp4[(2 * wave + g) * 32 + n4] = acc;
+                    sp4[(2 * wave + g) * PA_SP_S + n4] = acc;
                 }
             }
             __syncthreads();
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
             {   // column c4 (4 projection outputs) summed over the 32 slab groups by the 32 lanes of a half wave: no serial chain of LDS reads
                 const int c4 = ta >> 5, sgl = ta & 31;
                 if (c4 < n4c) {   // (uniform per half wave)
-                    float4 v4 = sp4[sgl * 32 + c4];
+                    float4 v4 = sp4[sgl * PA_SP_S + c4];   // (odd row stride: the half wave's 32 rows of one column in different banks)
 #pragma unroll
                     for (int o = 16; o >= 1; o >>= 1) {
                         v4.x += __shfl_xor(v4.x, o, 64); v4.y += __shfl_xor(v4.y, o, 64);

@@ -217,9 +217,9 @@ __global__ __launch_bounds__(PA_THREADS) void attn_persistent_kernel(AttnPersist
 
     // location features of the next step from the previous / cumulative weights in wc, on the MFMA units:
     //   conv   C[f][l] = sum_kk Wc[f][kk] X[kk][l],  kk = 32 ch + k, X[kk][l] = wc[ch][l + k]   (2 x 8 tiles of 16 x 16, K = 64)
-    //   dense  D[d][l] = sum_f  Wd[d][f]  C[f][l]                                               (4 x 4 tiles of 32 x 32, K = 32)
-    // v_mfma_f32_32x32x2_f32 (dense): A lane (i = lane & 31, kh = lane >> 5) gives A[i][kh], B lane (j, kh) gives B[kh][j], and lane
-    // (j, h) receives D[8 g + 4 h + r][j] in accumulator 4 g + r.  (As VALU loops this phase took 9.5 us per step.)
+    //   dense  D[l][d] = sum_f  C[f][l] Wd[d][f]                                                (8 x 8 tiles of 16 x 16, K = 32)
+    // both on v_mfma_f32_16x16x4_f32 over all 16 waves (lane mappings at the loops).  History of the phase: 9.5 us per step as VALU
+    // loops, 6.9 on 32 x 32 x 2 tiles (the convolution on 4 waves), 4.0 now - see EXPERIMENTS.md, round 4.
 #ifdef GVX_STAMPS
     bool loc_stamp_on = false;   // (stamps build: waves 0 / 5 / 10 / 15 of row 0 stamp the phases of the location features of step 20)
 #endif

@@ -10,10 +10,16 @@
 // of the padded buffer - no gather, no materialised im2col.  The conv weight is repacked at load
 // time to [Cout][k][Cin] with eval-mode BatchNorm folded in.
 //
-// Tile: 256 threads = 4 waves, BK = 32, LDS double buffered through registers.
-//   <2,2,2,2>: 128x128 tile, each wave 64x64 (2x2 MFMA tiles)       - general case
-//   <4,1,1,3>: 128x96 tile, each wave 32x96 (1x3 MFMA tiles)        - N <= 96 (the last Postnet conv, N = 80)
+// Tile: one wave per (WR, WC) cell of the shape, BK = 32, LDS double buffered through registers.
+//   <4,2,1,2>: 128x128 tile on eight waves of 32x64                 - general case (row-major operands)
+//   <2,2,2,2>: 128x128 tile, each of four waves 64x64               - its predecessor (GVX_GEMM_8W=0) and the K-major form
+//   <2,2,1,2> / <2,2,1,1>: 64x128 / 64x64 tiles of four waves       - few tiles (encoder convolutions), remainders
+//   <4,1,1,3>: 128x96 tile, each wave 32x96 (1x3 MFMA tiles)        - N <= 96 (the last Postnet conv, the mel / gate projection)
 //   <4,1,1,1>: 128x32                                              - N <= 32
+// Eight waves instead of four on the big tile: two waves per SIMD inside ONE workgroup - a workgroup's epilogue (64 KB of
+// stores) and its barrier waits run beside another wave's products (the attention LSTM's Prenet columns, K = 256 and 419 MB
+// of output: encoder stage 1.29 -> 1.19 ms; Postnet 2.15 -> 2.11 ms).  Tried for N <= 96 and dropped: 64x96 tiles of six
+// waves with one MFMA tile each (MFMA busy 0.40 vs 0.44), k-tiles of 64 (0.46, no better once the loads sat right).
 // LDS rows are 36 floats (144 B): with that stride the ds_read_b128 fragment reads of the
 // sixteen-lane groups fall on distinct 16-byte bank slots (conflict free).
 // MFMA operand trick: one float4 per lane feeds four k-steps (k = 8*kg + 4*(lane>>5) + s), so both
@@ -27,13 +33,12 @@ namespace gvx {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 32;
+constexpr int BK32 = 32;
 // (Rounds 1-3 carried a second version of these products on the bf16 matrix pipe - every fp32 operand split exactly into three bf16
 // pieces, six v_mfma_f32_32x32x16_bf16 per 16 k - which was 19 % faster on the Postnet and parity-green.  Retired in round 4: the
 // double-rate 16-bit MFMA forms of gfx950 corrupt fp32 kernels that run on the SAME OR A NEIGHBOURING CU at the same time
 // (tools/micro/mfma_bf16_neighbour.hip, profiles/r04_mfma_bf16_neighbour_cumask.txt: 0 wrong words on disjoint halves of the CU
 // mask, thousands on shared or interleaved CUs), and a library cannot choose its neighbours on the chip.)
-constexpr int LDS_LD = 36;
 
 __device__ __forceinline__ long row_off(const RowMap& m, int row) {
     return (long)(row / m.R) * m.s1 + (long)(row % m.R) * m.s0;
@@ -41,17 +46,21 @@ __device__ __forceinline__ long row_off(const RowMap& m, int row) {
 
 // KMAJ: both operands are K-major - element (m, k) of A at A + amap(k) + m, element (n, k) of W at W + wmap(k) + n - the
 // form of a weight gradient (sum over the rows of two activation matrices) without transposed copies.
-template <int WR, int WC, int TM, int TN, bool KMAJ = false>
-__device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int block_x) {
+template <int WR, int WC, int TM, int TN, bool KMAJ = false, int BK = BK32>
+__device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int block_x, const int tid, float* smem) {
+    constexpr int LDS_LD = BK + 4;   // 36 / 68 floats: see the header
+    static_assert(BK == 32 || (BK == 64 && !KMAJ), "k-tiles of 32, or 64 for the row-major form");
     constexpr int BM = WR * TM * 32;
     constexpr int BN = WC * TN * 32;
-    constexpr int A_V4 = BM / 32;  // float4 loads per thread for the A tile
-    constexpr int B_V4 = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = WR * WC * 64;  // threads: 256 for the four-wave shapes, 384 for <2,3,1,1>
+    constexpr int TPR = BK / 4;       // threads per tile row (16 bytes each)
+    constexpr int RPP = NT / TPR;     // tile rows one pass of the loaders covers
+    constexpr int A_V4 = (BM + RPP - 1) / RPP;  // float4 loads per thread for the A tile (the last pass may be partial)
+    constexpr int B_V4 = (BN + RPP - 1) / RPP;
+    static_assert(!KMAJ || NT == 256, "the K-major loaders are written for 256 threads");
     float* As = smem;                         // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const int r = lane & 31, h = lane >> 5;
@@ -65,7 +74,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int blo
     float* const Cout = p.C + (p.splitk > 1 ? (long)blockIdx.y * p.c_split : 0);
 
     // global -> register staging assignments
-    const int ld_row = tid >> 3, ld_c4 = tid & 7;
+    const int ld_row = tid / TPR, ld_c4 = tid % TPR;
     const float* a_ptr[A_V4]; bool a_ok[A_V4];
     const float* b_ptr[B_V4]; bool b_ok[B_V4];
     // K-major operands: a thread owns 4 consecutive rows of the tile (m or n) and one quad of k per pass: four 16-byte loads
@@ -90,13 +99,13 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int blo
     if (!KMAJ) {
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
-            int m = m0 + ld_row + 32 * i;
+            int m = m0 + ld_row + RPP * i;
             a_ok[i] = m < p.M;
             a_ptr[i] = p.A + (a_ok[i] ? row_off(p.amap, m) : 0);
         }
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
-            int n = n0 + ld_row + 32 * i;
+            int n = n0 + ld_row + RPP * i;
             b_ok[i] = n < p.N;
             b_ptr[i] = p.W + (b_ok[i] ? (long)n * p.ldw : 0);
         }
@@ -104,8 +113,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int blo
     float4 a_reg[A_V4], b_reg[B_V4];
 
     // global -> registers for the k-tile starting at K0.  Rows past M / N read row 0 (in bounds): their products land in
-    // accumulator rows / columns the epilogue never stores, so only the k tail is masked (per component: a float4
-    // select makes LLVM build a scratch lookup table).
+    // accumulator rows / columns the epilogue never stores; the k tail reads in-bounds addresses too and is zeroed at the LDS
+    // stores (GEMM_STORE_TILE), so that nothing depends on the loaded values while the products of the current tile run.
 #define GEMM_KMAJ_LOAD(NP, QPP, KQ, KG, KI, MAP, SAFE, PTR, COL, REG)                                        \
         _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                    \
             const int c_ = KQ + QPP * i;                                                                    \
@@ -114,9 +123,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int blo
                 int g_ = KG[i], x_ = KI[i];                                                                 \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
                     const bool ok_ = kq_ + j < k_end;                                                       \
-                    const float4 ld_ = *reinterpret_cast<const float4*>(PTR + (ok_ ? (long)g_ * MAP.s1 + (long)x_ * MAP.s0 : SAFE) + COL); \
-                    REG[i][j].x = ok_ ? ld_.x : 0.f; REG[i][j].y = ok_ ? ld_.y : 0.f;                       \
-                    REG[i][j].z = ok_ ? ld_.z : 0.f; REG[i][j].w = ok_ ? ld_.w : 0.f;                       \
+                    REG[i][j] = *reinterpret_cast<const float4*>(PTR + (ok_ ? (long)g_ * MAP.s1 + (long)x_ * MAP.s0 : SAFE) + COL); \
                     if (++x_ == MAP.R) { x_ = 0; ++g_; }                                                    \
                 }                                                                                           \
                 x_ = KI[i] + BK; g_ = KG[i];                                                                \
@@ -135,14 +142,12 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int blo
         const bool k_ok_ = k_ < k_end;                                                                      \
         const long a_koff_ = (long)(k_ >> 3) * p.a_kblk + (k_ & 7);                                         \
         _Pragma("unroll") for (int i = 0; i < A_V4; ++i) {                                                  \
-            const float4 v_ = *reinterpret_cast<const float4*>(a_ptr[i] + (k_ok_ ? a_koff_ : 0));           \
-            a_reg[i].x = k_ok_ ? v_.x : 0.f; a_reg[i].y = k_ok_ ? v_.y : 0.f;                               \
-            a_reg[i].z = k_ok_ ? v_.z : 0.f; a_reg[i].w = k_ok_ ? v_.w : 0.f;                               \
+            if (BM % RPP != 0 && ld_row + RPP * i >= BM) continue;                                          \
+            a_reg[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (k_ok_ ? a_koff_ : 0));                  \
         }                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < B_V4; ++i) {                                                  \
-            const float4 v_ = *reinterpret_cast<const float4*>(b_ptr[i] + (k_ok_ ? k_ : 0));               \
-            b_reg[i].x = k_ok_ ? v_.x : 0.f; b_reg[i].y = k_ok_ ? v_.y : 0.f;                               \
-            b_reg[i].z = k_ok_ ? v_.z : 0.f; b_reg[i].w = k_ok_ ? v_.w : 0.f;                               \
+            if (BN % RPP != 0 && ld_row + RPP * i >= BN) continue;                                          \
+            b_reg[i] = *reinterpret_cast<const float4*>(b_ptr[i] + (k_ok_ ? k_ : 0));                       \
         }                                                                                                   \
     }
 #define GEMM_KMAJ_STORE(NP, QPP, KQ, SM, ROWS, RQ, REG, BUF)                                                 \
@@ -150,28 +155,37 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int blo
             const int c_ = KQ + QPP * i;                                                                    \
             if (c_ < BK / 4) {                                                                              \
                 float* d_ = &SM[((BUF) * ROWS + 4 * RQ) * LDS_LD + 4 * c_];                                 \
-                *reinterpret_cast<float4*>(d_) = make_float4(REG[i][0].x, REG[i][1].x, REG[i][2].x, REG[i][3].x);              \
-                *reinterpret_cast<float4*>(d_ + LDS_LD) = make_float4(REG[i][0].y, REG[i][1].y, REG[i][2].y, REG[i][3].y);     \
-                *reinterpret_cast<float4*>(d_ + 2 * LDS_LD) = make_float4(REG[i][0].z, REG[i][1].z, REG[i][2].z, REG[i][3].z); \
-                *reinterpret_cast<float4*>(d_ + 3 * LDS_LD) = make_float4(REG[i][0].w, REG[i][1].w, REG[i][2].w, REG[i][3].w); \
+                const int kq_ = (KS_) + 4 * c_;   /* the k tail: zeros, here and not at the loads (see GEMM_LOAD_TILE) */ \
+                const bool o0_ = kq_ < k_end, o1_ = kq_ + 1 < k_end, o2_ = kq_ + 2 < k_end, o3_ = kq_ + 3 < k_end;   \
+                *reinterpret_cast<float4*>(d_) = make_float4(o0_ ? REG[i][0].x : 0.f, o1_ ? REG[i][1].x : 0.f, o2_ ? REG[i][2].x : 0.f, o3_ ? REG[i][3].x : 0.f);              \
+                *reinterpret_cast<float4*>(d_ + LDS_LD) = make_float4(o0_ ? REG[i][0].y : 0.f, o1_ ? REG[i][1].y : 0.f, o2_ ? REG[i][2].y : 0.f, o3_ ? REG[i][3].y : 0.f);     \
+                *reinterpret_cast<float4*>(d_ + 2 * LDS_LD) = make_float4(o0_ ? REG[i][0].z : 0.f, o1_ ? REG[i][1].z : 0.f, o2_ ? REG[i][2].z : 0.f, o3_ ? REG[i][3].z : 0.f); \
+                *reinterpret_cast<float4*>(d_ + 3 * LDS_LD) = make_float4(o0_ ? REG[i][0].w : 0.f, o1_ ? REG[i][1].w : 0.f, o2_ ? REG[i][2].w : 0.f, o3_ ? REG[i][3].w : 0.f); \
             }                                                                                               \
         }
-#define GEMM_STORE_TILE(BUF)                                                                                \
+#define GEMM_STORE_TILE(BUF, K0)                                                                            \
     if (KMAJ) {                                                                                             \
+        const int KS_ = (K0);                                                                               \
         GEMM_KMAJ_STORE(A_P, (256 / A_MQ), akq, As, BM, amq, ka_reg, BUF)                                   \
         GEMM_KMAJ_STORE(B_P, (256 / B_NQ), bkq, Bs, BN, bnq, kb_reg, BUF)                                   \
     } else                                                                                                  \
     {                                                                                                       \
+        const bool s_ok_ = (K0) + 4 * ld_c4 < k_end;   /* the k tail: zeros (per component: a float4 select makes LLVM build a scratch lookup table) */ \
         _Pragma("unroll") for (int i = 0; i < A_V4; ++i)                                                    \
-            *reinterpret_cast<float4*>(&As[((BUF) * BM + ld_row + 32 * i) * LDS_LD + 4 * ld_c4]) = a_reg[i]; \
+            if (BM % RPP == 0 || ld_row + RPP * i < BM)                                                     \
+                *reinterpret_cast<float4*>(&As[((BUF) * BM + ld_row + RPP * i) * LDS_LD + 4 * ld_c4]) =     \
+                    make_float4(s_ok_ ? a_reg[i].x : 0.f, s_ok_ ? a_reg[i].y : 0.f, s_ok_ ? a_reg[i].z : 0.f, s_ok_ ? a_reg[i].w : 0.f); \
         _Pragma("unroll") for (int i = 0; i < B_V4; ++i)                                                    \
-            *reinterpret_cast<float4*>(&Bs[((BUF) * BN + ld_row + 32 * i) * LDS_LD + 4 * ld_c4]) = b_reg[i]; \
+            if (BN % RPP == 0 || ld_row + RPP * i < BN)                                                     \
+                *reinterpret_cast<float4*>(&Bs[((BUF) * BN + ld_row + RPP * i) * LDS_LD + 4 * ld_c4]) =     \
+                    make_float4(s_ok_ ? b_reg[i].x : 0.f, s_ok_ ? b_reg[i].y : 0.f, s_ok_ ? b_reg[i].z : 0.f, s_ok_ ? b_reg[i].w : 0.f); \
     }
-#define GEMM_COMPUTE_TILE(BUF)                                                                              \
+#define GEMM_COMPUTE_TILE(BUF) GEMM_COMPUTE_KGS(BUF, 0, BK / 8)
+#define GEMM_COMPUTE_KGS(BUF, KG0, KG1)   /* k-groups KG0 .. KG1 - 1 of the tile in buffer BUF */           \
     {                                                                                                       \
         const float* a_base = &As[((BUF) * BM + wr * TM * 32 + r) * LDS_LD + 4 * h];                        \
         const float* b_base = &Bs[((BUF) * BN + wc * TN * 32 + r) * LDS_LD + 4 * h];                        \
-        _Pragma("unroll") for (int kg = 0; kg < BK / 8; ++kg) {                                             \
+        _Pragma("unroll") for (int kg = (KG0); kg < (KG1); ++kg) {                                          \
             float4 af[TM], bf[TN];                                                                          \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
                 af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDS_LD + 8 * kg);                \
@@ -198,14 +212,21 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int blo
     // rows that do not exist read row 0 / weight row 0 (in bounds) and are zeroed by the select above
     const int nkt = (k_end - k_begin + BK - 1) / BK;
     GEMM_LOAD_TILE(k_begin)
-    GEMM_STORE_TILE(0)
+    GEMM_STORE_TILE(0, k_begin)
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nkt; ++kt) {            // steady state: prefetch tile kt+1 while computing tile kt (no branches inside)
         const int cur = kt & 1;
         GEMM_LOAD_TILE(k_begin + (kt + 1) * BK)
-        GEMM_COMPUTE_TILE(cur)
-        GEMM_STORE_TILE(cur ^ 1)
+        // The loads stay in front of the products, and what they return is first touched (k-tail zeros, LDS stores) beside the
+        // products of the tile's LAST k-group, in the shadow of its MFMAs.  Left to itself the compiler put loads, selects and stores
+        // together - three quarters through the MFMA sequence (a whole memory latency exposed per k-tile), or right behind the
+        // loads once the selects had moved to the stores.
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_COMPUTE_KGS(cur, 0, BK / 8 - 1)
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_COMPUTE_KGS(cur, BK / 8 - 1, BK / 8)
+        GEMM_STORE_TILE(cur ^ 1, k_begin + (kt + 1) * BK)
         __syncthreads();
     }
     GEMM_COMPUTE_TILE(kt & 1)               // last tile
@@ -214,6 +235,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int blo
 #undef GEMM_KMAJ_STORE
 #undef GEMM_STORE_TILE
 #undef GEMM_COMPUTE_TILE
+#undef GEMM_COMPUTE_KGS
 
     // epilogue: D[row][col] with col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
 #pragma unroll
@@ -247,26 +269,19 @@ __device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int blo
     }
 }
 
-template <int WR, int WC, int TM, int TN, bool KMAJ = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) { gemm_f32_body<WR, WC, TM, TN, KMAJ>(p, (int)blockIdx.x); }
-
-// Two tile shapes in ONE launch (the wave-quantisation cover of launch_gemm): the first `n_big` workgroups take the 128 x 128
-// tiles of the full rounds (params `big`), the others the 64 x 64 tiles of the remaining rows (`small`), which fill the CUs
-// as the last big round drains.  As two launches the remainder ran alone on half the chip behind a barrier (90 us per Postnet
-// convolution); Postnet at 32 x 800 frames 2.42 -> 2.21 ms (small tiles FIRST: 2.29).
-__global__ __launch_bounds__(256) void gemm_f32_two_shape_kernel(GemmParams big, GemmParams small, int n_big) {
-    const int bx = (int)blockIdx.x;   // (the branch is uniform per workgroup)
-    if (bx < n_big) gemm_f32_body<2, 2, 2, 2>(big, bx);
-    else gemm_f32_body<2, 2, 1, 1>(small, bx - n_big);
+template <int WR, int WC, int TM, int TN, bool KMAJ = false, int BK = BK32>
+__global__ __launch_bounds__(WR * WC * 64) void gemm_f32_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_f32_body<WR, WC, TM, TN, KMAJ, BK>(p, (int)blockIdx.x, (int)threadIdx.x, smem);
 }
 
-template <int WR, int WC, int TM, int TN>
-static size_t lds_bytes_cfg() { return (size_t)2 * (WR * TM * 32 + WC * TN * 32) * LDS_LD * sizeof(float); }
+template <int WR, int WC, int TM, int TN, int BK = BK32>
+static size_t lds_bytes_cfg() { return (size_t)2 * (WR * TM * 32 + WC * TN * 32) * (BK + 4) * sizeof(float); }
 
-template <int WR, int WC, int TM, int TN, bool KMAJ = false>
+template <int WR, int WC, int TM, int TN, bool KMAJ = false, int BK = BK32>
 static hipError_t init_cfg() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<WR, WC, TM, TN, KMAJ>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_cfg<WR, WC, TM, TN>());
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<WR, WC, TM, TN, KMAJ, BK>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_cfg<WR, WC, TM, TN, BK>());
 }
 
 hipError_t gemm_init() {
@@ -276,24 +291,29 @@ hipError_t gemm_init() {
     if (e != hipSuccess) return e;
     e = init_cfg<4, 1, 1, 3>();
     if (e != hipSuccess) return e;
+    e = init_cfg<4, 2, 1, 2>();
+    if (e != hipSuccess) return e;
     e = init_cfg<2, 2, 1, 1>();
     if (e != hipSuccess) return e;
     e = init_cfg<2, 2, 2, 2, true>();
     if (e != hipSuccess) return e;
     e = init_cfg<2, 2, 1, 2, true>();
     if (e != hipSuccess) return e;
-    e = init_cfg<4, 1, 1, 1>();
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_two_shape_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds_bytes_cfg<2, 2, 2, 2>());
+    return init_cfg<4, 1, 1, 1>();
 }
 
-template <int WR, int WC, int TM, int TN, bool KMAJ = false>
+template <int WR, int WC, int TM, int TN, bool KMAJ = false, int BK = BK32>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
     const int grid = ((p.M - p.m_begin + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    gemm_f32_kernel<WR, WC, TM, TN, KMAJ><<<dim3(grid, p.splitk > 1 ? p.splitk : 1), dim3(256), lds_bytes_cfg<WR, WC, TM, TN>(), s>>>(p);
+    gemm_f32_kernel<WR, WC, TM, TN, KMAJ, BK><<<dim3(grid, p.splitk > 1 ? p.splitk : 1), dim3(WR * WC * 64), lds_bytes_cfg<WR, WC, TM, TN, BK>(), s>>>(p);
     return hipGetLastError();
+}
+
+// GVX_GEMM_8W=0 (A/B): the 128 x 128 tile on four waves of 64 x 64 instead of eight of 32 x 64
+static bool four_waves() {
+    static const bool on = [] { const char* e = std::getenv("GVX_GEMM_8W"); return e && e[0] == '0'; }();
+    return on;
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
@@ -313,11 +333,12 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     // 64 x 128 workgroup of four waves per CU left the matrix pipe waiting on its own loads (155 -> 115 us per convolution)
     if (tiles128 < 192) return launch_cfg<2, 2, 1, 1>(p, s);
     if (tiles128 < 384) return launch_cfg<2, 2, 1, 2>(p, s);
-    // Wave quantisation: 128 x 128 tiles run in rounds of 256 (one per CU); a last round with few tiles leaves most of the
-    // chip idle for a whole tile time (the Postnet at 32 x 800 frames: 800 tiles = 3 rounds + 32 tiles, 78 % of 4 rounds).
-    // When the last round would be at most a quarter full, the rows of the full rounds get the big tiles and the remaining
-    // rows 64 x 64 tiles (four times as many workgroups, a quarter of the time each) behind them in the same launch.  Every output
-    // element still sums its K products in the same order: results do not depend on the tile shape.
+    // Wave quantisation: a last round of 128 x 128 tiles with few tiles leaves most of the chip idle for a whole tile time (the
+    // Postnet at 32 x 800 frames: 800 tiles = 3 per CU + 32).  When that remainder is at most a quarter of a round, the rows of
+    // the full rounds get the big tiles and the remaining rows 64 x 64 tiles (four times as many workgroups, a quarter of the
+    // time each) in a second launch.  Every output element still sums its K products in the same order: results do not depend
+    // on the tile shape.  (Rounds 2-4 ran both shapes in ONE launch, the small tiles filling the CUs as the last big round
+    // drained: worth 0.2 ms per Postnet with four-wave tiles, but 2.18 vs 2.12 ms - slower - with the eight-wave ones.)
     const long rem = tiles128 % 256;
     if (p.splitk <= 1 && p.m_begin == 0 && rem > 0 && rem <= 64) {
         const long rows_big = ((tiles128 - rem) / n_tiles) * 128;   // whole row tiles of the full rounds
@@ -325,19 +346,12 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
             GemmParams a = p, b = p;
             a.M = (int)rows_big;
             b.m_begin = (int)rows_big;
-            static const bool two_launches = [] { const char* e = std::getenv("GVX_GEMM_TWO_LAUNCHES"); return e && e[0] == '1'; }();   // (A/B)
-            if (!two_launches) {
-                const int n_small = ((p.M - b.m_begin + 63) / 64) * ((p.N + 63) / 64);
-                const int n_big = (a.M / 128) * (int)n_tiles;
-                gemm_f32_two_shape_kernel<<<dim3(n_big + n_small), dim3(256), lds_bytes_cfg<2, 2, 2, 2>(), s>>>(a, b, n_big);
-                return hipGetLastError();
-            }
-            const hipError_t e = launch_cfg<2, 2, 2, 2>(a, s);
+            const hipError_t e = four_waves() ? launch_cfg<2, 2, 2, 2>(a, s) : launch_cfg<4, 2, 1, 2>(a, s);
             if (e != hipSuccess) return e;
             return launch_cfg<2, 2, 1, 1>(b, s);
         }
     }
-    return launch_cfg<2, 2, 2, 2>(p, s);
+    return four_waves() ? launch_cfg<2, 2, 2, 2>(p, s) : launch_cfg<4, 2, 1, 2>(p, s);
 }
 
 // out[m][n] = sum_s part[s][m][n] (+ bias[n]), splits added in index order
@@ -356,7 +370,7 @@ hipError_t launch_gemm_splitk(const GemmParams& p0, int splitk, float* scratch, 
     if (p0.act != ACT_NONE || p0.keep || p0.row_len || p0.c_halo || p0.c_nblk != 8 || p0.cmap.s1 != 0 || p0.cmap.R < p0.M || !scratch)
         return hipErrorInvalidValue;   // plain row-major outputs only
     GemmParams p = p0;
-    const int kc = ((p.K + splitk - 1) / splitk + BK - 1) / BK * BK;
+    const int kc = ((p.K + splitk - 1) / splitk + 63) / 64 * 64;   // (whole k-tiles of either size)
     p.splitk = (p.K + kc - 1) / kc;
     p.kchunk = kc;
     p.C = scratch; p.cmap = RowMap{p.M, 0, (long)p.N};

@@ -160,6 +160,7 @@ struct gvx_model {
                                        // wait of the loop runs into its limit (test of the time-out reporting only)
     hipStream_t pa_stream = nullptr;
     hipEvent_t pa_fork = nullptr, pa_join = nullptr, enc_mid = nullptr;
+    int enc_fork_after = 1;      // GVX_ENC_FORK_AFTER=<n>: the caller's Prenet products start behind n encoder convolutions
     // autoregressive loop: the all-rows-finished counter of chunk k is read (pinned slot k & 1, event k & 1) while chunk k + 1 runs
     int32_t* ar_done_host = nullptr;
     hipEvent_t ar_ev[2] = {nullptr, nullptr};
@@ -456,6 +457,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     if (const char* e = std::getenv("GVX_AR_RESIDENT")) m->ar_resident = e[0] == '1';
     if (const char* e = std::getenv("GVX_AR_SPLIT_H")) m->ar_split_h = e[0] != '0';
     if (const char* e = std::getenv("GVX_ENC_PERSISTENT")) m->enc_persistent = e[0] != '0';
+    if (const char* e = std::getenv("GVX_ENC_FORK_AFTER")) m->enc_fork_after = std::atoi(e);
     if (const char* e = std::getenv("GVX_TF_ROWS64")) m->tf_rows64 = e[0] == '1';
     if (const char* e = std::getenv("GVX_TF_RESIDENT")) m->tf_resident = e[0] != '0';
     if (const char* e = std::getenv("GVX_AR_RESIDENT_LOOP")) m->ar_resident_loop = e[0] != '0';
@@ -832,18 +834,16 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
     float* enc_h = ws_ptr<float>(ws, wp.enc_h);
     float* enc_c = ws_ptr<float>(ws, wp.enc_c);
     int* flags = ws_ptr<int>(ws, wp.flags);
-    const size_t xbytes = (size_t)B * (L + 2 * pe) * E * sizeof(float);
     float* cur = xa;
     float* nxt = xb;
     if (conv_out) {
         HIP_TRY(launch_to_channels_last(conv_out, xa, B, E, L, pe, nullptr, s));
     } else {
-        HIP_TRY(zero_async(xa, xbytes, s));
-        HIP_TRY(zero_async(xb, xbytes, s));
         // (the token-error word is sticky: raised here, cleared only by gvx_workspace_status - a later chunk on the same
         // workspace must not wipe an earlier chunk's error)
-        HIP_TRY(launch_embed(tokens, m->dev_blob + m->blob.emb, d.n_tokens, xa, B, L, E, pe, flags + FLAG_TOKEN, s));
+        HIP_TRY(launch_embed(tokens, m->dev_blob + m->blob.emb, d.n_tokens, xa, xb, B, L, E, pe, flags + FLAG_TOKEN, s));   // (+ the halo rows of xa and xb)
         for (int i = 0; i < d.enc_n_conv; ++i) {
+            if (dense_done && i == m->enc_fork_after) { HIP_TRY(hipEventRecord(dense_done, s)); dense_done = nullptr; }
             int rc = conv_layer(m, cur, nxt, B, L, E, E, d.enc_kernel, m->blob.enc_w[i], m->blob.enc_b[i], ACT_RELU, pe, s);
             if (rc != GVX_OK) return rc;
             float* t = cur; cur = nxt; nxt = t;
@@ -861,13 +861,14 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
         g.M = B * L; g.N = 8 * H; g.K = E; g.act = ACT_NONE;
         HIP_TRY(launch_gemm(g, s));
     }
-    HIP_TRY(zero_async(enc_h, (size_t)4 * B * H * sizeof(float), s));
-    HIP_TRY(zero_async(enc_c, (size_t)2 * B * H * sizeof(float), s));
+    const bool resident = m->enc_persistent && encoder_persistent_supported(B, H);
+    if (!resident) HIP_TRY(zero_async(enc_h, (size_t)4 * B * H * sizeof(float), s));
+    if (!resident) HIP_TRY(zero_async(enc_c, (size_t)2 * B * H * sizeof(float), s));   // (the resident kernel keeps the cells in registers)
     // The L recurrence launches only reference workspace operands: lengths are copied next to them and the sequence output
     // goes to the workspace-resident memory buffer (copied to the caller's tensor afterwards when that is a different
     // one), so the key of the cached hipGraph does not depend on a freshly allocated output tensor.
     float* mem_ws = ws_ptr<float>(ws, wp.memory);
-    HIP_TRY(zero_async(mem_ws, (size_t)B * L * E * sizeof(float), s));
+    if (!resident) HIP_TRY(zero_async(mem_ws, (size_t)B * L * E * sizeof(float), s));   // (the resident kernel writes every position)
     const int32_t* len_ws = nullptr;
     if (lengths) {
         int32_t* lc = ws_ptr<int32_t>(ws, wp.len_copy);
@@ -897,11 +898,13 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
         }
         return GVX_OK;
     };
-    if (m->enc_persistent && encoder_persistent_supported(B, H)) {
+    if (resident) {
         // one resident launch for the whole recurrence (skinny.hip, encoder_lstm_persistent_kernel); a hand-off that times out
         // leaves NaN in the encoder output and raises the sticky status word, like the resident decoder loops
         unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
-        HIP_TRY(zero_async(sync, HANDOFF_WORDS * sizeof(unsigned), s));
+        void* const zp[2] = {enc_h, sync + HANDOFF_TIMEOUT};   // the exchange buffers (generation bits 0), the call's time-out word
+        const size_t zb[2] = {(size_t)4 * B * H * sizeof(float), sizeof(unsigned)};
+        HIP_TRY(launch_zero_many(zp, zb, 2, s));
         EncPersistParams ep{};
         ep.Wp[0] = m->dev_blob + m->blob.enc_whh_frag[0]; ep.Wp[1] = m->dev_blob + m->blob.enc_whh_frag[1];
         ep.xg = xg; ep.lengths = len_ws; ep.hx = enc_h; ep.seq_out = mem_ws; ep.c_seq_out = c_seq_out;
@@ -946,11 +949,10 @@ DecoderBuffers decoder_buffers(void* ws, const WsPlan& wp) {
 int decoder_init_states(gvx_model* m, const float* memory, int B, int L, const DecoderBuffers& db, hipStream_t s) {
     const gvx_dims& d = m->d;
     const int E = d.embed_dim, A = d.att_rnn_dim, D = d.dec_rnn_dim;
-    HIP_TRY(zero_async(db.h_a, (size_t)RS_HA_SLOTS * B * A * sizeof(float), s));
-    HIP_TRY(zero_async(db.c_a, (size_t)B * A * sizeof(float), s));
-    HIP_TRY(zero_async(db.c_d, (size_t)B * D * sizeof(float), s));
-    HIP_TRY(zero_async(db.hc, (size_t)B * (D + E) * sizeof(float), s));  // slot 0
-    HIP_TRY(zero_async(db.w_cum, (size_t)B * L * sizeof(float), s));
+    void* const zp[5] = {db.h_a, db.c_a, db.c_d, db.hc /* slot 0 */, db.w_cum};
+    const size_t zb[5] = {(size_t)RS_HA_SLOTS * B * A * sizeof(float), (size_t)B * A * sizeof(float), (size_t)B * D * sizeof(float),
+                          (size_t)B * (D + E) * sizeof(float), (size_t)B * L * sizeof(float)};
+    HIP_TRY(launch_zero_many(zp, zb, 5, s));
     GemmParams g{};
     g.A = memory; g.amap = RowMap{B * L, 0, (long)E};
     g.W = m->dev_blob + m->blob.wmem; g.ldw = E;

@@ -144,17 +144,18 @@ struct AttnParams;
 hipError_t launch_skinny_attn(const SkinnyJob* jobs, int njobs, const AttnParams& ap, hipStream_t s);
 // Encoder BiLSTM recurrence as ONE resident launch (skinny.hip, encoder_lstm_persistent_kernel): 2 directions x 32 tiles, every
 // workgroup keeps its 32 KB of W_hh in registers for the whole sequence and its cell states in registers; the hidden state goes
-// round through a double-buffered blocked vector (write-through stores, sc1 loads) with one flag word per cell wave.  B <= 32,
-// H = 256 (the default layer size); packed-sequence semantics as the launch-per-step loop.
+// round through a double-buffered blocked vector (write-through stores, sc1 loads) whose words carry the hand-off's generation
+// bit themselves (no flags).  B <= 32, H = 256 (the default layer size); packed-sequence semantics as the launch-per-step
+// loop; every position of seq_out / c_seq_out is written (zeros past a row's length).
 struct EncPersistParams {
     const float* Wp[2];        // packed fragments of W_hh per direction [H/8 tiles][H/8 k-groups][64][4]
     const float* xg;           // input projections incl. biases [B][L][2 * 4H] (direction-major inside a position)
     const int32_t* lengths;    // [B] or nullptr (all rows L)
-    float* hx;                 // exchange buffers [2 directions][2][H/8][B][8]
+    float* hx;                 // exchange buffers [2 directions][2][H/8][B][8], zeroed by the caller (bit 30 of every word is the
+                               // hand-off's generation bit)
     float* seq_out;            // [B][L][2H]: direction d writes columns d*H ..
     float* c_seq_out;          // training tape: the cell state of every position, same layout, or nullptr
-    unsigned* sync;            // HANDOFF_WORDS words (zeroed by the caller): flags from HANDOFF_CNT_Q / HANDOFF_CNT_CTX on (one
-                               // direction each, 4 x H/8 words), time-out word
+    unsigned* sync;            // HANDOFF_WORDS words; only the time-out word (HANDOFF_TIMEOUT) is used, zeroed by the caller
     unsigned spin_limit;
     int B, L, H;
     int debug_skip_block;      // tests: this workgroup leaves at once (its flags never go up: every wait on them times out); -1 = none
@@ -368,7 +369,8 @@ __device__ __forceinline__ bool handoff_wait(const unsigned* cnt, unsigned targe
 // Small data-movement kernels.
 // ---------------------------------------------------------------------------------------------
 // x[b][p + l][:] = emb[tokens[b][l]][:]   into a halo-padded channels-last buffer (halo rows pre-zeroed)
-hipError_t launch_embed(const int64_t* tokens, const float* emb, int n_tokens, float* x, int B, int L, int E, int halo,
+// (x2: a second halo buffer of the same shape whose halo rows are cleared as well, or nullptr)
+hipError_t launch_embed(const int64_t* tokens, const float* emb, int n_tokens, float* x, float* x2, int B, int L, int E, int halo,
                         int* err_flag, hipStream_t s);
 // frames[(t)*B + b][m] = (t == 0) ? 0 : mel_in[b][m][t-1]     t in [0, T]
 hipError_t launch_frames_from_mel(const float* mel_in, float* frames, int B, int M, int T, hipStream_t s);
@@ -384,6 +386,8 @@ hipError_t launch_zero_halo(float* buf, int B, int T, int halo, int C, hipStream
 hipError_t launch_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* mel_lengths, int B, int M, int T,
                                hipStream_t s);
 // if *tmo != 0 (a bounded in-launch wait of this call gave up): NaN over the n_arrays (<= 4) output arrays and *sticky = *tmo
+// up to 8 arrays (4-byte aligned, sizes in bytes, multiples of 4) cleared by one launch
+hipError_t launch_zero_many(void* const* ptrs, const size_t* bytes, int n_arrays, hipStream_t s);
 hipError_t launch_poison_on_timeout(const unsigned* tmo, int* sticky, float* const* ptrs, const size_t* counts, int n_arrays, hipStream_t s);
 // dst[b][t][:] = src[t][b][:]  (rows of n floats, n % 4 == 0 not required)
 hipError_t launch_permute01(const float* src, float* dst, int T, int B, int n, hipStream_t s);

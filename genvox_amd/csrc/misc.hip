@@ -8,8 +8,20 @@
 namespace gvx {
 
 // ---- embedding gather (reference: nn.Embedding, models/tts/tacotron2.py:459/:486) -------------------
-__global__ void embed_kernel(const int64_t* tokens, const float* emb, int n_tokens, float* x, int L, int E, int halo, int* err_flag) {
+// Blocks past the B*L token rows clear the halo rows (the convolutions' zero padding) of x and of the stack's second buffer x2:
+// nobody else ever writes them, and clearing the two whole buffers cost two 8 MB fills per call.
+__global__ void embed_kernel(const int64_t* tokens, const float* emb, int n_tokens, float* x, float* x2, int B, int L, int E, int halo, int* err_flag) {
     const int row = blockIdx.x;  // b*L + l
+    if (row >= B * L) {
+        const int k = row - B * L, b = k / (2 * halo), r = k - b * 2 * halo;
+        const long at = ((long)b * (L + 2 * halo) + (r < halo ? r : L + r)) * E;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = threadIdx.x; i < E / 4; i += blockDim.x) {
+            reinterpret_cast<float4*>(x + at)[i] = z;
+            if (x2) reinterpret_cast<float4*>(x2 + at)[i] = z;
+        }
+        return;
+    }
     const int b = row / L, l = row - b * L;
     long tok = tokens[row];
     bool ok = tok >= 0 && tok < n_tokens;
@@ -19,9 +31,9 @@ __global__ void embed_kernel(const int64_t* tokens, const float* emb, int n_toke
     for (int i = threadIdx.x; i < E / 4; i += blockDim.x) dst[i] = ok ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-hipError_t launch_embed(const int64_t* tokens, const float* emb, int n_tokens, float* x, int B, int L, int E, int halo,
+hipError_t launch_embed(const int64_t* tokens, const float* emb, int n_tokens, float* x, float* x2, int B, int L, int E, int halo,
                         int* err_flag, hipStream_t s) {
-    hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(128), 0, s, tokens, emb, n_tokens, x, L, E, halo, err_flag);
+    hipLaunchKernelGGL(embed_kernel, dim3(B * L + B * 2 * halo), dim3(128), 0, s, tokens, emb, n_tokens, x, x2, B, L, E, halo, err_flag);
     return hipGetLastError();
 }
 
@@ -174,6 +186,29 @@ hipError_t launch_mask_padding(float* mel, float* mel_post, float* gate, const i
     int gx = (int)((n + 255) / 256);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(mask_padding_kernel, dim3(gx, B), dim3(256), 0, s, mel, mel_post, gate, mel_lengths, M, T);
+    return hipGetLastError();
+}
+
+// ---- several small buffers cleared by ONE launch (every hipMemsetAsync is a launch of its own: ~5 us on the stream) ----
+struct ZeroArgs { uint32_t* p[8]; size_t n[8]; };   // n: 32-bit words
+__global__ void zero_many_kernel(ZeroArgs a) {
+    uint32_t* p = a.p[blockIdx.y];
+    const size_t n = a.n[blockIdx.y];
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) p[k] = 0u;
+}
+hipError_t launch_zero_many(void* const* ptrs, const size_t* bytes, int n_arrays, hipStream_t s) {
+    if (n_arrays < 1 || n_arrays > 8) return hipErrorInvalidValue;
+    ZeroArgs a{};
+    size_t most = 0;
+    for (int i = 0; i < n_arrays; ++i) {
+        if ((reinterpret_cast<uintptr_t>(ptrs[i]) & 3) || (bytes[i] & 3)) return hipErrorInvalidValue;
+        a.p[i] = reinterpret_cast<uint32_t*>(ptrs[i]); a.n[i] = bytes[i] / 4;
+        if (a.n[i] > most) most = a.n[i];
+    }
+    int gx = (int)((most + 1023) / 1024);   // (four words per thread at the widest array, at most 64 workgroups each)
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(zero_many_kernel, dim3(gx, n_arrays), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -754,16 +754,22 @@ template <int MT> __global__ __launch_bounds__(SK_THREADS) void ar_lstm_step_ker
 // ---- Encoder BiLSTM recurrence, resident for the whole sequence (EncPersistParams, gvx_kernels.h).
 // The launch-per-step loop pays a dispatch, a first-byte round trip for 32 KB of L2-resident weights and a kernel-end write-back
 // per position (7.3 us of kernel + 1.5 us of gap for ~1 us of work).  Here workgroup (direction, tile) holds its weight
-// fragments (4 k-groups per wave = 16 VGPRs), its cell states and its previous hidden values in registers; per position it
-// waits for the direction's counter (all 32 tiles have published h(t-1)), reads the 32 KB vector with sc1 loads, runs 16
-// MFMAs per wave, sums the K slices through LDS, finishes the cells of its 8 hidden units, stores h(t) write-through and raises
-// its flags (one word per cell wave, plain stores: 128 adds per position to ONE counter word serialised at the memory side -
-// 529 us for 128 positions with the counter, tools/micro/handoff_latency.hip for the parts of a hand-off).  Buffer parity: h(t) goes to buffer (t+1) & 1, which position t-1's readers have left - they all
-// published h(t-1) before anybody could pass the wait of position t.  Every wait is bounded (handoff_wait): after a time-out
-// all waits return at once, the grid drains, and the caller's poison launch overwrites the output with NaN.
+// fragments (4 k-groups per wave = 16 VGPRs), its cell states and its previous hidden values in registers; per position every
+// wave reads its 4 KB of the direction's hidden vector with sc1 loads, runs 16 MFMAs, the K slices are summed through LDS, the
+// cell waves finish the cells of the tile's 8 hidden units and store h(t) write-through.
+// Hand-off WITHOUT flags: |h| <= 1, so bit 30 of its float pattern is always 0 - the store flips it to the generation bit of
+// the position (((t >> 1) & 1) ^ 1: the two exchange buffers alternate, so what a buffer held before - zeros at the start,
+// h(t-2) later - carries the other value), and a reader simply loads its share again until every dword carries the bit it
+// expects, then flips it back.  Every dword validates itself (a dword store is atomic), nothing waits for a write
+// acknowledgement and no flag line is shared by 32 pollers (the flag version - one word per cell wave, wait + barrier + loads,
+// `s_waitcnt vmcnt(0)` in front of the flag store - took 4.5 us per position).  A non-finite h never validates: the wait
+// times out and the output is poisoned - NaN comes out either way, with the status word up.
+// Buffer parity: h(t) goes to buffer (t+1) & 1, which position t-1's readers have left - a tile stores h(t-1) only behind its
+// own reads of position t-1, and nobody passes the reads of position t before all of h(t-1) is there.  Every wait is bounded:
+// after a time-out all waits return at their first look, the grid drains, and the caller's poison launch overwrites the
+// output with NaN.  Positions past a row's length get zeros from here (the caller does not clear the output).
 __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(EncPersistParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* red = smem;   // [SK_WAVES][16][64]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // two sets of partial sums [2][SK_WAVES][16][64]: one barrier per position
     const int tiles = p.H >> 3;                       // 32-row tiles per direction (4H / 32)
     // (one direction per XCD - blocks i % 8 == d of a grid of 8 x 32, the rest leaving at once - was tried: 1.97 instead of
     // 1.78 ms for the encoder stage; the exchange goes through memory either way and 32 workgroups then share one XCD's L2)
@@ -775,6 +781,7 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
     const int B = p.B, L = p.L, H = p.H, nkg = H >> 3;
     const unsigned blk = (unsigned)B * 8u;
     constexpr int KPW = 4;                            // k-groups per wave (H = 256)
+    constexpr unsigned GEN = 0x40000000u;             // the generation bit
     float4 wv[KPW];
     {
         const float4* wp = reinterpret_cast<const float4*>(p.Wp[dir]) + ((long)tile * nkg + wave * KPW) * 64 + lane;
@@ -786,14 +793,16 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
     const bool row = bl < B;
     const int len = row ? (p.lengths ? min(max(p.lengths[bl], 0), L) : L) : 0;   // (clamped: a bad length must not index past the row)
     float c_state = 0.f, h_state = 0.f;
-    unsigned* cnt = p.sync + (dir ? HANDOFF_CNT_CTX : HANDOFF_CNT_Q);
     unsigned* tmo = p.sync + HANDOFF_TIMEOUT;
+    const unsigned limit = (p.spin_limit ? p.spin_limit : HANDOFF_SPIN_LIMIT) * 16u;
     const long E2 = 2L * H;
     const float* xg_row = p.xg + (long)(row ? bl : 0) * L * 4 * E2 + (long)dir * 4 * H + tile * 32 + 8 * g + 4 * h;
     float* out_row = p.seq_out + (long)(row ? bl : 0) * L * E2 + (long)dir * H + j;
     float* cs_row = p.c_seq_out ? p.c_seq_out + (long)(row ? bl : 0) * L * E2 + (long)dir * H + j : nullptr;
-    const unsigned x_off = ((unsigned)(row ? bl : 0) * 8u + 4u * (unsigned)h) * 4u;
+    const unsigned x_off = ((unsigned)(row ? bl : 0) * 8u + 4u * (unsigned)h) * 4u + (unsigned)(wave * KPW) * blk * 4u;
+    bool gave_up = false;   // (wave-uniform)
     for (int step = 0; step < L; ++step) {
+        float* red = smem + (step & 1) * (SK_WAVES * 16 * 64);
         // the position's input projection (known since before the launch): fetched before the wait
         const bool active = cell_wave && row && step < len;
         const int tb = dir ? (len - 1 - step) : step;
@@ -803,27 +812,31 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
         if (step > 0) {   // h(-1) = 0: nothing to multiply at the first position
-            if (wave == 0) {   // every lane watches two of the direction's 4 * tiles flags: one 16-byte-per-lane look covers them all
-                const unsigned nflag = 4u * (unsigned)tiles;
-                const unsigned f0 = (unsigned)lane < nflag ? (unsigned)lane : 0u, f1 = (unsigned)lane + 64u < nflag ? (unsigned)lane + 64u : 0u;
-                const unsigned limit = (p.spin_limit ? p.spin_limit : HANDOFF_SPIN_LIMIT) * 16u;
-                unsigned spins = 0;
-                while (true) {
-                    const unsigned v0 = __hip_atomic_load(cnt + f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned v1 = __hip_atomic_load(cnt + f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all(v0 >= (unsigned)step && v1 >= (unsigned)step)) break;
-                    if ((++spins & 127u) == 1u) {   // (after a time-out every wait gives up at its first look)
-                        if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                        if (spins > limit) { if (lane == 0) __hip_atomic_store(tmo, 0x400u + (unsigned)dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.hx + ((long)dir * 2 + (step & 1)) * H * B);
+            const unsigned gen = ((((unsigned)(step - 1) >> 1) & 1u) ^ 1u) * GEN;   // what position step-1 stored with
+            float4 xv[KPW];
+            unsigned spins = 0;
+            while (true) {
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) xv[i] = load_sc1(rx, x_off + (unsigned)i * blk * 4u);
+                unsigned bad = 0u;
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) {
+                    const unsigned a = __float_as_uint(xv[i].x) ^ gen, b = __float_as_uint(xv[i].y) ^ gen;
+                    const unsigned c = __float_as_uint(xv[i].z) ^ gen, d = __float_as_uint(xv[i].w) ^ gen;
+                    bad |= a | b | c | d;
+                    xv[i] = make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float(c), __uint_as_float(d));
+                }
+                if (gave_up || __all((bad & GEN) == 0u)) break;
+                if ((++spins & 127u) == 1u) {   // (after a time-out every wait gives up at its first look)
+                    if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = true; break; }
+                    if (spins > limit) {
+                        if (lane == 0) __hip_atomic_store(tmo, 0x400u + (unsigned)dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gave_up = true;
+                        break;
                     }
-                    __builtin_amdgcn_s_sleep(2);
                 }
             }
-            __syncthreads();
-            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.hx + ((long)dir * 2 + (step & 1)) * H * B);
-            float4 xv[KPW];
-#pragma unroll
-            for (int i = 0; i < KPW; ++i) xv[i] = load_sc1(rx, x_off + (unsigned)(wave * KPW + i) * blk * 4u);
 #pragma unroll
             for (int i = 0; i < KPW; ++i) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i].x, xv[i].x, acc, 0, 0, 0);
@@ -834,7 +847,7 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + lane] = acc[q];
-        __syncthreads();
+        __syncthreads();   // (the only barrier of a position: the other set of sums is written behind the next one)
         if (cell_wave) {
             float s[4];
 #pragma unroll
@@ -848,19 +861,17 @@ __global__ __launch_bounds__(SK_THREADS) void encoder_lstm_persistent_kernel(Enc
                 const float p0 = s[0] + ad.x, p1 = s[1] + ad.y, p2 = s[2] + ad.z, p3 = s[3] + ad.w;
                 c_state = sigmoidf_(p1) * c_state + sigmoidf_(p0) * tanhf_(p2);
                 h_state = sigmoidf_(p3) * tanhf_(c_state);
-                out_row[(long)tb * E2] = h_state;
-                if (cs_row) cs_row[(long)tb * E2] = c_state;
             }
             if (row) {   // inactive rows carry their state (packed-sequence semantics); rows past B are never read
                 const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.hx + ((long)dir * 2 + ((step + 1) & 1)) * H * B);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h_state), rh, (int)(((unsigned)tile * blk + (unsigned)bl * 8u + (unsigned)jloc) * 4u), 0, 16);
+                const unsigned gen = ((((unsigned)step >> 1) & 1u) ^ 1u) * GEN;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h_state) ^ gen, rh, (int)(((unsigned)tile * blk + (unsigned)bl * 8u + (unsigned)jloc) * 4u), 0, 16);
+                // the sequence output: the cell of an active position, zeros past the row's length (position `step` then, for
+                // both directions: the reverse one walks len-1 .. 0 first)
+                const long pos = active ? tb : step;
+                out_row[pos * E2] = active ? h_state : 0.f;
+                if (cs_row) cs_row[pos * E2] = active ? c_state : 0.f;
             }
-        }
-        // every cell wave publishes for itself (4 per tile and position): no second barrier - `red` is not written again
-        // before the next position's barrier, which these waves reach after their reads
-        if (cell_wave) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores of this wave have left
-            if (lane == 0) __hip_atomic_store(cnt + 4 * tile + wave, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -905,6 +916,7 @@ hipError_t skinny_init() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ar_attn_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = set_lds(train_bptt_products_kernel, 1)) != hipSuccess) return e;
     if ((e = set_lds(encoder_lstm_step_kernel<1>, 1)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_lstm_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SK_WAVES * 16 * 64 * (int)sizeof(float))) != hipSuccess) return e;
     return set_lds(encoder_lstm_step_kernel<2>, 2);
 }
 
@@ -1009,7 +1021,7 @@ bool encoder_persistent_supported(int B, int H) { return B >= 1 && B <= 32 && H 
 hipError_t launch_encoder_persistent(const EncPersistParams& p, hipStream_t s) {
     if (!encoder_persistent_supported(p.B, p.H) || p.L < 1 || !p.Wp[0] || !p.Wp[1] || !p.xg || !p.hx || !p.seq_out || !p.sync) return hipErrorInvalidValue;
     const int tiles = p.H / 8;   // per direction
-    encoder_lstm_persistent_kernel<<<dim3(2 * tiles), dim3(SK_THREADS), (size_t)SK_WAVES * 16 * 64 * sizeof(float), s>>>(p);
+    encoder_lstm_persistent_kernel<<<dim3(2 * tiles), dim3(SK_THREADS), (size_t)2 * SK_WAVES * 16 * 64 * sizeof(float), s>>>(p);
     return hipGetLastError();
 }
 

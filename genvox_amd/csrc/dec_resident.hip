@@ -85,6 +85,10 @@ struct RsArgs {
     const float* proj_hd_t; const float* proj_ctx_t; const float* pre_w1; const uint8_t* keep1;   // autoregressive loop only ...
     float* prenet; const float* y1; float* p_slab; const int32_t* n_done; int PSB;
     float* h_a; float* hc; float* q_slab; float* c_a; float* c_d;
+    // training-mode tape of the teacher-forced loop (TR instantiations only): keep masks of the dropout on both cells' outputs
+    // [T][B][H], cell states [T+1][B][H], gate pre-activations [T][B][H][4]; h_a then points at the tape [T+1][A/8][B][8]
+    const uint8_t* tr_keep_a; const uint8_t* tr_keep_d; float* tr_c_a; float* tr_c_d; float* tr_pre_a; float* tr_pre_d;
+    float tr_scale_a, tr_scale_d;
     unsigned* sync;
     unsigned att_frag_bytes;
     int B, T;
@@ -260,8 +264,11 @@ template <bool B> struct RsBool { static constexpr bool value = B; };
 
 }  // namespace
 
-template <int KIND, bool AR>
+typedef const __attribute__((address_space(4))) RsArgs* RsKarg;   // the kernel-argument segment (the kernels' only parameter)
+
+template <int KIND, bool AR, bool TR = false>
 __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int bid) {
+    static_assert(!(AR && TR), "the tape belongs to the teacher-forced loop");
     using Cfg = RsCfg<KIND>;
     constexpr bool XH = Cfg::XH, ATT = Cfg::ATT;
     constexpr int NN = Cfg::NN, NC = Cfg::NC, NRN = Cfg::NRN, NLN = Cfg::NLN;
@@ -395,7 +402,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         // decoder LSTM (t - RS_HA_SLOTS), has finished: here the wait - a look at the decoder-LSTM flags every few steps - hides under
         // the wait for h_a(t-1); in the epilogue it sat on the step's chain (0.9 us in the steps that needed a look).  The
         // autoregressive loop needs no check: prenet(t) exists because that cell's step t - 1 has finished
-        if (ATT && !AR && t >= RS_HA_SLOTS && (wave == 6 || ((XH || RT == 2) && wave == 7))) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, lane);
+        if (ATT && !AR && !TR && t >= RS_HA_SLOTS && (wave == 6 || ((XH || RT == 2) && wave == 7))) rs_gate(ctrl, RC_HD, t + 1 - RS_HA_SLOTS, poll, lane);
         float4 add4 = bias4;
         if (PP && XH) {   // this step's Prenet-column fragments on their way into LDS (every reader of `red` / `red2` has passed the barrier that ended the last step)
             const unsigned kg = (unsigned)(4 * wave);
@@ -459,10 +466,11 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         for (int sub = 0; sub < NSUB; ++sub) {
             const float* xsrc;
             int word, need;
-            if (ATT) { xsrc = p.h_a + (long)(t % RS_HA_SLOTS) * RS_A * B + (long)(16 * wave) * B * 8; word = RC_HA; need = t; }
+            // (training mode: h_a is the tape, slot t + 1 = after step t - no ring, nothing is overwritten)
+            if (ATT) { xsrc = p.h_a + (long)(TR ? t : t % RS_HA_SLOTS) * RS_A * B + (long)(16 * wave) * B * 8; word = RC_HA; need = t; }
             else if (ARD && sub == 0) { xsrc = p.hc + (long)t * B * (RS_D + RS_E) + (long)(16 * wave) * B * 8; word = RC_HD; need = t; }
             else if (ARD) { xsrc = p.h_a + (long)((t + 1) % RS_HA_SLOTS) * RS_A * B + (long)(16 * wave) * B * 8; word = RC_HA; need = t + 1; }
-            else if (wave < 4) { xsrc = p.h_a + (long)((t + 1) % RS_HA_SLOTS) * RS_A * B + (long)(32 * wave) * B * 8; word = RC_HA; need = t + 1; }
+            else if (wave < 4) { xsrc = p.h_a + (long)(TR ? t + 1 : (t + 1) % RS_HA_SLOTS) * RS_A * B + (long)(32 * wave) * B * 8; word = RC_HA; need = t + 1; }
             else { xsrc = p.hc + (long)t * B * (RS_D + RS_E) + (long)(32 * (wave - 4)) * B * 8; word = RC_HD; need = t; }
             rs_gate(ctrl, word, need, poll, lane);
             if (sub == NSUB - 1) { RS_STAMP(1); RS_WGSTAMP(1); }
@@ -690,6 +698,17 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                 const float p0 = s2[0] + add4.x, p1 = s2[1] + add4.y, p2 = s2[2] + add4.z, p3 = s2[3] + add4.w;
                 c_state = sigmoidf_(p1) * c_state + sigmoidf_(p0) * tanhf_(p2);
                 hval = sigmoidf_(p3) * tanhf_(c_state);
+                if (TR) {   // the tape (skinny.hip's cell epilogue): pre-activations, the new cell state, dropout on the output
+                    // (the pointers from the kernel-argument segment at the point of use - as arguments they sat in scalar registers
+                    // for the whole loop and pushed others out; per-step bases are uniform, the lane's part is a 32-bit index)
+                    RsKarg kq = (RsKarg)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(kq));
+                    const unsigned u = (unsigned)eb2 * (unsigned)H + (unsigned)(xt * 8 + 4 * xhalf + eg2);
+                    const long tb = (long)t * B * H;
+                    reinterpret_cast<float4*>(kq->tr_pre_a + tb * 4)[u] = make_float4(p0, p1, p2, p3);
+                    (kq->tr_c_a + tb + (long)B * H)[u] = c_state;
+                    hval = (kq->tr_keep_a + tb)[u] ? hval * kq->tr_scale_a : 0.f;
+                }
             }
             hs2[eb2 * 4 + eg2] = hval;
         }
@@ -724,6 +743,15 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                     const float p0 = s[0] + add4.x, p1 = s[1] + add4.y, p2 = s[2] + add4.z, p3 = s[3] + add4.w;
                     c_state = sigmoidf_(p1) * c_state + sigmoidf_(p0) * tanhf_(p2);
                     hval = sigmoidf_(p3) * tanhf_(c_state);
+                    if (TR) {
+                        RsKarg kq = (RsKarg)__builtin_amdgcn_kernarg_segment_ptr();
+                        asm volatile("" : "+s"(kq));
+                        const unsigned u = (unsigned)ebl * (unsigned)H + (unsigned)((tile + (RT == 2 ? ph : 0)) * 8 + 2 * g + eh);
+                        const long tb = (long)t * B * H;
+                        reinterpret_cast<float4*>((ATT ? kq->tr_pre_a : kq->tr_pre_d) + tb * 4)[u] = make_float4(p0, p1, p2, p3);
+                        ((ATT ? kq->tr_c_a : kq->tr_c_d) + tb + (long)B * H)[u] = c_state;
+                        hval = ((ATT ? kq->tr_keep_a : kq->tr_keep_d) + tb)[u] ? hval * (ATT ? kq->tr_scale_a : kq->tr_scale_d) : 0.f;
+                    }
                 }
                 hs[(ebl * RT + ph) * 8 + 2 * g + eh] = hval;
             }
@@ -732,7 +760,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         RS_STAMP(6);
 
         // ---- publication: h' as 16-byte write-through pieces, the query slab (attention LSTM), then the workgroup's flag
-        float* hdst = ATT ? p.h_a + (long)((t + 1) % RS_HA_SLOTS) * RS_A * B : p.hc + (long)(t + 1) * B * (RS_D + RS_E);
+        float* hdst = ATT ? p.h_a + (long)(TR ? t + 1 : (t + 1) % RS_HA_SLOTS) * RS_A * B : p.hc + (long)(t + 1) * B * (RS_D + RS_E);
         if (slab_wave) {
             // slab[b][d] = sum_j h'[b][j] Wq[d][j] over the workgroup's 8 (12) hidden units, attention dims 32 wave .. + 31 (skinny.hip)
             f32x16 qa;
@@ -824,6 +852,21 @@ __global__ __launch_bounds__(RS_THREADS) void decoder_resident_kernel(RsArgs p) 
     else rs_body<3, false>(p, rs_smem, bid);
 }
 
+// Training-mode forward of the same loop (models/tts/tacotron2.py:341, :358 under .train()): dropout on both cells' outputs with the
+// caller's keep masks, and the tape of back-propagation through time written by the cell epilogues (RsArgs::tr_*).
+__global__ __launch_bounds__(RS_THREADS) void decoder_resident_train_kernel(RsArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+    const int bid = (int)blockIdx.x;
+    const int kind = p.layout == 2 ? (bid < 64 ? 3 : 2) : (bid < 64 ? 0 : (bid < 96 ? 1 : 2));
+    const int off_ctrl = kind == 0 ? RsCfg<0>::OFF_CTRL : (kind == 1 ? RsCfg<1>::OFF_CTRL : (kind == 2 ? RsCfg<2>::OFF_CTRL : RsCfg<3>::OFF_CTRL));
+    if (threadIdx.x < 64) reinterpret_cast<int*>(rs_smem + off_ctrl)[threadIdx.x] = 0;
+    __syncthreads();
+    if (kind == 0) rs_body<0, false, true>(p, rs_smem, bid);
+    else if (kind == 1) rs_body<1, false, true>(p, rs_smem, bid);
+    else if (kind == 2) rs_body<2, false, true>(p, rs_smem, bid);
+    else rs_body<3, false, true>(p, rs_smem, bid);
+}
+
 // Autoregressive decode (models/tts/tacotron2.py:390-413 Decoder.inference): the same engine in the 224-workgroup deal, ONE launch
 // for the whole decode.  The frame of step t feeds step t + 1, so both cells are on the step's chain:
 //   attention LSTM (t): h_a(t-1) and ctx(t-1) columns early, the Prenet columns when prenet(t) arrives     -> h_a(t), query slabs
@@ -860,6 +903,8 @@ hipError_t read_wg_stamps_resident(unsigned long long* host896) {
 hipError_t decoder_resident_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_resident_train_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_ar_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
 }
 
@@ -874,7 +919,15 @@ hipError_t launch_decoder_resident(const DecResidentParams& p, hipStream_t s) {
     a.att_frag = p.att_frag; a.att_bias = p.att_bias; a.wq_t = p.wq_t; a.dec_frag = p.dec_frag; a.dec_bias = p.dec_bias;
     a.pre_gate = p.pre_gate; a.h_a = p.h_a; a.hc = p.hc; a.q_slab = p.q_slab; a.c_a = p.c_a; a.c_d = p.c_d; a.sync = p.sync;
     a.att_frag_bytes = p.att_frag_bytes; a.B = p.B; a.T = p.T; a.spin_limit = p.spin_limit; a.debug = p.debug; a.layout = p.layout;
-    decoder_resident_kernel<<<dim3(p.layout == 2 ? 192 : 224), dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
+    const dim3 grid(p.layout == 2 ? 192 : 224);
+    if (p.tr_keep_a) {   // training mode: every tape pointer, or none
+        if (!p.tr_keep_d || !p.tr_c_a || !p.tr_c_d || !p.tr_pre_a || !p.tr_pre_d) return hipErrorInvalidValue;
+        a.tr_keep_a = p.tr_keep_a; a.tr_keep_d = p.tr_keep_d; a.tr_c_a = p.tr_c_a; a.tr_c_d = p.tr_c_d; a.tr_pre_a = p.tr_pre_a; a.tr_pre_d = p.tr_pre_d;
+        a.tr_scale_a = p.tr_scale_a; a.tr_scale_d = p.tr_scale_d;
+        decoder_resident_train_kernel<<<grid, dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
+    } else {
+        decoder_resident_kernel<<<grid, dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
+    }
     return hipGetLastError();
 }
 

@@ -160,6 +160,7 @@ struct gvx_model {
                                        // wait of the loop runs into its limit (test of the time-out reporting only)
     hipStream_t pa_stream = nullptr;
     hipEvent_t pa_fork = nullptr, pa_join = nullptr, enc_mid = nullptr;
+    bool train_resident_loop = true;   // GVX_TRAIN_RESIDENT_LOOP=0: the training forward's decoder loop as a launch per step
     int enc_fork_after = 1;      // GVX_ENC_FORK_AFTER=<n>: the caller's Prenet products start behind n encoder convolutions
     // autoregressive loop: the all-rows-finished counter of chunk k is read (pinned slot k & 1, event k & 1) while chunk k + 1 runs
     int32_t* ar_done_host = nullptr;
@@ -458,6 +459,7 @@ int gvx_model_create(const gvx_dims* dims, gvx_model** out) {
     if (const char* e = std::getenv("GVX_AR_SPLIT_H")) m->ar_split_h = e[0] != '0';
     if (const char* e = std::getenv("GVX_ENC_PERSISTENT")) m->enc_persistent = e[0] != '0';
     if (const char* e = std::getenv("GVX_ENC_FORK_AFTER")) m->enc_fork_after = std::atoi(e);
+    if (const char* e = std::getenv("GVX_TRAIN_RESIDENT_LOOP")) m->train_resident_loop = e[0] != '0';
     if (const char* e = std::getenv("GVX_TF_ROWS64")) m->tf_rows64 = e[0] == '1';
     if (const char* e = std::getenv("GVX_TF_RESIDENT")) m->tf_resident = e[0] != '0';
     if (const char* e = std::getenv("GVX_AR_RESIDENT_LOOP")) m->ar_resident_loop = e[0] != '0';
@@ -849,8 +851,8 @@ int encoder_impl(gvx_model* m, const int64_t* tokens, const int32_t* lengths, in
             float* t = cur; cur = nxt; nxt = t;
         }
     }
-    // (behind the convolutions, in front of the input projection: the caller's other dense products then end together with the
-    // recurrence - measured: encoder stage 1.37 ms with the event behind the projection, 1.32 ms here)
+    // (the fork event of the caller's other dense products, if the convolution loop has not recorded it: training mode, or
+    // GVX_ENC_FORK_AFTER >= the number of convolutions)
     if (dense_done) HIP_TRY(hipEventRecord(dense_done, s));
     {   // LSTM input projection for both directions: xg[b][l][dir*4H + 4j+gate]
         GemmParams g{};
@@ -1195,7 +1197,12 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
                                                                // workgroups); 3: 33 .. 64 rows (64 CUs, 384 workgroups, two per CU)
     unsigned* sync = ws_ptr<unsigned>(ws, wp.sync);
     // ... and the LSTM launches as ONE resident kernel too (dec_resident.hip): inference mode, one batch tile, L <= 128
-    const bool resident = pa && (pa_layout == 1 || pa_layout == 2) && m->tf_resident && !train && decoder_resident_supported(B, L);
+    // (training mode: the same kernel with the tape in its cell epilogues, when the caller asks for the whole tape;
+    // GVX_TRAIN_RESIDENT_LOOP=0 keeps the launch per step)
+    const bool train_resident_loop = m->train_resident_loop;
+    const bool tape_whole = train && train->h_a_all && train->c_a_all && train->c_d_all && train->pre_a_all && train->pre_d_all;
+    const bool resident = pa && (pa_layout == 1 || pa_layout == 2) && m->tf_resident && (!train || (train_resident_loop && tape_whole)) &&
+                          decoder_resident_supported(B, L);
     // the resident tile kernel's deal: 224 workgroups beside <= 32 attention workgroups - rows of 129-256 tokens take two each, so
     // up to 16 such rows keep the 224-workgroup deal (its 48-row workgroups are lighter than the pairs of the 192-workgroup one:
     // 15.4 vs 17.3 us per step at 16 x L = 190; not at B <= 2, where the products run on the vector ALUs and the 64 slabs of the
@@ -1370,6 +1377,11 @@ int decoder_tf_impl(gvx_model* m, const float* memory, const int32_t* lengths, i
         rp.att_frag = m->dev_blob + m->blob.att_frag; rp.att_bias = m->dev_blob + m->blob.att_bias; rp.wq_t = m->dev_blob + m->blob.wq_t;
         rp.dec_frag = m->dev_blob + m->blob.dec_frag; rp.dec_bias = m->dev_blob + m->blob.dec_bias;
         rp.pre_gate = db.pre_gate; rp.h_a = db.h_a; rp.hc = db.hc; rp.q_slab = db.q_slab; rp.c_a = db.c_a; rp.c_d = db.c_d;
+        if (train) {
+            rp.h_a = train->h_a_all;
+            rp.tr_keep_a = train->att_keep; rp.tr_keep_d = train->dec_keep; rp.tr_scale_a = train->att_scale; rp.tr_scale_d = train->dec_scale;
+            rp.tr_c_a = train->c_a_all; rp.tr_c_d = train->c_d_all; rp.tr_pre_a = train->pre_a_all; rp.tr_pre_d = train->pre_d_all;
+        }
         rp.sync = sync;
         rp.att_frag_bytes = (unsigned)(frag_floats(4 * d.att_rnn_dim, P + E + d.att_rnn_dim) * sizeof(float));
         rp.dec_frag_bytes = (unsigned)(frag_floats(4 * D, d.att_rnn_dim + E + D) * sizeof(float));
@@ -1722,9 +1734,10 @@ int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* to
         if (rc != GVX_OK) return rc;
         HIP_TRY(hipEventRecord(m->pa_fork, s));
         HIP_TRY(hipStreamWaitEvent(m->pa_stream, m->pa_fork, 0));
-        // The Prenet products start when the encoder's convolutions (~0.35 ms with the chip to themselves) are through: side by
-        // side from the start, the two sets of GEMMs only slowed each other 3x and left the second half of the recurrence - a
-        // quarter of the chip, latency bound - alone on an idle GPU (kernel timeline, tools/kernel_timeline.py, round 3)
+        // The Prenet products start behind the FIRST encoder convolution (enc_fork_after): side by side from the start the two sets
+        // of GEMMs slow each other and leave the second half of the recurrence - a quarter of the chip, latency bound - alone on
+        // an idle GPU; behind all three convolutions the `pre_gate` GEMM outlasts the recurrence (encoder stage 1.335 / 1.31 / 1.28 /
+        // 1.335 ms for the fork behind 3 / 2 / 1 / 0 convolutions, tools/r4_enc2.sh)
         rc = encoder_impl(m, tokens, token_lengths, B, L, memory, ws, wp, m->pa_stream, nullptr, nullptr, nullptr, m->enc_mid);
         if (rc != GVX_OK) return rc;
         // the decoder's zero states and the memory projection (needs the encoder output) right behind the encoder on its stream:

@@ -283,6 +283,11 @@ struct DecResidentParams {
     int debug;                      // timing experiments only (GVX_RS_DEBUG: sleeps between polls)
     int layout;                     // 1: 224 workgroups beside one attention workgroup per row (L <= 128); 2: 192 workgroups - 64 pairs of
                                     // attention-LSTM tiles + 128 decoder-LSTM tiles - beside two per row (128 < L <= 256)
+    // training mode (all or none): keep masks of the dropout on both cells' outputs [T][B][H] and their scales 1 / (1 - p), the
+    // tape - cell states [T+1][B][H] (slot 0 given), gate pre-activations [T][B][H][4]; h_a is then the tape of the (dropped)
+    // hidden states [T+1][A/8][B][8] (slot 0 given) instead of the ring
+    const uint8_t* tr_keep_a; const uint8_t* tr_keep_d; float tr_scale_a, tr_scale_d;
+    float* tr_c_a; float* tr_c_d; float* tr_pre_a; float* tr_pre_d;
 };
 // Autoregressive decode as ONE launch of the same weight-stationary engine (224-workgroup deal) beside the resident attention
 // kernel, which also reduces the projection slabs, tests the stop condition and runs Prenet layer 1 (attn_persist.hip, AR role).

@@ -90,6 +90,8 @@ SIGNATURES = {
     "gvx_train_decoder_bptt": (_i, [C.POINTER(gvx_bptt_decoder_args), _vp, _sz, _vp]),
     "gvx_train_encoder_lstm_bptt_workspace_bytes": (_sz, [_i, _i]),
     "gvx_train_encoder_lstm_bptt": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_train_encoder_lstm_bptt_resident": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "gvx_train_encoder_lstm_bptt_status": (_i, [_vp, _sz, _i, _i, C.POINTER(_i), _vp]),
     "gvx_prenet_masks_generate": (_i, [_vp, _sz, C.c_uint64, _vp]),
     "gvx_stage_timing_enable": (_i, [_vp, _i]),
     "gvx_stage_times_ms": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),

@@ -13,6 +13,7 @@
 #include "../../include/genvox_amd.h"
 #include "gvx_kernels.h"
 #include <cmath>
+#include <cstdlib>
 
 #include <cstdio>
 #include <cstring>
@@ -451,21 +452,42 @@ __global__ void unblock_kernel(const float* src, float* dst, long n_slots, int B
     }
 }
 // d embedding[row][e] = sum over the batch positions that hold token `row`, added in position order (no atomics: the result
-// does not depend on the launch's scheduling).  One workgroup per table row, threads over the channels.
+// does not depend on the launch's scheduling).  One workgroup per table row, threads over the channels.  The positions that hold
+// the row's token are first compacted, in order, into LDS (chunks of EMB_CHUNK tokens: every thread looks at a contiguous
+// segment, an exclusive scan over the threads places its matches) - walking all positions one by one, as the first version
+// did, took 0.32 ms for 4096 positions; the sums themselves then run over ~1 % of them with independent loads.
+constexpr int EMB_CHUNK = 8192;
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* tokens, const float* dx, long n_tok, int E, int n_rows, float* demb) {
-    const int row = blockIdx.x;
-    for (int e0 = threadIdx.x; e0 < E; e0 += 4 * 256) {
+    __shared__ int list[EMB_CHUNK];
+    __shared__ int cnt[257];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    for (int pass = 0; pass * 1024 < E; ++pass) {   // (E <= 1024: one pass; every thread takes part in the barriers of every pass)
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        const int e1 = e0 + 256, e2 = e0 + 512, e3 = e0 + 768;
-        for (long t = 0; t < n_tok; ++t) {
-            if (tokens[t] != row) continue;   // (uniform across the workgroup)
-            const float* r = dx + t * E;
-            a0 += r[e0];
-            if (e1 < E) a1 += r[e1];
-            if (e2 < E) a2 += r[e2];
-            if (e3 < E) a3 += r[e3];
+        const int e0 = pass * 1024 + tid, e1 = e0 + 256, e2 = e0 + 512, e3 = e0 + 768;
+        for (long base = 0; base < n_tok; base += EMB_CHUNK) {
+            const int n = (int)((n_tok - base) < EMB_CHUNK ? (n_tok - base) : EMB_CHUNK), seg = (n + 255) / 256;
+            const int lo = tid * seg, hi = lo + seg < n ? lo + seg : n;
+            int mine = 0;
+            for (int t = lo; t < hi; ++t) mine += tokens[base + t] == row;
+            __syncthreads();   // (the list of the previous chunk / pass has been consumed)
+            cnt[tid + 1] = mine;
+            if (tid == 0) cnt[0] = 0;
+            __syncthreads();
+            if (tid == 0) for (int i = 1; i <= 256; ++i) cnt[i] += cnt[i - 1];
+            __syncthreads();
+            int at = cnt[tid];
+            for (int t = lo; t < hi; ++t) if (tokens[base + t] == row) list[at++] = t;
+            __syncthreads();
+            const int m = cnt[256];
+            for (int k = 0; k < m; ++k) {   // position order; the loads of later positions do not wait for the adds
+                const float* r = dx + (base + list[k]) * E;
+                if (e0 < E) a0 += r[e0];
+                if (e1 < E) a1 += r[e1];
+                if (e2 < E) a2 += r[e2];
+                if (e3 < E) a3 += r[e3];
+            }
         }
-        demb[(long)row * E + e0] = a0;
+        if (e0 < E) demb[(long)row * E + e0] = a0;
         if (e1 < E) demb[(long)row * E + e1] = a1;
         if (e2 < E) demb[(long)row * E + e2] = a2;
         if (e3 < E) demb[(long)row * E + e3] = a3;
@@ -491,12 +513,15 @@ __global__ __launch_bounds__(256) void sqnorm_many_kernel(const gvx_tensor_ref* 
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) partials[(long)blockIdx.y * SQN_BLOCKS + blockIdx.x] = red[0];
 }
-__global__ void sqnorm_finish_kernel(const double* partials, int n, double* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += partials[i];
-        out[0] = s;
-    }
+__global__ __launch_bounds__(256) void sqnorm_finish_kernel(const double* partials, int n, double* out) {
+    // 256 strided sums, then a tree: a fixed order (one thread walking all ~6 000 partials took 0.2 ms)
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = red[0];
 }
 // torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected), gradient pre-scaled by gscale (clipping),
 // for MANY tensors in one launch: workgroup (x, tensor) walks its share of the tensor
@@ -591,7 +616,7 @@ int gvx_train_embedding_backward(const int64_t* tokens, const float* dx, long n_
 int gvx_train_sqnorm_many(const gvx_tensor_ref* refs_device, int n_tensors, double* scratch, double* sumsq_out, void* stream) {
     if (!refs_device || !scratch || !sumsq_out || n_tensors < 1) return tfail(GVX_ERR_INVALID_ARG, "sqnorm_many: bad argument");
     hipLaunchKernelGGL(sqnorm_many_kernel, dim3(SQN_BLOCKS, n_tensors), dim3(256), 0, (hipStream_t)stream, refs_device, scratch);
-    hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, SQN_BLOCKS * n_tensors, sumsq_out);
+    hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, SQN_BLOCKS * n_tensors, sumsq_out);
     TR_TRY(hipGetLastError());
     return GVX_OK;
 }
@@ -1206,8 +1231,8 @@ int gvx_train_decoder_bptt(const gvx_bptt_decoder_args* ap, void* workspace, siz
 }  // extern "C"
 
 // =====================================================================================================================
-// Back-propagation through the encoder BiLSTM in one call (gvx_train_encoder_lstm_bptt): one launch per time step for both
-// directions, packed-sequence semantics as in the forward (a row takes part in step s while s < its length; the reverse
+// Back-propagation through the encoder BiLSTM in one call (gvx_train_encoder_lstm_bptt: one launch per time step for both
+// directions; gvx_train_encoder_lstm_bptt_resident: the same walk as ONE resident launch), packed-sequence semantics as in the forward (a row takes part in step s while s < its length; the reverse
 // direction walks each row from its own last token).  Workgroup = (4 hidden units, direction); thread = (batch row, lane
 // r of 8) - the 8 lanes of a row split the K of every dot product and combine with DPP-free shuffles.  Launch s first
 // finishes dh(s) = dgates(s + 1) W_hh + pass-through for its units (the previous launch wrote dgates(s + 1)), recomputes
@@ -1235,15 +1260,9 @@ struct EncBptt {
     int stamp;
 };
 
-__global__ __launch_bounds__(256) void encoder_bptt_step_kernel(EncBptt p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int H = p.H, H4 = 4 * H, L = p.L, B = p.B;
-    const int dir = blockIdx.y, j0 = blockIdx.x * EB_UJ, tid = threadIdx.x;
-    TR_STAMP(p.stamp, 1, 0);
-    const int r = tid & 7, b0 = tid >> 3;
-    const int len0 = b0 < B ? p.lengths[b0] : 0;   // (requested before the staging loads: the row's addresses depend on it)
-    float* wcol = sm;                    // [UJ][4H]  column j of W_hh = row j of its transpose
-    float* wrow = sm + EB_UJ * H4;       // [4][UJ][H] rows (q H + j) of W_hh
+// staging of a workgroup's weights (EB_UJ columns and 4 EB_UJ rows of W_hh) into LDS
+__device__ __forceinline__ void enc_bptt_stage(const EncBptt& p, float* sm, int dir, int j0, int tid) {
+    const int H = p.H, H4 = 4 * H;
     const float* whh = p.w_hh + (size_t)dir * H4 * H;
     const float* whht = p.w_hh_t + (size_t)dir * H * H4;
     // staging: rows of 4H / H floats are contiguous on both sides -> 16-byte pieces, all requested before the first LDS store
@@ -1272,25 +1291,39 @@ __global__ __launch_bounds__(256) void encoder_bptt_step_kernel(EncBptt p) {
         }
     }
     __syncthreads();
-    TR_STAMP(p.stamp, 1, 1);
+}
+
+// One time step of the walk for this workgroup's units.  RES: the step runs inside the resident kernel - the vectors other
+// workgroups wrote in the previous step of the same launch (dg_in) and this workgroup's own state words are read and written
+// write-through / past the L1 (sc1), as every handed-off byte of the resident loops is.
+template <bool RES>
+__device__ __forceinline__ void enc_bptt_step(const EncBptt& p, const float* sm, int dir, int j0, int tid) {
+    const int H = p.H, H4 = 4 * H, L = p.L, B = p.B;
+    const int r = tid & 7, b0 = tid >> 3;
+    const float* wcol = sm;                    // [UJ][4H]  column j of W_hh = row j of its transpose
+    const float* wrow = sm + EB_UJ * H4;       // [4][UJ][H] rows (q H + j) of W_hh
+    const __amdgpu_buffer_rsrc_t r_dgi = make_rsrc(p.dg_in), r_dgo = make_rsrc(p.dg_out), r_pi = make_rsrc(p.dpass_in),
+                                 r_po = make_rsrc(p.dpass_out), r_dc = make_rsrc(p.dc);
     // thread = (batch row, lane r of 8).  The 8 lanes of a row split K in float4 pieces: lane r takes the floats
     // 32 i + 4 r ... + 3, so that a row's 8 lanes read 128 contiguous bytes per instruction (global and LDS alike)
     const bool vec_h = (H & 31) == 0;
     for (int b = b0; b < B; b += 32) {
-        const int len = b == b0 ? len0 : p.lengths[b];
+        const int len = p.lengths[b];
         const bool active = p.s < len;
         const int t_idx = dir == 0 ? p.s : max(len - 1 - p.s, 0);
         const int p_idx = dir == 0 ? t_idx - 1 : t_idx + 1;
         const bool has_prev = active && p.s > 0;
         const float* hp = p.memory + ((size_t)b * L + min(max(p_idx, 0), L - 1)) * 2 * H + dir * H;
         const float* dgi = p.dg_in + ((size_t)dir * B + b) * H4;
+        const unsigned dgi_off = (unsigned)(((size_t)dir * B + b) * H4 * sizeof(float));
         // operands of the cell (lanes r < UJ own unit j0 + r): requested now, used after the dot products
         const int j = j0 + r;
         const bool own = r < EB_UJ && j < H;
         const size_t sj = ((size_t)dir * B + b) * H + (own ? j : 0);
         float o_pass = 0.f, o_dmem = 0.f, o_dc = 0.f, o_cp = 0.f, o_hp = 0.f, o_x0 = 0.f, o_x1 = 0.f, o_x2 = 0.f, o_x3 = 0.f;
         if (own) {
-            o_pass = p.dpass_in[sj]; o_dc = p.dc[sj];
+            if (RES) { o_pass = load_sc1_f32(r_pi, (unsigned)(sj * 4)); o_dc = load_sc1_f32(r_dc, (unsigned)(sj * 4)); }
+            else { o_pass = p.dpass_in[sj]; o_dc = p.dc[sj]; }
             if (active) {
                 o_dmem = p.dmemory[((size_t)b * L + t_idx) * 2 * H + dir * H + j];
                 const float* xg = p.xg + (((size_t)dir * B + b) * L + t_idx) * H4;
@@ -1305,7 +1338,9 @@ __global__ __launch_bounds__(256) void encoder_bptt_step_kernel(EncBptt p) {
         for (int ib = 0; ib < H4 / 32; ib += NX) {
             float4 x[NX];
 #pragma unroll
-            for (int u = 0; u < NX; ++u) x[u] = ib + u < H4 / 32 ? *reinterpret_cast<const float4*>(dgi + 32 * (ib + u) + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < NX; ++u)
+                x[u] = ib + u >= H4 / 32 ? make_float4(0.f, 0.f, 0.f, 0.f)
+                       : (RES ? load_sc1(r_dgi, dgi_off + (unsigned)(32 * (ib + u) + 4 * r) * 4u) : *reinterpret_cast<const float4*>(dgi + 32 * (ib + u) + 4 * r));
 #pragma unroll
             for (int u = 0; u < NX; ++u) {
                 if (ib + u < H4 / 32) {
@@ -1364,22 +1399,90 @@ __global__ __launch_bounds__(256) void encoder_bptt_step_kernel(EncBptt p) {
         if (own) {
             const float dh = my_dh + o_pass + o_dmem;
             float* dgo = p.dg_out + ((size_t)dir * B + b) * H4;
+            const unsigned dgo_off = (unsigned)((((size_t)dir * B + b) * H4 + j) * sizeof(float));
+            auto put = [&](float* ptr, __amdgpu_buffer_rsrc_t rs, unsigned off, float v) {
+                if (RES) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)off, 0, 16); else *ptr = v;
+            };
             if (!active) {
-                dgo[j] = dgo[H + j] = dgo[2 * H + j] = dgo[3 * H + j] = 0.f;
-                p.dpass_out[sj] = dh;   // (dc stays)
+                for (int q = 0; q < 4; ++q) put(dgo + q * H + j, r_dgo, dgo_off + (unsigned)(q * H) * 4u, 0.f);
+                put(p.dpass_out + sj, r_po, (unsigned)(sj * 4), dh);   // (dc stays)
             } else {
                 float gi, gf, gg, go, dcp;
                 lstm_cell_bwd_one(dh, o_dc, o_x0 + my_pre[0], o_x1 + my_pre[1], o_x2 + my_pre[2], o_x3 + my_pre[3], o_cp, gi, gf, gg, go, dcp);
-                p.dc[sj] = dcp;
-                p.dpass_out[sj] = 0.f;
-                dgo[j] = gi; dgo[H + j] = gf; dgo[2 * H + j] = gg; dgo[3 * H + j] = go;
+                put(p.dc + sj, r_dc, (unsigned)(sj * 4), dcp);
+                put(p.dpass_out + sj, r_po, (unsigned)(sj * 4), 0.f);
+                put(dgo + j, r_dgo, dgo_off, gi); put(dgo + H + j, r_dgo, dgo_off + (unsigned)H * 4u, gf);
+                put(dgo + 2 * H + j, r_dgo, dgo_off + (unsigned)(2 * H) * 4u, gg); put(dgo + 3 * H + j, r_dgo, dgo_off + (unsigned)(3 * H) * 4u, go);
                 float* dgp = p.dg_pos + (((size_t)dir * B + b) * L + t_idx) * H4;
                 dgp[j] = gi; dgp[H + j] = gf; dgp[2 * H + j] = gg; dgp[3 * H + j] = go;
                 p.hprev_pos[(((size_t)dir * B + b) * L + t_idx) * H + j] = o_hp;
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void encoder_bptt_step_kernel(EncBptt p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int dir = blockIdx.y, j0 = blockIdx.x * EB_UJ, tid = threadIdx.x;
+    TR_STAMP(p.stamp, 1, 0);
+    enc_bptt_stage(p, sm, dir, j0, tid);
+    TR_STAMP(p.stamp, 1, 1);
+    enc_bptt_step<false>(p, sm, dir, j0, tid);
     TR_STAMP(p.stamp, 1, 5);
+}
+
+// The whole walk as ONE resident launch (the launch per time step: 128 x 22 us for ~2 us of work each, and at the end of a
+// training step it runs alone on the GPU).  Same grid, same arithmetic in the same order; the weights are staged once; step s
+// starts when every workgroup of the direction has published step s + 1 (one flag word per workgroup, each on a 128-byte line
+// of its own, value = steps published; stores drained and a barrier in front of the flag, cdna_hip_programming.md guideline
+// 16).  Parity buffers as in the launch-per-step walk: step s writes what step s + 1's readers have left - they all published
+// s + 1 before anybody could start s.  Every wait is bounded: after a time-out all waits return at once, the grid drains and
+// the caller's last launch overwrites the outputs with NaN and raises the status word of the workspace.
+struct EncBpttRes {
+    EncBptt q;               // (s, dg_in / dg_out, dpass_in / dpass_out are set per step inside)
+    float* dg; float* dpass; // [2 parities][2][B][4H] / [2 parities][2][B][H]
+    unsigned* flags;         // [2][nwg] x 32 words
+    unsigned* tmo;           // the call's time-out word
+    unsigned spin_limit;
+    int nwg;                 // workgroups per direction
+    int debug_skip_block;    // tests: this workgroup leaves at once
+};
+__global__ __launch_bounds__(256) void encoder_bptt_resident_kernel(EncBpttRes a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int dir = blockIdx.y, j0 = blockIdx.x * EB_UJ, tid = threadIdx.x;
+    if ((int)(blockIdx.y * gridDim.x + blockIdx.x) == a.debug_skip_block) return;   // (uniform per workgroup)
+    EncBptt p = a.q;
+    enc_bptt_stage(p, sm, dir, j0, tid);
+    const int B = p.B, H = p.H, L = p.L;
+    const unsigned* fl = a.flags + (size_t)dir * a.nwg * 32;
+    const unsigned limit = (a.spin_limit ? a.spin_limit : HANDOFF_SPIN_LIMIT) * 16u;
+    for (int st = L - 1; st >= 0; --st) {
+        const int par = st & 1;
+        p.s = st;
+        p.dg_in = a.dg + (size_t)(par ^ 1) * 2 * B * 4 * H; p.dg_out = a.dg + (size_t)par * 2 * B * 4 * H;
+        p.dpass_in = a.dpass + (size_t)(par ^ 1) * 2 * B * H; p.dpass_out = a.dpass + (size_t)par * 2 * B * H;
+        if (st < L - 1) {   // everybody has published step st + 1 = (L - 1 - st) steps
+            if (tid < 64) {
+                const unsigned want = (unsigned)(L - 1 - st);
+                unsigned spins = 0;
+                while (true) {
+                    bool ok = true;
+                    for (int w = tid; w < a.nwg; w += 64) ok = ok && __hip_atomic_load(fl + (size_t)w * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+                    if (__all(ok)) break;
+                    if ((++spins & 127u) == 1u) {   // (after a time-out every wait gives up at its first look)
+                        if (__hip_atomic_load(a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                        if (spins > limit) { if (tid == 0) __hip_atomic_store(a.tmo, 0x600u + (unsigned)dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+        }
+        enc_bptt_step<true>(p, sm, dir, j0, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have left
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.flags + ((size_t)dir * a.nwg + blockIdx.x) * 32, (unsigned)(L - st), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // dst[d][c][r] = src[d][r][c]
@@ -1392,7 +1495,8 @@ __global__ void transpose_batched_kernel(const float* src, float* dst, int n, in
     }
 }
 
-struct EncBpttPlan { size_t wt, dg, dpass, dc, total; };
+struct EncBpttPlan { size_t wt, dg, dpass, dc, sync, total; };
+constexpr int EB_SYNC_STATUS = 0, EB_SYNC_TMO = 32, EB_SYNC_FLAGS = 64;   // words inside the sync region (a 128-byte line each)
 EncBpttPlan enc_bptt_plan(int B, int H) {
     EncBpttPlan p{};
     size_t o = 0;
@@ -1401,6 +1505,7 @@ EncBpttPlan enc_bptt_plan(int B, int H) {
     p.dg = take((size_t)2 * 2 * B * 4 * H);      // two parities
     p.dpass = take((size_t)2 * 2 * B * H);
     p.dc = take((size_t)2 * B * H);
+    p.sync = take((size_t)EB_SYNC_FLAGS + (size_t)2 * ((H + EB_UJ - 1) / EB_UJ) * 32);   // status word, time-out word, a flag line per workgroup
     p.total = o;
     return p;
 }
@@ -1415,9 +1520,9 @@ size_t gvx_train_encoder_lstm_bptt_workspace_bytes(int B, int H) {
     return enc_bptt_plan(B, H).total * sizeof(float);
 }
 
-int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const float* cell_states, const float* dmemory, const float* w_hh,
-                                const int32_t* lengths, int B, int L, int H, float* dg_pos, float* hprev_pos, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+static int encoder_lstm_bptt_impl(const float* xg, const float* memory, const float* cell_states, const float* dmemory, const float* w_hh,
+                                  const int32_t* lengths, int B, int L, int H, float* dg_pos, float* hprev_pos, void* workspace,
+                                  size_t workspace_bytes, void* stream, bool resident) {
     if (!xg || !memory || !cell_states || !dmemory || !w_hh || !lengths || !dg_pos || !hprev_pos || !workspace)
         return tfail(GVX_ERR_INVALID_ARG, "encoder_lstm_bptt: null argument");
     if (B < 1 || L < 1 || H < 8 || (H % 8)) return tfail(GVX_ERR_UNSUPPORTED, "encoder_lstm_bptt: B, L >= 1, H a positive multiple of 8");
@@ -1432,6 +1537,26 @@ int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const floa
     TR_TRY(hipMemsetAsync(ws + pl.dg, 0, (pl.total - pl.dg) * sizeof(float), s));
     TR_TRY(hipMemsetAsync(dg_pos, 0, (size_t)2 * B * L * 4 * H * sizeof(float), s));
     TR_TRY(hipMemsetAsync(hprev_pos, 0, (size_t)2 * B * L * H * sizeof(float), s));
+    // one resident launch for the whole walk where all its workgroups fit on the GPU at once (default layer size: 128 of 256 CUs)
+    const int nwg = (H + EB_UJ - 1) / EB_UJ;
+    if (resident && 2 * nwg <= 192 && lds <= 64 * 1024) {
+        TR_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_bptt_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        unsigned* sync = reinterpret_cast<unsigned*>(ws + pl.sync);
+        EncBpttRes a{};
+        a.q.B = B; a.q.L = L; a.q.H = H;
+        a.q.xg = xg; a.q.memory = memory; a.q.c_enc = cell_states; a.q.dmemory = dmemory; a.q.w_hh = w_hh; a.q.w_hh_t = ws + pl.wt; a.q.lengths = lengths;
+        a.q.dc = ws + pl.dc; a.q.dg_pos = dg_pos; a.q.hprev_pos = hprev_pos;
+        a.dg = ws + pl.dg; a.dpass = ws + pl.dpass; a.flags = sync + EB_SYNC_FLAGS; a.tmo = sync + EB_SYNC_TMO; a.nwg = nwg;
+        { const char* e = std::getenv("GVX_HANDOFF_SPIN_LIMIT"); a.spin_limit = e ? (unsigned)std::strtoul(e, nullptr, 10) : 0u; }
+        { const char* e = std::getenv("GVX_DEBUG_ENC_BPTT_SKIP_BLOCK"); a.debug_skip_block = e ? std::atoi(e) : -1; }   // (tests: forced time-out)
+        hipLaunchKernelGGL(encoder_bptt_resident_kernel, dim3(nwg, 2), dim3(256), lds, s, a);
+        // a hand-off that timed out must not look like a result: NaN over both outputs, the code into the workspace's status word
+        float* outs[2] = {dg_pos, hprev_pos};
+        const size_t counts[2] = {(size_t)2 * B * L * 4 * H, (size_t)2 * B * L * H};
+        TR_TRY(launch_poison_on_timeout(sync + EB_SYNC_TMO, reinterpret_cast<int*>(sync + EB_SYNC_STATUS), outs, counts, 2, s));
+        TR_TRY(hipGetLastError());
+        return GVX_OK;
+    }
     for (int st = L - 1; st >= 0; --st) {
         EncBptt q{};
         q.B = B; q.L = L; q.H = H; q.s = st;
@@ -1444,6 +1569,26 @@ int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const floa
         hipLaunchKernelGGL(encoder_bptt_step_kernel, dim3((H + EB_UJ - 1) / EB_UJ, 2), dim3(256), lds, s, q);
     }
     TR_TRY(hipGetLastError());
+    return GVX_OK;
+}
+
+int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const float* cell_states, const float* dmemory, const float* w_hh,
+                                const int32_t* lengths, int B, int L, int H, float* dg_pos, float* hprev_pos, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return encoder_lstm_bptt_impl(xg, memory, cell_states, dmemory, w_hh, lengths, B, L, H, dg_pos, hprev_pos, workspace, workspace_bytes, stream, false);
+}
+int gvx_train_encoder_lstm_bptt_resident(const float* xg, const float* memory, const float* cell_states, const float* dmemory, const float* w_hh,
+                                         const int32_t* lengths, int B, int L, int H, float* dg_pos, float* hprev_pos, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    return encoder_lstm_bptt_impl(xg, memory, cell_states, dmemory, w_hh, lengths, B, L, H, dg_pos, hprev_pos, workspace, workspace_bytes, stream, true);
+}
+int gvx_train_encoder_lstm_bptt_status(const void* workspace, size_t workspace_bytes, int B, int H, int* code_out, void* stream) {
+    if (!workspace || !code_out || B < 1 || H < 8) return tfail(GVX_ERR_INVALID_ARG, "encoder_lstm_bptt_status: bad argument");
+    const EncBpttPlan pl = enc_bptt_plan(B, H);
+    if (workspace_bytes < pl.total * sizeof(float)) return tfail(GVX_ERR_WORKSPACE, "encoder_lstm_bptt_status: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    TR_TRY(hipMemcpyAsync(code_out, reinterpret_cast<const float*>(workspace) + pl.sync + EB_SYNC_STATUS, sizeof(int), hipMemcpyDeviceToHost, s));
+    TR_TRY(hipStreamSynchronize(s));
     return GVX_OK;
 }
 

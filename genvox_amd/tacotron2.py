@@ -23,6 +23,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import math
+import warnings
 from typing import Dict, Optional
 
 import numpy as np
@@ -747,7 +748,7 @@ class Tacotron2(nn.Module):
         behind the C ABI; the formulas are pinned to the reference's loss.backward() through oracle/train_ref.py).  Fills
         ``loss_items`` and ``grad_norm_val`` like the reference.  Any batch size (the recurrent part runs in chunks of at most
         32 rows); both recurrences are walked back inside single C-ABI calls and the packed blob is re-built on the device:
-        31 ms per step at 32 x 200 frames, reproducible bit for bit (profiles/r03_train_step_timing.txt)."""
+        27 ms per step at 32 x 200 frames, reproducible bit for bit (profiles/r04_train_step_timing.txt)."""
         from . import training
 
         if optimizer is None:
@@ -761,8 +762,17 @@ class Tacotron2(nn.Module):
             # (a token id outside the table raised before the forward touched anything; a hand-off time-out was caught - and the
             # recurrent part re-run - before the Postnet's BatchNorm update; this is the last look before gradients reach the weights)
             self.check_status()
+            self._enc_bptt_workspaces = []
             grads = training.train_backward(self, batch, outputs, tape)
             self.grad_norm_val, scale = training.clip_grad_norm(grads, self.model_config.grad_clip_thresh)
+            if not math.isfinite(self.grad_norm_val) and training.encoder_bptt_timed_out(self):
+                # the resident walk of the encoder BiLSTM gave up on a hand-off (NaN gradients): from now on a launch per time
+                # step for this model, and the backward once more - nothing has touched the weights yet
+                warnings.warn("genvox_amd: the resident encoder-BiLSTM backward timed out; re-running the backward with a launch per time step")
+                self._enc_bptt_resident = False
+                grads = training.train_backward(self, batch, outputs, tape)
+                self.grad_norm_val, scale = training.clip_grad_norm(grads, self.model_config.grad_clip_thresh)
+            self._enc_bptt_workspaces = []
             optimizer["optimizer"].step(grads, scale)
             self._packed_key = None
             self.last_grads = grads   # (kept for inspection / tests; the reference keeps them in .grad)

@@ -401,8 +401,13 @@ def _recurrent_backward(model, ops: "_Ops", ch: dict, dmel: torch.Tensor, dgate:
     dg_pos, hprev_pos = torch.empty(2, B * L, 4 * H, device=dev), torch.empty(2, B * L, H, device=dev)
     wse = torch.empty(lib.gvx_train_encoder_lstm_bptt_workspace_bytes(B, H), dtype=torch.uint8, device=dev)
     tl32 = ch["token_lengths"].to(device=dev, dtype=torch.int32).contiguous()
-    _lib.check(lib.gvx_train_encoder_lstm_bptt(_p(xg), _p(memory.contiguous()), _p(c_enc.contiguous()), _p(dmemory.contiguous()), _p(w_hh2), _p(tl32),
-                                               B, L, H, _p(dg_pos), _p(hprev_pos), _p(wse), wse.numel(), st))
+    # (one resident launch for the whole walk unless the model has seen it time out: encoder_bptt_timed_out below)
+    walk = lib.gvx_train_encoder_lstm_bptt_resident if getattr(model, "_enc_bptt_resident", True) else lib.gvx_train_encoder_lstm_bptt
+    _lib.check(walk(_p(xg), _p(memory.contiguous()), _p(c_enc.contiguous()), _p(dmemory.contiguous()), _p(w_hh2), _p(tl32),
+                    B, L, H, _p(dg_pos), _p(hprev_pos), _p(wse), wse.numel(), st))
+    if not hasattr(model, "_enc_bptt_workspaces"):
+        model._enc_bptt_workspaces = []
+    model._enc_bptt_workspaces.append((wse, B, H))   # (kept until the step's gradients have been looked at)
     for d_, sfx in enumerate(sfxs):
         dg2 = dg_pos[d_]
         g["encoder.lstm.weight_ih_l0" + sfx] = ops.mm_tn(dg2, x.reshape(B * L, E))
@@ -451,6 +456,22 @@ def train_backward(model, batch: Dict[str, torch.Tensor], outputs: Dict[str, tor
     _lib.check(lib.gvx_train_embedding_backward(_p(tok), _p(dtok), B * L, E, demb.shape[0], _p(demb), st))
     g["embedding.weight"] = demb
     return g
+
+
+def encoder_bptt_timed_out(model) -> bool:
+    """True when a resident walk of the encoder BiLSTM (gvx_train_encoder_lstm_bptt_resident) of this step gave up on a hand-off -
+    its workgroups could not run at the same time; its outputs are NaN then.  Reads the status word of every workspace the step
+    used (one stream synchronisation each) and forgets them."""
+    import ctypes as C
+
+    lib = _lib.load()
+    hit = False
+    for wse, B, H in getattr(model, "_enc_bptt_workspaces", []):
+        code = C.c_int(0)
+        _lib.check(lib.gvx_train_encoder_lstm_bptt_status(_p(wse), wse.numel(), B, H, C.byref(code), torch.cuda.current_stream(wse.device).cuda_stream))
+        hit = hit or code.value != 0
+    model._enc_bptt_workspaces = []
+    return hit
 
 
 def _device_table(entries, dev) -> torch.Tensor:

@@ -356,6 +356,14 @@ size_t gvx_train_encoder_lstm_bptt_workspace_bytes(int B, int H);
 int gvx_train_encoder_lstm_bptt(const float* xg, const float* memory, const float* cell_states, const float* dmemory, const float* w_hh,
                                 const int32_t* lengths, int B, int L, int H, float* dg_pos, float* hprev_pos, void* workspace,
                                 size_t workspace_bytes, void* stream);
+/* The same walk as ONE resident launch (its workgroups hand the gate gradients of a step round through the workspace; shapes
+ * whose workgroups do not all fit on the GPU at once take the launch per step).  Bounded waits: after a time-out - the workgroups
+ * could not run at the same time - both outputs are NaN and the workspace's status word holds the code, which
+ * gvx_train_encoder_lstm_bptt_status reads (one stream synchronisation; 0 = fine). */
+int gvx_train_encoder_lstm_bptt_resident(const float* xg, const float* memory, const float* cell_states, const float* dmemory,
+                                         const float* w_hh, const int32_t* lengths, int B, int L, int H, float* dg_pos,
+                                         float* hprev_pos, void* workspace, size_t workspace_bytes, void* stream);
+int gvx_train_encoder_lstm_bptt_status(const void* workspace, size_t workspace_bytes, int B, int H, int* code_out, void* stream);
 
 /* ---- Prenet keep-mask generator for callers that do not supply masks (the reference draws them from
  * torch's RNG inside F.dropout, models/tts/tacotron2.py:143).  Writes n bytes of Bernoulli(0.5) {0,1}. */

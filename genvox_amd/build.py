@@ -54,6 +54,12 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(lib):
         run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib", "-o", lib])
+    if not stamps and not os.environ.get("GVX_LIB_NAME"):
+        # a diagnostic variant older than the C ABI's header no longer exports what _lib.py binds (tools/stamps*.py would fail with an
+        # AttributeError at load): better gone than stale - `python -m genvox_amd.build --stamps` makes it again
+        variant = LIB.replace(".so", "_stamps.so")
+        if os.path.exists(variant) and os.path.getmtime(variant) < os.path.getmtime(headers[-1]):
+            os.remove(variant)
     return lib
 
 

@@ -838,33 +838,48 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
     if (cell2_wave && b2 < B) c_mem[(long)b2 * H + j2] = c_state;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void decoder_resident_kernel(RsArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+// One kernel per deal: with all four workgroup kinds behind one run-time branch the register allocation of the kernel was
+// the union of their needs (49 scalar registers spilled into vector lanes in the 224-workgroup deal's kinds, which the
+// 192-workgroup deal's pairs of tiles had pushed out).
+template <bool TR>
+__device__ __forceinline__ void rs_kernel_224(const RsArgs& p, char* rs_smem) {
     const int bid = (int)blockIdx.x;
-    // kind of this workgroup: 224-workgroup deal 0 / 1 / 2, 192-workgroup deal 3 / 2      (uniform per workgroup)
-    const int kind = p.layout == 2 ? (bid < 64 ? 3 : 2) : (bid < 64 ? 0 : (bid < 96 ? 1 : 2));
-    const int off_ctrl = kind == 0 ? RsCfg<0>::OFF_CTRL : (kind == 1 ? RsCfg<1>::OFF_CTRL : (kind == 2 ? RsCfg<2>::OFF_CTRL : RsCfg<3>::OFF_CTRL));
+    const int kind = bid < 64 ? 0 : (bid < 96 ? 1 : 2);   // (uniform per workgroup)
+    const int off_ctrl = kind == 0 ? RsCfg<0>::OFF_CTRL : (kind == 1 ? RsCfg<1>::OFF_CTRL : RsCfg<2>::OFF_CTRL);
     if (threadIdx.x < 64) reinterpret_cast<int*>(rs_smem + off_ctrl)[threadIdx.x] = 0;
     __syncthreads();
-    if (kind == 0) rs_body<0, false>(p, rs_smem, bid);
-    else if (kind == 1) rs_body<1, false>(p, rs_smem, bid);
-    else if (kind == 2) rs_body<2, false>(p, rs_smem, bid);
-    else rs_body<3, false>(p, rs_smem, bid);
+    if (kind == 0) rs_body<0, false, TR>(p, rs_smem, bid);
+    else if (kind == 1) rs_body<1, false, TR>(p, rs_smem, bid);
+    else rs_body<2, false, TR>(p, rs_smem, bid);
+}
+template <bool TR>
+__device__ __forceinline__ void rs_kernel_192(const RsArgs& p, char* rs_smem) {
+    const int bid = (int)blockIdx.x;
+    const int kind = bid < 64 ? 3 : 2;
+    const int off_ctrl = kind == 3 ? RsCfg<3>::OFF_CTRL : RsCfg<2>::OFF_CTRL;
+    if (threadIdx.x < 64) reinterpret_cast<int*>(rs_smem + off_ctrl)[threadIdx.x] = 0;
+    __syncthreads();
+    if (kind == 3) rs_body<3, false, TR>(p, rs_smem, bid);
+    else rs_body<2, false, TR>(p, rs_smem, bid);
+}
+__global__ __launch_bounds__(RS_THREADS) void decoder_resident_kernel(RsArgs p) {   // the 224-workgroup deal (p.layout == 1)
+    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+    rs_kernel_224<false>(p, rs_smem);
+}
+__global__ __launch_bounds__(RS_THREADS) void decoder_resident_pairs_kernel(RsArgs p) {   // the 192-workgroup deal (p.layout == 2)
+    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+    rs_kernel_192<false>(p, rs_smem);
 }
 
 // Training-mode forward of the same loop (models/tts/tacotron2.py:341, :358 under .train()): dropout on both cells' outputs with the
 // caller's keep masks, and the tape of back-propagation through time written by the cell epilogues (RsArgs::tr_*).
 __global__ __launch_bounds__(RS_THREADS) void decoder_resident_train_kernel(RsArgs p) {
     extern __shared__ __attribute__((aligned(16))) char rs_smem[];
-    const int bid = (int)blockIdx.x;
-    const int kind = p.layout == 2 ? (bid < 64 ? 3 : 2) : (bid < 64 ? 0 : (bid < 96 ? 1 : 2));
-    const int off_ctrl = kind == 0 ? RsCfg<0>::OFF_CTRL : (kind == 1 ? RsCfg<1>::OFF_CTRL : (kind == 2 ? RsCfg<2>::OFF_CTRL : RsCfg<3>::OFF_CTRL));
-    if (threadIdx.x < 64) reinterpret_cast<int*>(rs_smem + off_ctrl)[threadIdx.x] = 0;
-    __syncthreads();
-    if (kind == 0) rs_body<0, false, true>(p, rs_smem, bid);
-    else if (kind == 1) rs_body<1, false, true>(p, rs_smem, bid);
-    else if (kind == 2) rs_body<2, false, true>(p, rs_smem, bid);
-    else rs_body<3, false, true>(p, rs_smem, bid);
+    rs_kernel_224<true>(p, rs_smem);
+}
+__global__ __launch_bounds__(RS_THREADS) void decoder_resident_train_pairs_kernel(RsArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+    rs_kernel_192<true>(p, rs_smem);
 }
 
 // Autoregressive decode (models/tts/tacotron2.py:390-413 Decoder.inference): the same engine in the 224-workgroup deal, ONE launch
@@ -903,8 +918,9 @@ hipError_t read_wg_stamps_resident(unsigned long long* host896) {
 hipError_t decoder_resident_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_resident_train_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
-    if (e != hipSuccess) return e;
+    for (const void* k : {reinterpret_cast<const void*>(decoder_resident_train_kernel), reinterpret_cast<const void*>(decoder_resident_pairs_kernel),
+                          reinterpret_cast<const void*>(decoder_resident_train_pairs_kernel)})
+        if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES)) != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_ar_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
 }
 
@@ -924,7 +940,10 @@ hipError_t launch_decoder_resident(const DecResidentParams& p, hipStream_t s) {
         if (!p.tr_keep_d || !p.tr_c_a || !p.tr_c_d || !p.tr_pre_a || !p.tr_pre_d) return hipErrorInvalidValue;
         a.tr_keep_a = p.tr_keep_a; a.tr_keep_d = p.tr_keep_d; a.tr_c_a = p.tr_c_a; a.tr_c_d = p.tr_c_d; a.tr_pre_a = p.tr_pre_a; a.tr_pre_d = p.tr_pre_d;
         a.tr_scale_a = p.tr_scale_a; a.tr_scale_d = p.tr_scale_d;
-        decoder_resident_train_kernel<<<grid, dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
+        if (p.layout == 2) decoder_resident_train_pairs_kernel<<<grid, dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
+        else decoder_resident_train_kernel<<<grid, dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
+    } else if (p.layout == 2) {
+        decoder_resident_pairs_kernel<<<grid, dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
     } else {
         decoder_resident_kernel<<<grid, dim3(RS_THREADS), RS_LDS_BYTES, s>>>(a);
     }

@@ -266,7 +266,7 @@ template <bool B> struct RsBool { static constexpr bool value = B; };
 
 typedef const __attribute__((address_space(4))) RsArgs* RsKarg;   // the kernel-argument segment (the kernels' only parameter)
 
-template <int KIND, bool AR, bool TR = false>
+template <int KIND, bool AR, bool TR = false, bool KA = AR>
 __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int bid) {
     static_assert(!(AR && TR), "the tape belongs to the teacher-forced loop");
     using Cfg = RsCfg<KIND>;
@@ -396,6 +396,10 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
     for (int t = 0; t < T; ++t) {
         RS_STAMP(0);
         RS_WGSTAMP(0);
+        // (the autoregressive loop's own arguments are read from the kernel-argument segment where they are used: as arguments they
+        // sat in scalar registers for the whole loop and were spilled into vector lanes around the step's products)
+        RsKarg ka = nullptr;
+        if (KA) { ka = (RsKarg)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(ka)); }
         // ---- the step's addend (attention LSTM: the Prenet columns, applied to all steps before the loop): its round trip hides
         // under the products
         // (teacher-forced loop) the waves that will store h_a(t) into ring slot (t + 1) % RS make sure NOW that the slot's last reader,
@@ -435,7 +439,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         auto prenet_part = [&]() __attribute__((always_inline)) {
             rs_gate(ctrl, RC_PRE, t, poll, lane);
             RS_ARSTAMP(2);
-            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.prenet + (long)(4 * wave) * B * 8);
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(ka->prenet + (long)(4 * wave) * B * 8);
             float4 xp[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) xp[u] = load_sc1(rx, x_lane + (unsigned)u * blkb);
@@ -551,16 +555,16 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
             if (l2_wg && t >= 1) {
                 // (this lane's keep bytes of layer 2's dropout: requested before the wait, their round trip is off the chain)
                 unsigned km = 0;
-                if (wave < 4 && bl < B) km = *reinterpret_cast<const unsigned*>(p.keep1 + ((long)t * B + bl) * RS_P + 32 * (bid - 64) + 8 * wave + 4 * h);
+                if (wave < 4 && bl < B) km = *reinterpret_cast<const unsigned*>(ka->keep1 + ((long)t * B + bl) * RS_P + 32 * (bid - 64) + 8 * wave + 4 * h);
                 rs_gate(ctrl, RC_Y1, t, poll, lane);
                 RS_ARSTAMP(0);
-                const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y1 + (long)(4 * wave) * B * 8);
+                const __amdgpu_buffer_rsrc_t ry = make_rsrc(ka->y1 + (long)(4 * wave) * B * 8);
                 float4 xy[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) xy[u] = load_sc1(ry, x_lane + (unsigned)u * blkb);
                 // every row has run the stop test of step t - 1: when all have fired, the loop is over (models/tts/tacotron2.py:401-406) -
                 // nothing is published any more, every wait of every workgroup ends at its next look at the stop word
-                if (bid == 64 && tid == 0 && __hip_atomic_load(p.n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= B) {
+                if (bid == 64 && tid == 0 && __hip_atomic_load(ka->n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= B) {
                     __hip_atomic_store(p.sync + HANDOFF_STOP, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ctrl + RC_ABORT, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -599,7 +603,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
                         o.y = (km & 0xff00u) ? 2.f * fmaxf(o.y, 0.f) : 0.f;
                         o.z = (km & 0xff0000u) ? 2.f * fmaxf(o.z, 0.f) : 0.f;
                         o.w = (km & 0xff000000u) ? 2.f * fmaxf(o.w, 0.f) : 0.f;
-                        const __amdgpu_buffer_rsrc_t rp = make_rsrc(p.prenet + (long)(4 * (bid - 64) + wave) * B * 8);
+                        const __amdgpu_buffer_rsrc_t rp = make_rsrc(ka->prenet + (long)(4 * (bid - 64) + wave) * B * 8);
                         store_sc1(rp, (unsigned)(bl * 8 + 4 * h) * 4u, o);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -661,11 +665,11 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
         if (AR && !ATT && slab_wave) {
             // projection slab of this tile's 8 hidden units, output dims 32 wave .. + 31 (rows past PSB: clamped, never stored), and the
             // four context columns that ride on it: weights (L2 hits) and ctx(t)[b][4 tile .. + 3]
-            const int dd = min(32 * wave + ebl, p.PSB - 1);
-            const float* wp_l = p.proj_hd_t + ((long)tile * p.PSB + dd) * 8;
+            const int dd = min(32 * wave + ebl, ka->PSB - 1);
+            const float* wp_l = ka->proj_hd_t + ((long)tile * ka->PSB + dd) * 8;
             wq_a = *reinterpret_cast<const float4*>(wp_l);
             wq_b = *reinterpret_cast<const float4*>(wp_l + 4);
-            wq_c = *reinterpret_cast<const float4*>(p.proj_ctx_t + ((long)tile * p.PSB + dd) * 4);
+            wq_c = *reinterpret_cast<const float4*>(ka->proj_ctx_t + ((long)tile * ka->PSB + dd) * 4);
             const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.hc + (long)(t + 1) * B * (RS_D + RS_E) + (long)RS_D * B + (long)(tile >> 1) * B * 8);
             xe = load_sc1(rc, (unsigned)((ebl < B ? ebl : 0) * 8 + 4 * (tile & 1)) * 4u);
         }
@@ -793,8 +797,8 @@ __device__ __forceinline__ void rs_body(const RsArgs& p, char* smem, const int b
             for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) tq[(8 * gg + 4 * eh + rr) * 32 + ebl] = qa[4 * gg + rr];
-            const int sdim = ATT ? RS_ATT : p.PSB;   // floats per slab row
-            const __amdgpu_buffer_rsrc_t rq = make_rsrc(ATT ? p.q_slab + (long)bid * B * RS_ATT + 32 * wave : p.p_slab + (long)tile * B * sdim + 32 * wave);
+            const int sdim = ATT ? RS_ATT : ka->PSB;   // floats per slab row
+            const __amdgpu_buffer_rsrc_t rq = make_rsrc(ATT ? p.q_slab + (long)bid * B * RS_ATT + 32 * wave : ka->p_slab + (long)tile * B * sdim + 32 * wave);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int row = 8 * ps + (el >> 3), c4 = el & 7;
@@ -848,9 +852,9 @@ __device__ __forceinline__ void rs_kernel_224(const RsArgs& p, char* rs_smem) {
     const int off_ctrl = kind == 0 ? RsCfg<0>::OFF_CTRL : (kind == 1 ? RsCfg<1>::OFF_CTRL : RsCfg<2>::OFF_CTRL);
     if (threadIdx.x < 64) reinterpret_cast<int*>(rs_smem + off_ctrl)[threadIdx.x] = 0;
     __syncthreads();
-    if (kind == 0) rs_body<0, false, TR>(p, rs_smem, bid);
-    else if (kind == 1) rs_body<1, false, TR>(p, rs_smem, bid);
-    else rs_body<2, false, TR>(p, rs_smem, bid);
+    if (kind == 0) rs_body<0, false, TR, !TR>(p, rs_smem, bid);
+    else if (kind == 1) rs_body<1, false, TR, !TR>(p, rs_smem, bid);
+    else rs_body<2, false, TR, !TR>(p, rs_smem, bid);
 }
 template <bool TR>
 __device__ __forceinline__ void rs_kernel_192(const RsArgs& p, char* rs_smem) {

@@ -421,8 +421,8 @@ def main():
             if lanes:
                 execution = "2 chunks x 32 rows, concurrently on 2 HIP streams, one C-ABI call each (launch per attention step)"
             elif seq32:
-                execution = ("2 chunks x 32 rows, one after the other on one stream, each beside the resident attention kernel "
-                             "(stage_ms: the second chunk's call)")
+                execution = ("2 chunks x 32 rows, one after the other on one stream, each beside the resident attention kernel; the Postnet "
+                             "once over all 64 rows behind them (stage_ms: the second chunk's call, which ends behind the projection)")
             else:
                 execution = ("ONE call: 64-row loop beside the resident attention kernel (64 CUs), 384-workgroup launches with two batch "
                              "tiles each - one pass over the recurrent weights per step for all 64 rows")

@@ -1717,7 +1717,7 @@ int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* to
                           float* gate_out, float* align_out, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_common(m, B, L, T, ws, ws_bytes);
     if (rc != GVX_OK) return rc;
-    if (!tokens || !mel_in || !keep_masks || !mel_out || !mel_post_out || !gate_out || !align_out)
+    if (!tokens || !mel_in || !keep_masks || !mel_out || !gate_out || !align_out)   // (mel_post_out may be null: no Postnet, no padding mask)
         return fail(GVX_ERR_INVALID_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const WsPlan wp = make_ws_plan(m, B, L, T);
@@ -1757,13 +1757,17 @@ int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* to
     rc = decoder_tf_impl(m, memory, token_lengths, B, L, mel_in, T, keep_masks, mel_out, gate_out, align_out, ws, wp, s, overlap);
     if (rc != GVX_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(m->ev[4], s));
-    rc = postnet_impl(m, mel_out, nullptr, B, T, mel_post_out, ws_ptr<float>(ws, wp.ya), ws_ptr<float>(ws, wp.yb), s);
-    if (rc != GVX_OK) return rc;
-    if (mel_lengths) HIP_TRY(launch_mask_padding(mel_out, mel_post_out, gate_out, mel_lengths, B, m->d.n_mels, T, s));
-    float* outs[4] = {mel_out, mel_post_out, gate_out, align_out};
+    // (mel_post_out == nullptr: the caller runs the Postnet and the padding mask itself - over all chunks of a larger batch in
+    // one call, whose GEMMs fill the chip better than a chunk's; a timed-out call's NaN in mel_out reaches them through the Postnet)
+    if (mel_post_out) {
+        rc = postnet_impl(m, mel_out, nullptr, B, T, mel_post_out, ws_ptr<float>(ws, wp.ya), ws_ptr<float>(ws, wp.yb), s);
+        if (rc != GVX_OK) return rc;
+        if (mel_lengths) HIP_TRY(launch_mask_padding(mel_out, mel_post_out, gate_out, mel_lengths, B, m->d.n_mels, T, s));
+    }
+    float* outs[4] = {mel_out, gate_out, align_out, mel_post_out};
     const size_t nm = (size_t)B * m->d.n_mels * T;
-    const size_t counts[4] = {nm, nm, (size_t)B * T, (size_t)B * T * L};
-    rc = poison_if_timed_out(m, B, L, ws, wp, outs, counts, 4, s);
+    const size_t counts[4] = {nm, (size_t)B * T, (size_t)B * T * L, nm};
+    rc = poison_if_timed_out(m, B, L, ws, wp, outs, counts, mel_post_out ? 4 : 3, s);
     if (rc != GVX_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(m->ev[5], s));
     return GVX_OK;

@@ -418,13 +418,13 @@ class Tacotron2(nn.Module):
                "gate_outputs": torch.empty(B, T, device=dev), "alignments": torch.empty(B, T, L, device=dev)}
         lib = _lib.load()
 
-        def run(lo: int, hi: int, ws: torch.Tensor, handle: int) -> None:
+        def run(lo: int, hi: int, ws: torch.Tensor, handle: int, postnet: bool = True) -> None:
             n = hi - lo
             masks = self._keep_masks(given[:, :, lo:hi].contiguous() if given is not None else None, 2 * (T + 1) * n * P, dev)
             _lib.check(lib.gvx_tacotron2_forward(
                 handle, tokens[lo:hi].data_ptr(), tok_len[lo:hi].data_ptr(), n, L, mel_in[lo:hi].data_ptr(),
                 mel_len[lo:hi].data_ptr() if self.model_config.mask_padding else None, T, masks.data_ptr(),
-                out["mel_outputs"][lo:hi].data_ptr(), out["mel_outputs_postnet"][lo:hi].data_ptr(),
+                out["mel_outputs"][lo:hi].data_ptr(), out["mel_outputs_postnet"][lo:hi].data_ptr() if postnet else None,
                 out["gate_outputs"][lo:hi].data_ptr(), out["alignments"][lo:hi].data_ptr(),
                 ws.data_ptr(), ws.numel(), self._stream()))
 
@@ -448,9 +448,18 @@ class Tacotron2(nn.Module):
         if sequential:   # chunks of at most `rows` rows, one after the other on the caller's stream
             n_chunks = -(-B // rows)
             bounds = [(B * i) // n_chunks for i in range(n_chunks + 1)]
-            ws = self._get_workspace(max(hi - lo for lo, hi in zip(bounds, bounds[1:])), L, T)
+            # (one workspace for the chunks' calls and the Postnet over all rows behind them)
+            ws = self._workspace_of(max(lib.gvx_workspace_bytes(self._handle, max(hi - lo for lo, hi in zip(bounds, bounds[1:])), L, T),
+                                        lib.gvx_postnet_workspace_bytes(self._handle, B, T)))
+            # the Postnet and the padding mask once over all rows, behind the chunks' decoder loops: its GEMMs fill the chip better on
+            # B x T frames than on a chunk's (models/tts/tacotron2.py:464-473 in the same order: Postnet on the unmasked mel, then the mask)
             for lo, hi in zip(bounds, bounds[1:]):
-                run(lo, hi, ws, self._handle)
+                run(lo, hi, ws, self._handle, postnet=False)
+            _lib.check(lib.gvx_postnet_forward(self._handle, out["mel_outputs"].data_ptr(), None, B, T, out["mel_outputs_postnet"].data_ptr(),
+                                               ws.data_ptr(), ws.numel(), self._stream()))
+            if self.model_config.mask_padding:
+                _lib.check(lib.gvx_mask_padding(out["mel_outputs"].data_ptr(), out["mel_outputs_postnet"].data_ptr(), out["gate_outputs"].data_ptr(),
+                                                mel_len.data_ptr(), B, M, T, self._stream()))
             return out
         # chunks of near-equal size, alternating over two streams (rows never interact, so the split is invisible in the
         # results); the caller's stream waits for both lanes before anything downstream may touch the outputs

@@ -204,7 +204,9 @@ int gvx_mask_padding(float* mel, float* mel_post, float* gate, const int32_t* me
                      int B, int n_mels, int T, void* stream);
 
 /* ---- Whole teacher-forced forward in one call (what Tacotron2.forward does, models/tts/tacotron2.py:450-481).
- * mel_lengths may be NULL (no padding mask). */
+ * mel_lengths may be NULL (no padding mask).  mel_post_out may be NULL: the call then ends behind the mel / gate projection
+ * (mel_out, gate_out, align_out unmasked) and the caller runs gvx_postnet_forward + gvx_mask_padding itself - once over all
+ * 32-row chunks of a larger batch, for instance. */
 int gvx_tacotron2_forward(gvx_model* model, const int64_t* tokens, const int32_t* token_lengths, int B, int L,
                           const float* mel_in, const int32_t* mel_lengths, int T, const uint8_t* keep_masks,
                           float* mel_out, float* mel_post_out, float* gate_out, float* align_out,

@@ -15,6 +15,7 @@
 //   <2,2,2,2>: 128x128 tile, each of four waves 64x64               - its predecessor (GVX_GEMM_8W=0) and the K-major form
 //   <2,2,1,2> / <2,2,1,1>: 64x128 / 64x64 tiles of four waves       - few tiles (encoder convolutions), remainders
 //   <4,1,1,3>: 128x96 tile, each wave 32x96 (1x3 MFMA tiles)        - N <= 96 (the last Postnet conv, the mel / gate projection)
+//   <2,3,1,1>: 64x96 tile of six waves, each 32x32                  - N <= 96 and few rows (a wave's MFMA chain is the launch)
 //   <4,1,1,1>: 128x32                                              - N <= 32
 // Eight waves instead of four on the big tile: two waves per SIMD inside ONE workgroup - a workgroup's epilogue (64 KB of
 // stores) and its barrier waits run beside another wave's products (the attention LSTM's Prenet columns, K = 256 and 419 MB
@@ -291,6 +292,8 @@ hipError_t gemm_init() {
     if (e != hipSuccess) return e;
     e = init_cfg<4, 1, 1, 3>();
     if (e != hipSuccess) return e;
+    e = init_cfg<2, 3, 1, 1>();
+    if (e != hipSuccess) return e;
     e = init_cfg<4, 2, 1, 2>();
     if (e != hipSuccess) return e;
     e = init_cfg<2, 2, 1, 1>();
@@ -325,7 +328,13 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     }
     if (p.K & 3) return hipErrorInvalidValue;
     if (p.N <= 32) return launch_cfg<4, 1, 1, 1>(p, s);
-    if (p.N <= 96) return launch_cfg<4, 1, 1, 3>(p, s);
+    if (p.N <= 96) {
+        // few rows (a single utterance: 568 frames = 5 tiles of 128 rows): the launch lasts as long as ONE wave's chain of dependent
+        // MFMAs over K - three accumulators per wave in the 128 x 96 tile (151 us for the last Postnet convolution on 800 frames),
+        // one in the 64 x 96 tile of six waves.  Many rows: the six-wave tile is no faster (MFMA busy 0.40 vs 0.44, round 4)
+        if (p.M - p.m_begin <= 4096) return launch_cfg<2, 3, 1, 1>(p, s);
+        return launch_cfg<4, 1, 1, 3>(p, s);
+    }
     // fewer than ~1.5 workgroups per CU with 128 x 128 tiles (encoder convolutions: 4096 x 512): halve the tile height so
     // that all 256 CUs get work
     const long n_tiles = (p.N + 127) / 128, tiles128 = (long)((p.M + 127) / 128) * n_tiles;

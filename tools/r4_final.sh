@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4, final tree: smoke, the whole GPU suite, the bench line as the driver runs it, rocprofv3's kernel summary of the headline
-# configuration, rows of 190 / 256 tokens, stamps of both resident loops
+# configuration, rows of 190 / 256 tokens, stamps of both resident loops (the stamps steps need the diagnostic library:
+# `python -m genvox_amd.build --stamps` in the container before the run - build() removes one older than the C ABI's header)
 set -u
 : "${GRAFT_REPO_ROOT:?}"
 cd "$GRAFT_REPO_ROOT"

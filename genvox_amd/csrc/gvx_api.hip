@@ -1737,7 +1737,8 @@ int gvx_tacotron2_forward(gvx_model* m, const int64_t* tokens, const int32_t* to
         // The Prenet products start behind the FIRST encoder convolution (enc_fork_after): side by side from the start the two sets
         // of GEMMs slow each other and leave the second half of the recurrence - a quarter of the chip, latency bound - alone on
         // an idle GPU; behind all three convolutions the `pre_gate` GEMM outlasts the recurrence (encoder stage 1.335 / 1.31 / 1.28 /
-        // 1.335 ms for the fork behind 3 / 2 / 1 / 0 convolutions, tools/r4_enc2.sh)
+        // 1.335 ms for the fork behind 3 / 2 / 1 / 0 convolutions with four-wave GEMM tiles; 1.14 / 1.13 / 1.15 / 1.22 with eight-wave ones:
+        // tools/r4_enc2.sh)
         rc = encoder_impl(m, tokens, token_lengths, B, L, memory, ws, wp, m->pa_stream, nullptr, nullptr, nullptr, m->enc_mid);
         if (rc != GVX_OK) return rc;
         // the decoder's zero states and the memory projection (needs the encoder output) right behind the encoder on its stream:
